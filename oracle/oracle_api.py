@@ -1,0 +1,236 @@
+"""ORACLE (test infrastructure, NOT product code) -- ctypes wrapper over oracle/liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  It
+implements the same scene-builder protocol as the product's host wrapper
+(ray-and-pathtracer_amd/host_api.py), so one scene definition drives both sides.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+COUNTER_NAMES = ["inner_visits", "prim_tests", "tlas_inner", "instance_visits",
+                 "rays_nearest", "rays_occluded", "brute_tests", "light_tests"]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".h", ".cpp"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_scene_new.restype = C.c_void_p
+        L.orc_renderer_new.restype = C.c_void_p
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_intersect_aabb.restype = C.c_float
+        _LIB = L
+    return _LIB
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleScene:
+    """Scene builder + queries over the CPU restatement (oracle)."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.orc_scene_new())
+        self.n_instances = 0
+
+    def close(self):
+        if self.h:
+            self.L.orc_scene_free(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError(self.L.orc_last_error(self.h).decode())
+        return rc
+
+    # ---- builder protocol ----
+    def diffuse(self, albedo, col, ks=0.2, kd=0.8, n=2, emission=0.0, shininess=0.0, rt=True):
+        a = albedo if hasattr(albedo, "__len__") else (albedo,) * 3
+        return self.L.orc_add_diffuse(self.h, _f3(a), _f3(col), C.c_float(ks), C.c_float(kd), int(n),
+                                      C.c_float(emission), C.c_float(shininess), int(rt))
+
+    def metal(self, fuzzy, col, rt=True):
+        return self.L.orc_add_metal(self.h, C.c_float(fuzzy), _f3(col), int(rt))
+
+    def glass(self, ir, col, absorption=(0, 0, 0), rt=True):
+        return self.L.orc_add_glass(self.h, C.c_float(ir), _f3(col), _f3(absorption), int(rt))
+
+    def area_light(self, idx, pos, strength, col, radius, normal):
+        return self.L.orc_add_area_light(self.h, idx, _f3(pos), C.c_float(strength), _f3(col), C.c_float(radius), _f3(normal))
+
+    def dir_light(self, idx, pos, strength, col, normal, r):
+        return self.L.orc_add_dir_light(self.h, idx, _f3(pos), C.c_float(strength), _f3(col), _f3(normal), C.c_float(r))
+
+    def sphere(self, idx, mat, pos, r):
+        return self.L.orc_add_sphere(self.h, idx, mat, _f3(pos), C.c_float(r))
+
+    def plane(self, idx, mat, N, d):
+        return self.L.orc_add_plane(self.h, idx, mat, _f3(N), C.c_float(d))
+
+    def mesh_raw(self, group, mat, v9):
+        v9 = np.ascontiguousarray(v9, dtype=np.float32).reshape(-1, 9)
+        return self.L.orc_add_mesh_raw(self.h, group, mat, _p(v9), len(v9))
+
+    def mesh_obj(self, group, path, mat, pos, scale):
+        return self._chk(self.L.orc_add_mesh_obj(self.h, group, path.encode(), mat, _f3(pos), C.c_float(scale)))
+
+    def mesh_tri(self, group, path, mat):
+        return self._chk(self.L.orc_add_mesh_tri(self.h, group, path.encode(), mat))
+
+    def sky(self, pixels):
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        hgt, w, n = px.shape
+        self.L.orc_set_sky(self.h, w, hgt, n, _p(px))
+
+    def trs(self, t, s, rx, ry, rz):
+        out = np.zeros(16, dtype=np.float32)
+        self.L.orc_mat4_trs(_f3(t), C.c_float(s), C.c_float(rx), C.c_float(ry), C.c_float(rz), _p(out))
+        return out
+
+    def build(self, split=0):
+        self._chk(self.L.orc_build(self.h, split))
+
+    def build_tlas(self, split, instances):
+        idx = np.array([i for i, _ in instances], dtype=np.int32)
+        T = np.ascontiguousarray(np.stack([np.asarray(t, dtype=np.float32).reshape(16) for _, t in instances]))
+        self._chk(self.L.orc_build_tlas(self.h, split, len(idx), _p(idx), _p(T)))
+        self.n_instances = len(idx)
+
+    def set_raytracer(self, rt):
+        self.L.orc_set_raytracer(self.h, int(rt))
+
+    # ---- dumps ----
+    def mesh_tris(self, mesh):
+        n = self.L.orc_mesh_count(self.h, mesh)
+        out = np.zeros((n, 15), dtype=np.float32)
+        ids = np.zeros(n, dtype=np.int32)
+        self.L.orc_mesh_get(self.h, mesh, _p(out), _p(ids))
+        return out, ids
+
+    def bvh_dump(self, blas=-1):
+        info = (C.c_int * 7)()
+        self.L.orc_bvh_info(self.h, blas, info)
+        nodes = np.zeros((info[0], 8), dtype=np.uint32)
+        prim = np.zeros(info[1], dtype=np.uint32)
+        self.L.orc_bvh_get(self.h, blas, _p(nodes), _p(prim))
+        return dict(nodes=nodes, prim_idx=prim, nodes_used=info[0], N=info[1], NTri=info[2], NSph=info[3],
+                    NPla=info[4], max_depth=info[5])
+
+    def blas_count(self):
+        return self.L.orc_blas_count(self.h)
+
+    def tlas_dump(self):
+        n = self.L.orc_tlas_nodes_used(self.h)
+        nodes = np.zeros((n, 8), dtype=np.uint32)
+        self.L.orc_tlas_get(self.h, _p(nodes))
+        return nodes
+
+    def instance_dump(self, i):
+        blas = C.c_int()
+        T = np.zeros(16, dtype=np.float32)
+        iT = np.zeros(16, dtype=np.float32)
+        b = np.zeros(6, dtype=np.float32)
+        self.L.orc_instance_get(self.h, i, C.byref(blas), _p(T), _p(iT), _p(b))
+        return dict(blas=blas.value, T=T, invT=iT, bounds=b)
+
+    # ---- queries ----
+    def find_nearest(self, O, D, tmax=None, t_min=1e-6):
+        O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        n = len(O)
+        t = np.zeros(n, dtype=np.float32)
+        obj = np.zeros(n, dtype=np.int32)
+        mat = np.zeros(n, dtype=np.int32)
+        nrm = np.zeros((n, 3), dtype=np.float32)
+        cnt = np.zeros(8, dtype=np.uint64)
+        tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
+        self.L.orc_find_nearest_batch(self.h, n, _p(O), _p(D), tm, C.c_float(t_min), _p(t), _p(obj), _p(mat), _p(nrm), _p(cnt))
+        return dict(t=t, obj=obj, mat=mat, normal=nrm, counters=dict(zip(COUNTER_NAMES, cnt.tolist())))
+
+    def is_occluded(self, O, D, tmax=None):
+        O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        n = len(O)
+        out = np.zeros(n, dtype=np.uint8)
+        cnt = np.zeros(8, dtype=np.uint64)
+        tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
+        self.L.orc_is_occluded_batch(self.h, n, _p(O), _p(D), tm, _p(out), _p(cnt))
+        return dict(occluded=out, counters=dict(zip(COUNTER_NAMES, cnt.tolist())))
+
+
+class OracleRenderer:
+    """Renderer::Tick pixel loop over an OracleScene (per-pixel RNG streams)."""
+
+    def __init__(self, scene, width, height):
+        self.L = lib()
+        self.scene = scene
+        self.w, self.hgt = width, height
+        self.h = C.c_void_p(self.L.orc_renderer_new(scene.h, width, height))
+
+    def close(self):
+        if self.h:
+            self.L.orc_renderer_free(self.h)
+            self.h = None
+
+    def set_camera(self, cam_pos, top_left, top_right, bottom_left, fisheye=False, view_angle=0.25, y_angle=0.0):
+        self.L.orc_renderer_set_camera(self.h, _f3(cam_pos), _f3(top_left), _f3(top_right), _f3(bottom_left),
+                                       int(fisheye), C.c_float(view_angle), C.c_float(y_angle))
+
+    def camera(self):
+        out = np.zeros(12, dtype=np.float32)
+        self.L.orc_renderer_get_camera(self.h, _p(out))
+        return out.reshape(4, 3)
+
+    def clear(self):
+        self.L.orc_renderer_clear(self.h)
+
+    def render(self, frame0=0, nframes=1, seed_base=0x12345678, y0=0, y1=None, nthreads=1, max_depth=4):
+        cnt = np.zeros(8, dtype=np.uint64)
+        self.L.orc_render(self.h, C.c_uint(frame0), nframes, C.c_uint(seed_base), y0, self.hgt if y1 is None else y1,
+                          nthreads, max_depth, _p(cnt))
+        return dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+    def accumulator(self):
+        out = np.zeros((self.hgt, self.w, 4), dtype=np.float32)
+        self.L.orc_get_accumulator(self.h, _p(out))
+        return out
+
+    def resolve(self, it=1):
+        out = np.zeros((self.hgt, self.w), dtype=np.uint32)
+        self.L.orc_resolve(self.h, it, _p(out))
+        return out
+
+    def primary_hits(self, t_min=1e-6):
+        obj = np.zeros((self.hgt, self.w), dtype=np.int32)
+        t = np.zeros((self.hgt, self.w), dtype=np.float32)
+        cnt = np.zeros(8, dtype=np.uint64)
+        self.L.orc_primary_hits(self.h, C.c_float(t_min), _p(obj), _p(t), _p(cnt))
+        return obj, t, dict(zip(COUNTER_NAMES, cnt.tolist()))
+
+    def primary_rays(self):
+        O = np.zeros((self.hgt * self.w, 3), dtype=np.float32)
+        D = np.zeros((self.hgt * self.w, 3), dtype=np.float32)
+        self.L.orc_primary_rays(self.h, _p(O), _p(D))
+        return O, D

@@ -1,0 +1,107 @@
+"""Mesh fixtures: the reference's Resources/*.obj and unity.tri as numbers (assets/*.npz, packed by
+tests/golden/make_assets.py), re-emitted as text files in the two dialects the reference's Mesh
+loaders read (template/scene.h:261-313) so the host loaders parse real files.
+
+'%.9g' round-trips float32 exactly, so a loader using strtof semantics recovers the packed values.
+"""
+import os
+import tempfile
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+_CACHE = None
+
+
+def _cache_dir():
+    global _CACHE
+    if _CACHE is None:
+        _CACHE = tempfile.mkdtemp(prefix="rapt_assets_")
+    return _CACHE
+
+
+def obj_arrays(name):
+    z = np.load(os.path.join(_DIR, name + "_obj.npz"))
+    return z["v"], z["f"]
+
+
+def tri_rows(name):
+    return np.load(os.path.join(_DIR, name + "_tri.npz"))["rows"]
+
+
+def write_obj(path, v, f):
+    with open(path, "w") as fh:
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+        for t in f:
+            fh.write("f %d//%d %d//%d %d//%d\n" % (t[0], t[0], t[1], t[1], t[2], t[2]))
+
+
+def write_tri(path, rows, trailing_newline=False):
+    # unity.tri ends without a newline after its sentinel record; keep that shape
+    with open(path, "w") as fh:
+        fh.write("\n".join(" ".join("%.9g" % x for x in r) for r in rows))
+        if trailing_newline:
+            fh.write("\n")
+
+
+def obj_path(name):
+    """Path of a text .obj file for fixture `name` (ico, three, stellatedDode, lowBigB, BigB)."""
+    p = os.path.join(_cache_dir(), name + ".obj")
+    if not os.path.exists(p):
+        v, f = obj_arrays(name)
+        write_obj(p, v, f)
+    return p
+
+
+def tri_path(name):
+    """Path of a text .tri file for fixture `name` (unity)."""
+    p = os.path.join(_cache_dir(), name + ".tri")
+    if not os.path.exists(p):
+        write_tri(p, tri_rows(name))
+    return p
+
+
+def synthetic_sky(width=512, height=256, seed=7):
+    """Seeded 8-bit lat-long sky texture standing in for the missing Resources/*.hdr files
+    (.MISSING_LARGE_BLOBS): vertical gradient + sun blob + low-frequency noise, RGB uint8."""
+    rng = np.random.default_rng(seed)
+    y = np.linspace(0.0, 1.0, height, dtype=np.float32)[:, None]
+    x = np.linspace(0.0, 1.0, width, dtype=np.float32)[None, :]
+    top = np.array([70, 120, 220], dtype=np.float32)
+    hor = np.array([225, 225, 235], dtype=np.float32)
+    gnd = np.array([90, 80, 70], dtype=np.float32)
+    img = np.where(y[..., None] < 0.5, top + (hor - top) * (y[..., None] * 2), hor + (gnd - hor) * ((y[..., None] - 0.5) * 2))
+    img = np.broadcast_to(img, (height, width, 3)).copy()
+    sun = np.exp(-(((x - 0.7) * 6) ** 2 + ((y - 0.25) * 8) ** 2))
+    img += sun[..., None] * 60
+    noise = rng.normal(0, 1, (height // 16 + 1, width // 16 + 1)).astype(np.float32)
+    noise = np.kron(noise, np.ones((16, 16), dtype=np.float32))[:height, :width]
+    img += noise[..., None] * 6
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def lattice_tower(levels=40, sides=12, seed=3):
+    """Procedural stand-in for the missing eifel.obj: a tapering lattice tower of thin triangular
+    struts.  Returns float32 [n, 9] triangles; n = levels * sides * 8."""
+    rng = np.random.default_rng(seed)
+    tris = []
+    def ring(k):
+        h = k / levels
+        r = 1.2 * (1 - h) ** 1.6 + 0.05
+        a = np.arange(sides) * (2 * np.pi / sides) + 0.15 * k
+        return np.stack([r * np.cos(a), np.full(sides, 6.0 * h), r * np.sin(a)], axis=1)
+    def strut(p, q, w):
+        d = q - p
+        n = np.cross(d, rng.normal(size=3))
+        n = n / (np.linalg.norm(n) + 1e-9) * w
+        tris.append(np.concatenate([p - n, p + n, q + n]))
+        tris.append(np.concatenate([p - n, q + n, q - n]))
+    for k in range(levels):
+        a, b = ring(k), ring(k + 1)
+        for s in range(sides):
+            s2 = (s + 1) % sides
+            strut(a[s], b[s], 0.02)
+            strut(a[s], a[s2], 0.02)
+            strut(a[s], b[s2], 0.015)
+            strut(a[s2], b[s], 0.015)
+    return np.array(tris, dtype=np.float32)
