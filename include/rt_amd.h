@@ -1,0 +1,190 @@
+/* rt_amd.h -- C ABI of the MI355X trace-loop library (librt_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Fannollost/Ray-and-pathtracer: the per-pixel
+ * trace loop.  The reference has no device boundary (everything is one address space); this
+ * library inserts one at the `#pragma omp parallel for` line of Renderer::Tick
+ * (renderer.cpp:259): one rt_render() call replaces the whole parallel region, and the batch
+ * queries replace Scene::FindNearest / Scene::IsOccluded.  Citations are file:line in the
+ * reference repository.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every call returns 0 on success or a
+ * negative rt_status; rt_last_error() gives the text.  The caller owns every host buffer.  A
+ * context is bound to one GPU and is NOT thread-safe (one host thread per context, one context per
+ * GPU).  The library never falls back to a CPU path: without a usable gfx950 device rt_create()
+ * fails.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum {
+	RT_OK = 0,
+	RT_E_NODEVICE = -1,    /* no HIP device / not gfx950 */
+	RT_E_ARG = -2,         /* bad argument */
+	RT_E_HIP = -3,         /* HIP runtime error */
+	RT_E_UNSUPPORTED = -4, /* scene feature outside the device path (see rt_upload_scene) */
+	RT_E_STATE = -5,       /* call order (e.g. render before upload) */
+	RT_E_OVERFLOW = -6     /* traversal stack deeper than 64 (the reference's stack[64], bvh.cpp:608) */
+} rt_status;
+
+/* ---- scene records -------------------------------------------------------------------------
+ * Shapes follow the reference's own structures so a binding can fill them with a few loops.
+ * 'material' fields are indices into rt_scene_desc.materials (the reference stores material*). */
+
+/* BVHNode (bvh.h:10-24), 32 bytes, identical layout. leaf: prim_count > 0, left_first = first
+ * entry in prim_idx; inner: prim_count == 0, children at left_first and left_first + 1. */
+typedef struct { float aabb_min[3]; uint32_t left_first; float aabb_max[3]; uint32_t prim_count; } rt_bvh_node;
+
+/* TLASNode (tlas.h:4-11), 32 bytes, identical layout. leaf: left_right == 0, blas = instance
+ * index; inner: children = left_right & 0xFFFF and left_right >> 16. Node 0 is the root. */
+typedef struct { float aabb_min[3]; uint32_t left_right; float aabb_max[3]; uint32_t blas; } rt_tlas_node;
+
+/* Triangle (template/scene.h:175-251): v0, v1, v2, N, objIdx, mat (e1, e2, centroid are derived) */
+typedef struct { float v0[3], v1[3], v2[3], N[3]; int32_t obj_idx; int32_t material; } rt_triangle;
+/* Sphere (template/scene.h:347-394) */
+typedef struct { float pos[3]; float r2, invr, r; int32_t obj_idx; int32_t material; } rt_sphere;
+/* Plane (template/scene.h:401-448) */
+typedef struct { float N[3]; float d; int32_t obj_idx; int32_t material; } rt_plane;
+
+/* Light / AreaLight / DirectionalLight (template/scene.h:75-168) */
+enum { RT_LIGHT_AREA = 0, RT_LIGHT_DIRECTIONAL = 1, RT_LIGHT_BASE = 2 };
+typedef struct {
+	int32_t kind; int32_t obj_idx;
+	float pos[3]; float strength; float col[3]; float normal[3];
+	float radius;    /* AreaLight */
+	float sin_angle; /* DirectionalLight */
+} rt_light;
+
+/* material / diffuse / metal / glass (template/scene.h:582-676) */
+enum { RT_MAT_DIFFUSE = 1, RT_MAT_METAL = 2, RT_MAT_GLASS = 3 };
+typedef struct {
+	int32_t type;
+	int32_t raytracer; /* material::raytracer as captured at construction */
+	float col[3], albedo[3];
+	float specu, diffu, shinieness; int32_t N; /* diffuse */
+	float ir; float absorption[3];           /* glass */
+} rt_material;
+
+/* One bvh object (bvh.h:45-86): node array, primitiveIdx, and the primitive arrays it indexes.
+ * prim_idx values < n_tri address triangles, then spheres, then planes (bvh.cpp:618-627).
+ * A mesh BVH (bvh(Mesh*)) has n_sph = n_pla = 0. */
+typedef struct {
+	const rt_bvh_node* nodes; uint32_t nodes_used;
+	const uint32_t* prim_idx; uint32_t n_prims;
+	const rt_triangle* tris; uint32_t n_tri;
+	const rt_sphere* spheres; uint32_t n_sph;
+	const rt_plane* planes; uint32_t n_pla;
+} rt_blas;
+
+/* bvhInstance (bvhInstance.h): BLAS index + matTransform + invTransform (row-major mat4) */
+typedef struct { int32_t blas; float transform[16]; float inv_transform[16]; } rt_instance;
+
+typedef struct {
+	/* use_tlas == 0 (template/scene.h:1388): blas[0] is the scene BVH, nothing else is used.
+	 * use_tlas != 0: tlas_nodes/instances/blas[] are traversed, brute_spheres/brute_planes are
+	 * tested by brute force in FindNearest and ignored by IsOccluded (template/scene.h:1259-1263,
+	 * 1288). */
+	int32_t use_tlas;
+	const rt_blas* blas; uint32_t n_blas;
+	const rt_instance* instances; uint32_t n_instances;
+	const rt_tlas_node* tlas_nodes; uint32_t tlas_nodes_used;
+	const rt_sphere* brute_spheres; uint32_t n_brute_spheres;
+	const rt_plane* brute_planes; uint32_t n_brute_planes;
+	const rt_light* lights; uint32_t n_lights;
+	const rt_material* materials; uint32_t n_materials;
+	/* skydome as loaded by stbi_load(..., 3): 8-bit, sky_n channels (template/scene.h:1312-1327).
+	 * sky_pixels == NULL: misses return black. */
+	const uint8_t* sky_pixels; int32_t sky_w, sky_h, sky_n;
+} rt_scene_desc;
+
+/* Camera state read by Camera::GetPrimaryRay (camera.h:24-52) */
+typedef struct {
+	float cam_pos[3], top_left[3], top_right[3], bottom_left[3];
+	int32_t fisheye; float view_angle; float y_angle;
+} rt_camera;
+
+/* result of one nearest-hit query: the fields Scene::FindNearest leaves in the Ray
+ * (template/scene.h:66-72): t, objIdx (-1 = miss), material index, hitNormal */
+typedef struct { float t; int32_t obj_idx; int32_t material; float normal[3]; } rt_hit;
+
+/* work counters = the reference's DataCollector tallies (bvh.cpp:610-631) plus ray counts */
+typedef struct {
+	uint64_t inner_visits, prim_tests, tlas_inner, instance_visits;
+	uint64_t rays_nearest, rays_occluded, brute_tests, light_tests;
+} rt_counters;
+
+/* per-kernel device time, measured with HIP events on the context's stream */
+typedef struct { uint64_t launches; double ms; } rt_kernel_time;
+typedef struct { rt_kernel_time generate, extend, shade, connect, query; } rt_profile;
+
+enum { RT_MODE_WHITTED = 0, RT_MODE_PATH = 1 };
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int rt_device_count(void);
+/* Replaces Renderer::Init (renderer.cpp:5-11): allocates the float4 accumulator [width*height] in
+ * HBM (zeroed) plus the path-state arrays.  Returns NULL on failure (rt_last_error(NULL)). */
+rt_ctx* rt_create(int device, int width, int height);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* ---- scene / camera -------------------------------------------------------------------------- */
+/* Copies the scene into HBM in the traversal layout.  Replaces the pointers Scene keeps to
+ * bvh / tlas / bvhInstance / primitive vectors (template/scene.h:1371-1378).
+ * RT_E_UNSUPPORTED: more than 8 lights, or a TLAS with more than 256 instances. */
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* desc);
+int rt_set_camera(rt_ctx* ctx, const rt_camera* cam);
+
+/* ---- the pixel loop ---------------------------------------------------------------------------- */
+/* Replaces the pixel loop of Renderer::Tick (renderer.cpp:259-285) for frames
+ * [frame0, frame0 + nframes) and rows [y0, y1): per pixel, Camera::GetPrimaryRay then
+ * Renderer::Trace (mode RT_MODE_WHITTED, renderer.cpp:21-126; nframes must be 1) or
+ * Renderer::Sample (RT_MODE_PATH, renderer.cpp:128-236), accumulated into the accumulator exactly
+ * as :270 / :279-282 do.  The random stream of pixel p in frame f starts at
+ * InitSeed(seed_base + p + f*width*height) (template/template.cpp:680-683).
+ * max_depth is the depth argument of Trace (4 at renderer.cpp:269); Sample always starts at 4.
+ * RT_E_UNSUPPORTED in RT_MODE_PATH when a diffuse material has shinieness != 0 or
+ * raytracer == 0 (their draws interleave with shadow queries). */
+int rt_render(rt_ctx* ctx, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int y0, int y1, int max_depth);
+/* memset of the accumulator (renderer.cpp:9, :274) */
+int rt_clear(rt_ctx* ctx);
+/* rows [y0, y1) of the float4 accumulator -> host (Renderer::accumulator, renderer.h:98) */
+int rt_download_accumulator(rt_ctx* ctx, int y0, int y1, float* out);
+/* screen->pixels for rows [y0, y1): RGBF32_to_RGB8(accumulator / iteration) (renderer.cpp:287-290,
+ * template/precomp.h:445-448) */
+int rt_resolve(rt_ctx* ctx, int iteration, int y0, int y1, uint32_t* rgb8_out);
+/* Device address of the accumulator (width*height float4), and rebinding it to caller-owned device
+ * memory (e.g. a torch tensor handed to an RCCL gather).  The caller keeps that memory alive. */
+void* rt_accumulator_device_ptr(rt_ctx* ctx);
+int rt_bind_accumulator(rt_ctx* ctx, void* device_ptr);
+
+/* ---- batch queries ---------------------------------------------------------------------------- */
+/* Scene::FindNearest(ray, t_min) (template/scene.h:1248-1267) for n rays. O, D: n*3 floats;
+ * tmax: n floats or NULL (1e34f, the Ray constructor default, template/scene.h:42). */
+int rt_intersect_batch(rt_ctx* ctx, int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out);
+/* Scene::IsOccluded(ray) (template/scene.h:1286-1291) for n rays; out[i] = 0 / 1 */
+int rt_occluded_batch(rt_ctx* ctx, int n, const float* O, const float* D, const float* tmax, uint8_t* out);
+/* Camera::GetPrimaryRay(x, y) + Scene::FindNearest(t_min) for every pixel ("primary rays only") */
+int rt_primary_hits(rt_ctx* ctx, float t_min, int32_t* obj_idx_out, float* t_out);
+/* Renderer::Trace / Renderer::Sample on caller-supplied rays: rgb_out[n*3].  Stream i starts at
+ * InitSeed(seed_base + i). */
+int rt_trace_batch(rt_ctx* ctx, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, float* rgb_out);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* counting != 0: kernels tally rt_counters (slower; keep off when timing) */
+int rt_set_counting(rt_ctx* ctx, int counting);
+int rt_get_counters(rt_ctx* ctx, rt_counters* out, int reset);
+/* profiling != 0: HIP events bracket every kernel launch on the context's stream */
+int rt_set_profiling(rt_ctx* ctx, int profiling);
+int rt_get_profile(rt_ctx* ctx, rt_profile* out, int reset);
+int rt_synchronize(rt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

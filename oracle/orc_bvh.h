@@ -197,7 +197,7 @@ struct bvh {
 					rightCount++;
 					rightBox.grow(triangle.v0); rightBox.grow(triangle.v1); rightBox.grow(triangle.v2);
 				}
-			} else if (primIdx >= NTri && primIdx < N) {
+			} else if (primIdx >= NTri && primIdx < NTri + NSph) { // the reference tests '< N' and would index past the spheres for a plane
 				primIdx -= NTri;
 				const Sphere& sphere = scene->spheres[primIdx];
 				// the reference grows by the scalar pos[axis] -/+ r broadcast to all three axes
@@ -300,10 +300,13 @@ struct bvh {
 			if (primIdx < NTri) {
 				if (getTriangle(primIdx).centroid[axis] < splitPos) i++;
 				else std::swap(primitiveIdx[i], primitiveIdx[j--]);
-			} else if (primIdx >= NTri && primIdx < N) {
+			} else if (primIdx >= NTri && primIdx < NTri + NSph) {
 				primIdx -= NTri;
 				if (scene->spheres[primIdx].pos[axis] < splitPos) i++;
 				else std::swap(primitiveIdx[i], primitiveIdx[j--]);
+			} else {
+				// a plane: the reference ('< N') indexes past its sphere array here; defined as "goes right"
+				std::swap(primitiveIdx[i], primitiveIdx[j--]);
 			}
 		}
 		int leftCount = i - first;

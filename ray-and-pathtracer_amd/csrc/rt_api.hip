@@ -1,0 +1,679 @@
+// librt_amd.so: implementation of the C ABI in include/rt_amd.h for gfx950.
+// Host part: context, repacking of the reference-shaped scene arrays into the HBM traversal layout
+// (rt_scene_dev.h), the round loop of the wavefront pixel loop, batch queries, counters, profiling.
+#include "rt_kernels.h"
+#include "../../include/rt_amd.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rtd;
+
+static std::string g_err;
+
+struct Timer {
+	hipEvent_t a = nullptr, b = nullptr;
+};
+
+struct rt_ctx {
+	int device = 0, width = 0, height = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	// scene
+	DScene S;
+	bool sceneLoaded = false;
+	std::vector<void*> sceneAllocs;
+	bool pathUnsupported = false; // shiny or rt==0 diffuse present
+	std::string pathUnsupportedWhy;
+	// camera
+	DCamera C;
+	bool cameraSet = false;
+	// accumulator
+	float4* accum = nullptr;
+	bool accumOwned = true;
+	// path state for the current tile size
+	PathState P;
+	Queues Q;
+	int stateSlots = 0, stateLights = -1;
+	bool statePend = false;
+	std::vector<void*> stateAllocs;
+	// traversal stack spill + flags
+	uint* spill = nullptr;
+	int gridBlocks = 0;
+	int* flags = nullptr; // [0] overflow for batch queries
+	DCounters* counters = nullptr;
+	bool counting = false, profiling = false;
+	rt_profile prof;
+	std::vector<Timer> timers; // pending event pairs, resolved lazily
+	std::vector<int> timerKind;
+	int* hostCounts = nullptr; // pinned
+};
+
+static int fail(rt_ctx* c, int code, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	if (c) c->err = buf; else g_err = buf;
+	return code;
+}
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, RT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+template <typename T>
+static hipError_t dalloc(std::vector<void*>& pool, T** p, size_t count)
+{
+	void* q = nullptr;
+	hipError_t e = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+	if (e == hipSuccess) { pool.push_back(q); *p = (T*)q; }
+	return e;
+}
+static void free_pool(std::vector<void*>& pool)
+{
+	for (void* p : pool) (void)hipFree(p);
+	pool.clear();
+}
+
+// ---- profiling helpers ---------------------------------------------------------------------
+enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_CONNECT, K_QUERY };
+static void prof_begin(rt_ctx* c, int kind)
+{
+	if (!c->profiling) return;
+	Timer t;
+	(void)hipEventCreate(&t.a);
+	(void)hipEventCreate(&t.b);
+	(void)hipEventRecord(t.a, c->stream);
+	c->timers.push_back(t);
+	c->timerKind.push_back(kind);
+}
+static void prof_end(rt_ctx* c)
+{
+	if (!c->profiling) return;
+	(void)hipEventRecord(c->timers.back().b, c->stream);
+}
+static void prof_collect(rt_ctx* c)
+{
+	if (c->timers.empty()) return;
+	(void)hipStreamSynchronize(c->stream);
+	rt_kernel_time* slot[5] = { &c->prof.generate, &c->prof.extend, &c->prof.shade, &c->prof.connect, &c->prof.query };
+	for (size_t i = 0; i < c->timers.size(); i++) {
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, c->timers[i].a, c->timers[i].b);
+		slot[c->timerKind[i]]->launches++;
+		slot[c->timerKind[i]]->ms += ms;
+		(void)hipEventDestroy(c->timers[i].a);
+		(void)hipEventDestroy(c->timers[i].b);
+	}
+	c->timers.clear();
+	c->timerKind.clear();
+}
+
+extern "C" {
+
+int rt_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+rt_ctx* rt_create(int device, int width, int height)
+{
+	if (width <= 0 || height <= 0) { fail(nullptr, RT_E_ARG, "rt_create: bad size %dx%d", width, height); return nullptr; }
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { fail(nullptr, RT_E_NODEVICE, "rt_create: no HIP device (this library has no CPU path)"); return nullptr; }
+	if (device < 0 || device >= n) { fail(nullptr, RT_E_ARG, "rt_create: device %d of %d", device, n); return nullptr; }
+	if (hipSetDevice(device) != hipSuccess) { fail(nullptr, RT_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(nullptr, RT_E_HIP, "hipGetDeviceProperties failed"); return nullptr; }
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { fail(nullptr, RT_E_NODEVICE, "rt_create: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName); return nullptr; }
+	rt_ctx* c = new rt_ctx();
+	c->device = device, c->width = width, c->height = height;
+	memset(&c->S, 0, sizeof(c->S));
+	memset(&c->P, 0, sizeof(c->P));
+	memset(&c->Q, 0, sizeof(c->Q));
+	memset(&c->prof, 0, sizeof(c->prof));
+	memset(&c->C, 0, sizeof(c->C));
+	bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+	ok = ok && hipMalloc((void**)&c->accum, (size_t)width * height * sizeof(float4)) == hipSuccess;
+	ok = ok && hipMemset(c->accum, 0, (size_t)width * height * sizeof(float4)) == hipSuccess;
+	// launch geometry: enough 256-lane blocks to fill 256 CUs at 8 blocks per CU; queues are drained
+	// through shared work heads, so the same grid serves every queue length
+	c->gridBlocks = prop.multiProcessorCount * 8;
+	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
+	ok = ok && hipMalloc((void**)&c->flags, 16 * sizeof(int)) == hipSuccess;
+	ok = ok && hipMemset(c->flags, 0, 16 * sizeof(int)) == hipSuccess;
+	ok = ok && hipMalloc((void**)&c->counters, sizeof(DCounters)) == hipSuccess;
+	ok = ok && hipMemset(c->counters, 0, sizeof(DCounters)) == hipSuccess;
+	ok = ok && hipHostMalloc((void**)&c->hostCounts, 16 * sizeof(int)) == hipSuccess;
+	if (!ok) { fail(nullptr, RT_E_HIP, "rt_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); rt_destroy(c); return nullptr; }
+	// default camera = Camera::Camera (camera.h:10-22) for this aspect
+	const float aspect = (float)width / (float)height;
+	rt_camera cam;
+	memset(&cam, 0, sizeof(cam));
+	cam.cam_pos[0] = 0, cam.cam_pos[1] = 1, cam.cam_pos[2] = -2;
+	cam.top_left[0] = -aspect, cam.top_left[1] = 2, cam.top_right[0] = aspect, cam.top_right[1] = 2;
+	cam.bottom_left[0] = -aspect, cam.view_angle = 0.25f;
+	rt_set_camera(c, &cam);
+	return c;
+}
+
+void rt_destroy(rt_ctx* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	prof_collect(c);
+	free_pool(c->sceneAllocs);
+	free_pool(c->stateAllocs);
+	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
+	if (c->spill) (void)hipFree(c->spill);
+	if (c->flags) (void)hipFree(c->flags);
+	if (c->counters) (void)hipFree(c->counters);
+	if (c->hostCounts) (void)hipHostFree(c->hostCounts);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int rt_set_camera(rt_ctx* c, const rt_camera* cam)
+{
+	if (!c || !cam) return fail(c, RT_E_ARG, "rt_set_camera: null argument");
+	memcpy(c->C.camPos, cam->cam_pos, 12), memcpy(c->C.topLeft, cam->top_left, 12);
+	memcpy(c->C.topRight, cam->top_right, 12), memcpy(c->C.bottomLeft, cam->bottom_left, 12);
+	c->C.fisheye = cam->fisheye, c->C.viewAngle = cam->view_angle, c->C.yAngle = cam->y_angle;
+	c->C.width = c->width, c->C.height = c->height;
+	c->cameraSet = true;
+	return RT_OK;
+}
+
+// ---- scene upload: reference-shaped arrays -> HBM traversal layout ---------------------------------
+static void pack_prim(float* rec, const rt_blas& b, uint p, bool last)
+{
+	memset(rec, 0, 64);
+	int kind, obj, mat;
+	if (p < b.n_tri) {
+		const rt_triangle& t = b.tris[p];
+		rec[0] = t.v0[0], rec[1] = t.v0[1], rec[2] = t.v0[2], rec[3] = t.N[0];
+		rec[4] = t.v1[0], rec[5] = t.v1[1], rec[6] = t.v1[2], rec[7] = t.N[1];
+		rec[8] = t.v2[0], rec[9] = t.v2[1], rec[10] = t.v2[2], rec[11] = t.N[2];
+		// float d = -dot(N, v0) (template/scene.h:193), same expression tree as the per-ray evaluation
+		volatile float p0 = t.N[0] * t.v0[0], p1 = t.N[1] * t.v0[1], p2 = t.N[2] * t.v0[2];
+		volatile float s01 = p0 + p1;
+		volatile float s = s01 + p2;
+		rec[12] = -s;
+		kind = RT_KIND_TRI, obj = t.obj_idx, mat = t.material;
+	} else if (p < b.n_tri + b.n_sph) {
+		const rt_sphere& s = b.spheres[p - b.n_tri];
+		rec[0] = s.pos[0], rec[1] = s.pos[1], rec[2] = s.pos[2], rec[3] = s.r2;
+		rec[4] = s.invr, rec[5] = s.r;
+		kind = RT_KIND_SPHERE, obj = s.obj_idx, mat = s.material;
+	} else {
+		const rt_plane& q = b.planes[p - b.n_tri - b.n_sph];
+		rec[0] = q.N[0], rec[1] = q.N[1], rec[2] = q.N[2], rec[3] = q.d;
+		kind = RT_KIND_PLANE, obj = q.obj_idx, mat = q.material;
+	}
+	int kl = kind | (last ? RT_LAST_BIT : 0);
+	memcpy(rec + 13, &obj, 4), memcpy(rec + 14, &mat, 4), memcpy(rec + 15, &kl, 4);
+}
+
+int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
+{
+	if (!c || !d) return fail(c, RT_E_ARG, "rt_upload_scene: null argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (d->n_lights > RT_MAX_LIGHTS) return fail(c, RT_E_UNSUPPORTED, "rt_upload_scene: %u lights (limit %d)", d->n_lights, RT_MAX_LIGHTS);
+	if (d->n_blas < 1 || !d->blas) return fail(c, RT_E_ARG, "rt_upload_scene: no bvh");
+	if (d->use_tlas && (d->n_instances < 1 || d->n_instances > 256 || !d->tlas_nodes)) return fail(c, RT_E_UNSUPPORTED, "rt_upload_scene: TLAS needs 1..256 instances (nodeIdx[256], tlas.cpp:16)");
+	for (uint i = 0; i < d->n_materials; i++) {
+		const rt_material& m = d->materials[i];
+		if (m.type < 1 || m.type > 3) return fail(c, RT_E_ARG, "rt_upload_scene: material %u has type %d", i, m.type);
+	}
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	free_pool(c->sceneAllocs);
+	c->sceneLoaded = false;
+	c->pathUnsupported = false;
+	for (uint i = 0; i < d->n_materials; i++) {
+		const rt_material& m = d->materials[i];
+		if (m.type == RT_MAT_DIFFUSE && (m.shinieness != 0 || m.raytracer == 0)) {
+			c->pathUnsupported = true;
+			c->pathUnsupportedWhy = m.shinieness != 0 ? "a diffuse material has shinieness != 0" : "a diffuse material was built with raytracer == 0";
+		}
+	}
+
+	// pairs + prims of every BLAS, concatenated
+	std::vector<float> pairs, prims;
+	std::vector<uint> rootLink(d->n_blas);
+	for (uint k = 0; k < d->n_blas; k++) {
+		const rt_blas& b = d->blas[k];
+		if (b.nodes_used < 1 || (b.nodes_used & 1) || !b.nodes) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u has %u nodes (expected an even count >= 2)", k, b.nodes_used);
+		if (b.n_prims != b.n_tri + b.n_sph + b.n_pla) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u primitive counts disagree", k);
+		const uint pairOff = (uint)(pairs.size() / 16), primOff = (uint)(prims.size() / 16);
+		std::vector<char> last(b.n_prims, 0);
+		auto link_of = [&](uint i) -> uint {
+			const rt_bvh_node& nd = b.nodes[i];
+			if (nd.prim_count > 0) return RT_LEAF_BIT | (primOff + nd.left_first);
+			return pairOff + nd.left_first / 2;
+		};
+		for (uint i = 0; i < b.nodes_used; i++) {
+			if (i == 1) continue;
+			const rt_bvh_node& nd = b.nodes[i];
+			if (nd.prim_count > 0) {
+				if (nd.left_first + nd.prim_count > b.n_prims) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u node %u leaf range out of bounds", k, i);
+				last[nd.left_first + nd.prim_count - 1] = 1;
+			} else if (b.n_prims > 0 && ((nd.left_first & 1) || nd.left_first < 2 || nd.left_first + 1 >= b.nodes_used)) {
+				return fail(c, RT_E_ARG, "rt_upload_scene: blas %u node %u child index %u invalid", k, i, nd.left_first);
+			}
+		}
+		rootLink[k] = b.n_prims == 0 ? RT_EMPTY : link_of(0);
+		pairs.resize(pairs.size() + (size_t)(b.nodes_used / 2) * 16, 0.0f);
+		for (uint i = 2; i + 1 < b.nodes_used + 0u && b.n_prims > 0; i += 2) {
+			float* rec = &pairs[(size_t)(pairOff + i / 2) * 16];
+			for (int s = 0; s < 2; s++) {
+				const rt_bvh_node& nd = b.nodes[i + s];
+				uint lk = link_of(i + s);
+				memcpy(rec + 8 * s, nd.aabb_min, 12), memcpy(rec + 8 * s + 3, &lk, 4);
+				memcpy(rec + 8 * s + 4, nd.aabb_max, 12);
+			}
+		}
+		prims.resize(prims.size() + (size_t)b.n_prims * 16);
+		for (uint j = 0; j < b.n_prims; j++) {
+			const uint p = b.prim_idx[j];
+			if (p >= b.n_prims) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u prim_idx[%u] = %u out of range", k, j, p);
+			pack_prim(&prims[(size_t)(primOff + j) * 16], b, p, last[j] != 0);
+		}
+	}
+	DScene S;
+	memset(&S, 0, sizeof(S));
+	float* dp = nullptr;
+	HIPCHK(c, dalloc(c->sceneAllocs, &dp, pairs.size() + 16));
+	HIPCHK(c, hipMemcpy(dp, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+	S.pairs = (const float4*)dp;
+	HIPCHK(c, dalloc(c->sceneAllocs, &dp, prims.size() + 16));
+	HIPCHK(c, hipMemcpy(dp, prims.data(), prims.size() * 4, hipMemcpyHostToDevice));
+	S.prims = (const float4*)dp;
+	S.rootLink = rootLink[0];
+	S.useTLAS = d->use_tlas ? 1 : 0;
+
+	if (d->use_tlas) {
+		for (uint i = 0; i < d->tlas_nodes_used; i++) {
+			const rt_tlas_node& nd = d->tlas_nodes[i];
+			if (nd.left_right == 0) { if (nd.blas >= d->n_instances && i != 0) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u instance %u out of range", i, nd.blas); }
+			else if ((nd.left_right & 0xFFFF) >= d->tlas_nodes_used || (nd.left_right >> 16) >= d->tlas_nodes_used) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u child out of range", i);
+		}
+		HIPCHK(c, dalloc(c->sceneAllocs, &dp, (size_t)d->tlas_nodes_used * 8));
+		HIPCHK(c, hipMemcpy(dp, d->tlas_nodes, (size_t)d->tlas_nodes_used * 32, hipMemcpyHostToDevice));
+		S.tlas = (const float4*)dp;
+		std::vector<DInstance> inst(d->n_instances);
+		for (uint i = 0; i < d->n_instances; i++) {
+			const rt_instance& in = d->instances[i];
+			if (in.blas < 0 || (uint)in.blas >= d->n_blas) return fail(c, RT_E_ARG, "rt_upload_scene: instance %u blas %d out of range", i, in.blas);
+			memset(&inst[i], 0, sizeof(DInstance));
+			memcpy(inst[i].invT, in.inv_transform, 48), memcpy(inst[i].T, in.transform, 48);
+			inst[i].rootLink = rootLink[in.blas];
+		}
+		DInstance* di = nullptr;
+		HIPCHK(c, dalloc(c->sceneAllocs, &di, inst.size()));
+		HIPCHK(c, hipMemcpy(di, inst.data(), inst.size() * sizeof(DInstance), hipMemcpyHostToDevice));
+		S.inst = di;
+		// brute-force primitives in prim-record form
+		rt_blas fake;
+		memset(&fake, 0, sizeof(fake));
+		fake.spheres = d->brute_spheres, fake.n_sph = d->n_brute_spheres, fake.planes = d->brute_planes, fake.n_pla = d->n_brute_planes;
+		const uint nb = fake.n_sph + fake.n_pla;
+		std::vector<float> brute((size_t)nb * 16 + 16);
+		for (uint j = 0; j < nb; j++) pack_prim(&brute[(size_t)j * 16], fake, j, true);
+		HIPCHK(c, dalloc(c->sceneAllocs, &dp, brute.size()));
+		HIPCHK(c, hipMemcpy(dp, brute.data(), brute.size() * 4, hipMemcpyHostToDevice));
+		S.brute = (const float4*)dp;
+		S.nBruteSph = (int)fake.n_sph, S.nBrutePla = (int)fake.n_pla;
+	}
+	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);
+	for (uint i = 0; i < d->n_lights; i++) {
+		const rt_light& l = d->lights[i];
+		DLight& o = lights[i];
+		o.kind = l.kind, o.objIdx = l.obj_idx, o.strength = l.strength, o.radius = l.radius, o.sinAngle = l.sin_angle;
+		memcpy(o.pos, l.pos, 12), memcpy(o.col, l.col, 12), memcpy(o.normal, l.normal, 12);
+	}
+	DLight* dl = nullptr;
+	HIPCHK(c, dalloc(c->sceneAllocs, &dl, lights.size()));
+	HIPCHK(c, hipMemcpy(dl, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+	S.lights = dl, S.nLights = (int)d->n_lights;
+	std::vector<DMaterial> mats(d->n_materials ? d->n_materials : 1);
+	for (uint i = 0; i < d->n_materials; i++) {
+		const rt_material& m = d->materials[i];
+		DMaterial& o = mats[i];
+		o.type = m.type, o.raytracer = m.raytracer, o.specu = m.specu, o.diffu = m.diffu, o.shinieness = m.shinieness, o.N = m.N, o.ir = m.ir;
+		memcpy(o.col, m.col, 12), memcpy(o.albedo, m.albedo, 12), memcpy(o.absorption, m.absorption, 12);
+	}
+	DMaterial* dm = nullptr;
+	HIPCHK(c, dalloc(c->sceneAllocs, &dm, mats.size()));
+	HIPCHK(c, hipMemcpy(dm, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
+	S.mats = dm;
+	if (d->sky_pixels && d->sky_w > 0 && d->sky_h > 0 && d->sky_n >= 3) {
+		unsigned char* ds = nullptr;
+		const size_t nbytes = (size_t)d->sky_w * d->sky_h * d->sky_n;
+		HIPCHK(c, dalloc(c->sceneAllocs, &ds, nbytes));
+		HIPCHK(c, hipMemcpy(ds, d->sky_pixels, nbytes, hipMemcpyHostToDevice));
+		S.sky = ds, S.skyW = d->sky_w, S.skyH = d->sky_h, S.skyN = d->sky_n;
+	}
+	c->S = S;
+	c->sceneLoaded = true;
+	return RT_OK;
+}
+
+// ---- path state -------------------------------------------------------------------------------
+static int ensure_state(rt_ctx* c, int nSlots, bool pend)
+{
+	if (c->stateSlots >= nSlots && c->stateLights == c->S.nLights && (c->statePend || !pend)) { c->P.nSlots = nSlots; if (!pend) {} return RT_OK; }
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	free_pool(c->stateAllocs);
+	c->stateSlots = 0;
+	PathState P;
+	memset(&P, 0, sizeof(P));
+	const size_t n = (size_t)nSlots;
+	for (int b = 0; b < 2; b++) { HIPCHK(c, dalloc(c->stateAllocs, &P.O[b], n)); HIPCHK(c, dalloc(c->stateAllocs, &P.D[b], n)); }
+	HIPCHK(c, dalloc(c->stateAllocs, &P.hitN, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.hitId, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.W, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.E, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.L, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.sh, n * (size_t)(c->S.nLights + 1)));
+	if (pend) {
+		HIPCHK(c, dalloc(c->stateAllocs, &P.pend, n * RT_PEND_CAP * 4));
+		HIPCHK(c, dalloc(c->stateAllocs, &P.pendCount, n));
+	}
+	Queues Q;
+	memset(&Q, 0, sizeof(Q));
+	HIPCHK(c, dalloc(c->stateAllocs, &Q.active[0], n));
+	HIPCHK(c, dalloc(c->stateAllocs, &Q.active[1], n));
+	HIPCHK(c, dalloc(c->stateAllocs, &Q.shadow, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &Q.counts, 16));
+	HIPCHK(c, hipMemset(Q.counts, 0, 16 * sizeof(int)));
+	P.nSlots = nSlots;
+	c->P = P, c->Q = Q;
+	c->stateSlots = nSlots, c->stateLights = c->S.nLights, c->statePend = pend;
+	return RT_OK;
+}
+
+// The round loop shared by rt_render and rt_trace_batch.
+static int run_rounds(rt_ctx* c, const RenderParams& R, uint frame0, int maxRounds)
+{
+	PathState P = c->P;
+	if (R.mode != RT_MODE_WHITTED) P.pend = nullptr, P.pendCount = nullptr;
+	const Queues Q = c->Q;
+	const int n = P.nSlots;
+	const float t_min = R.mode == RT_MODE_WHITTED ? (float)1e-6 : 0.001f; // renderer.cpp:24, :131
+	const int grid = c->gridBlocks;
+	prof_begin(c, K_GENERATE);
+	hipLaunchKernelGGL(k_generate, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->C, R, P, Q, frame0);
+	prof_end(c);
+	int parity = 0;
+	for (int round = 0; round < maxRounds; round++) {
+		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, c->stream, Q, parity);
+		prof_begin(c, K_EXTEND);
+		if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->spill, c->counters);
+		else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->spill, c->counters);
+		prof_end(c);
+		prof_begin(c, K_SHADE);
+		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity);
+		prof_end(c);
+		prof_begin(c, K_CONNECT);
+		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity, c->spill, c->counters);
+		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity, c->spill, c->counters);
+		prof_end(c);
+		parity = 1 - parity;
+		// look at the queue length every few rounds (one small D2H copy + sync); stop when it is empty
+		if ((round & 3) == 3 || round + 1 == maxRounds) {
+			HIPCHK(c, hipMemcpyAsync(c->hostCounts, Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			if (c->hostCounts[3] == 1) return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+			if (c->hostCounts[3] == 2) return fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
+			if (c->hostCounts[parity] == 0) break;
+			if (round + 1 == maxRounds) return fail(c, RT_E_STATE, "paths still active after %d rounds", maxRounds);
+		}
+	}
+	HIPCHK(c, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_render(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int y0, int y1, int max_depth)
+{
+	if (!c) return RT_E_ARG;
+	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_render: no scene uploaded");
+	if (mode != RT_MODE_WHITTED && mode != RT_MODE_PATH) return fail(c, RT_E_ARG, "rt_render: mode %d", mode);
+	if (y0 < 0 || y1 > c->height || y0 >= y1) return fail(c, RT_E_ARG, "rt_render: rows [%d,%d) outside 0..%d", y0, y1, c->height);
+	if (nframes < 1 || (mode == RT_MODE_WHITTED && nframes != 1)) return fail(c, RT_E_ARG, "rt_render: nframes %d (Whitted frames overwrite the accumulator: 1 only)", nframes);
+	if (mode == RT_MODE_PATH && c->pathUnsupported) return fail(c, RT_E_UNSUPPORTED, "rt_render: path mode unsupported for this scene: %s", c->pathUnsupportedWhy.c_str());
+	HIPCHK(c, hipSetDevice(c->device));
+	const int nSlots = c->width * (y1 - y0);
+	if (mode == RT_MODE_WHITTED && max_depth <= 0) { // Trace(depth <= 0) returns black without tracing
+		HIPCHK(c, hipMemsetAsync(c->accum + (size_t)y0 * c->width, 0, (size_t)nSlots * sizeof(float4), c->stream));
+		return RT_OK;
+	}
+	int rc = ensure_state(c, nSlots, mode == RT_MODE_WHITTED);
+	if (rc != RT_OK) return rc;
+	RenderParams R;
+	memset(&R, 0, sizeof(R));
+	R.mode = mode, R.frameEnd = frame0 + (uint)nframes, R.seedBase = seed_base, R.y0 = y0, R.maxDepth = max_depth, R.accum = c->accum;
+	// upper bounds on rounds: a path sample has at most 5 segments (depth 4..0); a Whitted pixel at
+	// most 2^depth - 1 glass segments plus shiny-diffuse branches
+	int maxRounds = mode == RT_MODE_PATH ? 5 * nframes + 4 : ((1 << (max_depth < 12 ? max_depth : 12)) * (1 + c->S.nLights) + 4);
+	return run_rounds(c, R, frame0, maxRounds);
+}
+
+int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, float* rgb_out)
+{
+	if (!c || !O || !D || !rgb_out || n < 0) return fail(c, RT_E_ARG, "rt_trace_batch: bad argument");
+	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_trace_batch: no scene uploaded");
+	if (mode == RT_MODE_PATH && c->pathUnsupported) return fail(c, RT_E_UNSUPPORTED, "rt_trace_batch: path mode unsupported for this scene: %s", c->pathUnsupportedWhy.c_str());
+	if (n == 0) return RT_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	if ((mode == RT_MODE_WHITTED && depth <= 0) || (mode == RT_MODE_PATH && depth < 0)) {
+		const float v = mode == RT_MODE_WHITTED ? 0.0f : 0.05f; // renderer.cpp:23, :129
+		for (int i = 0; i < 3 * n; i++) rgb_out[i] = v;
+		return RT_OK;
+	}
+	int rc = ensure_state(c, n, mode == RT_MODE_WHITTED);
+	if (rc != RT_OK) return rc;
+	float *dO = nullptr, *dD = nullptr;
+	float4* dOut = nullptr;
+	std::vector<void*> tmp;
+	HIPCHK(c, dalloc(tmp, &dO, (size_t)3 * n));
+	HIPCHK(c, dalloc(tmp, &dD, (size_t)3 * n));
+	HIPCHK(c, dalloc(tmp, &dOut, (size_t)n));
+	HIPCHK(c, hipMemcpyAsync(dO, O, (size_t)12 * n, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream));
+	RenderParams R;
+	memset(&R, 0, sizeof(R));
+	R.mode = mode, R.frameEnd = 1, R.seedBase = seed_base, R.maxDepth = depth, R.accum = c->accum;
+	R.customO = dO, R.customD = dD, R.customOut = dOut, R.customDepth = depth;
+	int maxRounds = mode == RT_MODE_PATH ? depth + 6 : ((1 << (depth < 12 ? depth : 12)) * (1 + c->S.nLights) + 4);
+	rc = run_rounds(c, R, 0, maxRounds);
+	if (rc == RT_OK) {
+		std::vector<float> out4((size_t)4 * n);
+		hipError_t e = hipMemcpy(out4.data(), dOut, (size_t)16 * n, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = fail(c, RT_E_HIP, "rt_trace_batch: copy back failed: %s", hipGetErrorString(e));
+		else for (int i = 0; i < n; i++) { rgb_out[3 * i] = out4[4 * i], rgb_out[3 * i + 1] = out4[4 * i + 1], rgb_out[3 * i + 2] = out4[4 * i + 2]; }
+	}
+	(void)hipStreamSynchronize(c->stream);
+	free_pool(tmp);
+	return rc;
+}
+
+int rt_clear(rt_ctx* c)
+{
+	if (!c) return RT_E_ARG;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemsetAsync(c->accum, 0, (size_t)c->width * c->height * sizeof(float4), c->stream));
+	return RT_OK;
+}
+
+int rt_download_accumulator(rt_ctx* c, int y0, int y1, float* out)
+{
+	if (!c || !out || y0 < 0 || y1 > c->height || y0 >= y1) return fail(c, RT_E_ARG, "rt_download_accumulator: bad argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemcpy(out, c->accum + (size_t)y0 * c->width, (size_t)(y1 - y0) * c->width * sizeof(float4), hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_resolve(rt_ctx* c, int iteration, int y0, int y1, uint32_t* rgb8_out)
+{
+	if (!c || !rgb8_out || y0 < 0 || y1 > c->height || y0 >= y1 || iteration == 0) return fail(c, RT_E_ARG, "rt_resolve: bad argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	const int n = (y1 - y0) * c->width;
+	uint* d = nullptr;
+	HIPCHK(c, hipMalloc((void**)&d, (size_t)n * 4));
+	hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, y0 * c->width, n, iteration, d);
+	hipError_t e = hipStreamSynchronize(c->stream);
+	if (e == hipSuccess) e = hipMemcpy(rgb8_out, d, (size_t)n * 4, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(c, RT_E_HIP, "rt_resolve: %s", hipGetErrorString(e));
+	return RT_OK;
+}
+
+void* rt_accumulator_device_ptr(rt_ctx* c) { return c ? c->accum : nullptr; }
+int rt_bind_accumulator(rt_ctx* c, void* p)
+{
+	if (!c || !p) return fail(c, RT_E_ARG, "rt_bind_accumulator: null argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
+	c->accum = (float4*)p, c->accumOwned = false;
+	return RT_OK;
+}
+
+// ---- batch queries -------------------------------------------------------------------------------
+static int check_overflow(rt_ctx* c)
+{
+	int f = 0;
+	HIPCHK(c, hipMemcpy(&f, c->flags, sizeof(int), hipMemcpyDeviceToHost));
+	if (f) { (void)hipMemset(c->flags, 0, sizeof(int)); return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX); }
+	return RT_OK;
+}
+static int query_grid(rt_ctx* c, int n) { int g = (n + RT_BLOCK - 1) / RT_BLOCK; return g < 1 ? 1 : (g > c->gridBlocks ? c->gridBlocks : g); }
+
+int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out)
+{
+	if (!c || !O || !D || !out || n < 0) return fail(c, RT_E_ARG, "rt_intersect_batch: bad argument");
+	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_intersect_batch: no scene uploaded");
+	if (n == 0) return RT_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	std::vector<void*> tmp;
+	float *dO = nullptr, *dD = nullptr, *dT = nullptr;
+	QueryHit* dH = nullptr;
+	int rc = RT_OK;
+	hipError_t e = dalloc(tmp, &dO, (size_t)3 * n);
+	if (e == hipSuccess) e = dalloc(tmp, &dD, (size_t)3 * n);
+	if (e == hipSuccess && tmax) e = dalloc(tmp, &dT, (size_t)n);
+	if (e == hipSuccess) e = dalloc(tmp, &dH, (size_t)n);
+	if (e == hipSuccess) e = hipMemcpyAsync(dO, O, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		prof_begin(c, K_QUERY);
+		if (c->counting) hipLaunchKernelGGL(k_query_nearest<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, dH, c->spill, c->flags, c->counters);
+		else hipLaunchKernelGGL(k_query_nearest<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, dH, c->spill, c->flags, c->counters);
+		prof_end(c);
+		e = hipStreamSynchronize(c->stream);
+	}
+	static_assert(sizeof(QueryHit) == sizeof(rt_hit), "rt_hit layout");
+	if (e == hipSuccess) e = hipMemcpy(out, dH, (size_t)n * sizeof(rt_hit), hipMemcpyDeviceToHost);
+	if (e != hipSuccess) rc = fail(c, RT_E_HIP, "rt_intersect_batch: %s", hipGetErrorString(e));
+	free_pool(tmp);
+	if (rc == RT_OK) rc = check_overflow(c);
+	return rc;
+}
+
+int rt_occluded_batch(rt_ctx* c, int n, const float* O, const float* D, const float* tmax, uint8_t* out)
+{
+	if (!c || !O || !D || !out || n < 0) return fail(c, RT_E_ARG, "rt_occluded_batch: bad argument");
+	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_occluded_batch: no scene uploaded");
+	if (n == 0) return RT_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	std::vector<void*> tmp;
+	float *dO = nullptr, *dD = nullptr, *dT = nullptr;
+	unsigned char* dR = nullptr;
+	int rc = RT_OK;
+	hipError_t e = dalloc(tmp, &dO, (size_t)3 * n);
+	if (e == hipSuccess) e = dalloc(tmp, &dD, (size_t)3 * n);
+	if (e == hipSuccess && tmax) e = dalloc(tmp, &dT, (size_t)n);
+	if (e == hipSuccess) e = dalloc(tmp, &dR, (size_t)n);
+	if (e == hipSuccess) e = hipMemcpyAsync(dO, O, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		prof_begin(c, K_QUERY);
+		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, dR, c->spill, c->flags, c->counters);
+		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, dR, c->spill, c->flags, c->counters);
+		prof_end(c);
+		e = hipStreamSynchronize(c->stream);
+	}
+	if (e == hipSuccess) e = hipMemcpy(out, dR, (size_t)n, hipMemcpyDeviceToHost);
+	if (e != hipSuccess) rc = fail(c, RT_E_HIP, "rt_occluded_batch: %s", hipGetErrorString(e));
+	free_pool(tmp);
+	if (rc == RT_OK) rc = check_overflow(c);
+	return rc;
+}
+
+int rt_primary_hits(rt_ctx* c, float t_min, int32_t* obj_out, float* t_out)
+{
+	if (!c || !obj_out || !t_out) return fail(c, RT_E_ARG, "rt_primary_hits: null argument");
+	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_primary_hits: no scene uploaded");
+	HIPCHK(c, hipSetDevice(c->device));
+	const int n = c->width * c->height;
+	std::vector<void*> tmp;
+	int* dO = nullptr;
+	float* dT = nullptr;
+	int rc = RT_OK;
+	hipError_t e = dalloc(tmp, &dO, (size_t)n);
+	if (e == hipSuccess) e = dalloc(tmp, &dT, (size_t)n);
+	if (e == hipSuccess) {
+		prof_begin(c, K_QUERY);
+		if (c->counting) hipLaunchKernelGGL(k_primary_hits<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, dO, dT, c->spill, c->flags, c->counters);
+		else hipLaunchKernelGGL(k_primary_hits<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, dO, dT, c->spill, c->flags, c->counters);
+		prof_end(c);
+		e = hipStreamSynchronize(c->stream);
+	}
+	if (e == hipSuccess) e = hipMemcpy(obj_out, dO, (size_t)n * 4, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(t_out, dT, (size_t)n * 4, hipMemcpyDeviceToHost);
+	if (e != hipSuccess) rc = fail(c, RT_E_HIP, "rt_primary_hits: %s", hipGetErrorString(e));
+	free_pool(tmp);
+	if (rc == RT_OK) rc = check_overflow(c);
+	return rc;
+}
+
+// ---- measurement ------------------------------------------------------------------------------
+int rt_set_counting(rt_ctx* c, int counting) { if (!c) return RT_E_ARG; c->counting = counting != 0; return RT_OK; }
+int rt_get_counters(rt_ctx* c, rt_counters* out, int reset)
+{
+	if (!c || !out) return fail(c, RT_E_ARG, "rt_get_counters: null argument");
+	static_assert(sizeof(rt_counters) == sizeof(DCounters), "rt_counters layout");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemcpy(out, c->counters, sizeof(DCounters), hipMemcpyDeviceToHost));
+	if (reset) HIPCHK(c, hipMemset(c->counters, 0, sizeof(DCounters)));
+	return RT_OK;
+}
+int rt_set_profiling(rt_ctx* c, int profiling) { if (!c) return RT_E_ARG; prof_collect(c); c->profiling = profiling != 0; return RT_OK; }
+int rt_get_profile(rt_ctx* c, rt_profile* out, int reset)
+{
+	if (!c || !out) return fail(c, RT_E_ARG, "rt_get_profile: null argument");
+	prof_collect(c);
+	*out = c->prof;
+	if (reset) memset(&c->prof, 0, sizeof(c->prof));
+	return RT_OK;
+}
+int rt_synchronize(rt_ctx* c)
+{
+	if (!c) return RT_E_ARG;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,630 @@
+// Wavefront kernels of the pixel loop: generate -> [extend -> shade -> connect]* .
+//
+// One *slot* per pixel of the rendered tile holds the state of the path currently being traced
+// for that pixel (SoA arrays in HBM, 16-byte elements so every lane moves whole dwordx4s).  Each
+// round runs three kernels over compacted queues of slot ids:
+//   extend   Scene::FindNearest for every active slot                       (the dominant kernel)
+//   shade    the body of Renderer::Trace / Renderer::Sample at the hit: leaf terms, material
+//            switch, light sampling, the next ray; survivors are appended to the next queue with a
+//            wave-wide ballot + prefix count and one atomic per wave
+//   connect  Scene::IsOccluded for the slots that sampled lights, then the direct-light terms in
+//            light order (their energy bookkeeping feeds the next bounce)
+// A finished path adds its sample to the accumulator and, while frames remain, the slot is
+// re-seeded with the next frame's primary ray in the same step (path regeneration), so queues stay
+// full until the last frames.  Sums are carried forward as path weights (W) instead of being
+// combined on return from recursion; per pixel the segment order is the reference's depth-first
+// order, so no atomics touch radiance and results do not depend on queue order.
+#pragma once
+#include "rt_scene_dev.h"
+
+namespace rtd {
+
+#define RT_PEND_CAP 12 // pending Whitted branches per pixel (glass: <= 3 at depth 4; shiny diffuse: more)
+
+struct DCamera {
+	float camPos[3], topLeft[3], topRight[3], bottomLeft[3];
+	int fisheye; float viewAngle, yAngle;
+	int width, height;
+};
+
+struct PathState {
+	float4* O[2];    // ray origin xyz, w = ray.t on entry (tmax); double buffered by round parity
+	float4* D[2];    // ray direction xyz
+	float4* hitN;    // hit normal xyz, w = t
+	int2* hitId;     // objIdx, material
+	float4* W;       // path weight xyz, w = depth (int bits)
+	float4* E;       // energy xyz, w = RNG state (uint bits)
+	float4* L;       // radiance of the current sample xyz, w = frame (uint bits)
+	float4* sh;      // [light][slot] sampled light position xyz (plane 0: w = flags); plane nLights: weight of the segment
+	float4* pend;    // [slot][RT_PEND_CAP][4]: pending Whitted branches {O,depth} {D,-} {W,-} {E,-}
+	int* pendCount;  // [slot]
+	int nSlots;
+};
+
+struct RenderParams {
+	int mode;          // RT_MODE_WHITTED / RT_MODE_PATH
+	uint frameEnd;     // frames [.., frameEnd) are rendered
+	uint seedBase;
+	int y0;            // first row of the tile; slot s is pixel y0*width + s
+	int maxDepth;      // depth argument of Trace
+	float4* accum;     // accumulator, whole image
+	// rt_trace_batch: caller rays instead of camera rays, raw radiance out instead of accumulation
+	const float* customO; const float* customD; float4* customOut; int customDepth;
+};
+
+struct Queues {
+	uint* active[2];
+	uint* shadow;
+	int* counts; // [0],[1]: active sizes by parity, [2]: shadow size, [3]: overflow flag, [4..6]: work heads
+};
+
+// ---- camera (camera.h:24-41) ---------------------------------------------------------------
+__device__ __forceinline__ f3 cam_rotate_y(const f3& p, const f3& center, float theta)
+{
+	double c = cos((double)theta), s = sin((double)theta);
+	f3 vect = p - center;
+	f3 xT((float)c, 0, (float)-s), zT((float)s, 0, (float)c);
+	f3 res(dot(vect, xT), vect.y, dot(vect, zT));
+	return res + center;
+}
+__device__ __forceinline__ f3 cam_rotate_x(const f3& p, const f3& center, float theta, float yAngle)
+{
+	double c = cos((double)theta), s = sin((double)theta);
+	f3 vect = p - center;
+	vect = cam_rotate_y(vect, f3(0.f), -yAngle);
+	f3 zT(0, (float)-s, (float)c), yT(0, (float)c, (float)s);
+	f3 res(vect.x, dot(vect, yT), dot(vect, zT));
+	res = cam_rotate_y(res, f3(0.f), yAngle);
+	return res + center;
+}
+__device__ __forceinline__ void primary_ray(const DCamera& C, int x, int y, f3& O, f3& D)
+{
+	const f3 camPos(C.camPos[0], C.camPos[1], C.camPos[2]), TL(C.topLeft[0], C.topLeft[1], C.topLeft[2]);
+	const f3 TR(C.topRight[0], C.topRight[1], C.topRight[2]), BL(C.bottomLeft[0], C.bottomLeft[1], C.bottomLeft[2]);
+	O = camPos;
+	if (C.fisheye) {
+		const float aspect = (float)C.width / (float)C.height;
+		f3 screenCenter = TL + .5f * (TR - TL) + .5f * (BL - TL);
+		const float u = (float)(x - C.width / 2) * (aspect * C.viewAngle / C.width);
+		const float v = (float)(y - C.width / 2) * (C.viewAngle / C.height);
+		f3 newRay = cam_rotate_x(cam_rotate_y(normalize(screenCenter - camPos), camPos, -u), camPos, -v, C.yAngle);
+		D = normalize(newRay);
+		return;
+	}
+	const float u = (float)x * (1.0f / C.width);
+	const float v = (float)y * (1.0f / C.height);
+	const f3 P = TL + u * (TR - TL) + v * (BL - TL);
+	D = normalize(P - camPos);
+}
+
+// ---- lights (template/scene.h:121-137, 152-165) -----------------------------------------------
+__device__ __forceinline__ f3 light_intensity(const DLight& L, const f3& p, const f3& n, const f3& from)
+{
+	const f3 col(L.col[0], L.col[1], L.col[2]);
+	if (L.kind == 0) {
+		float dis = length(from - p);
+		f3 dir = from - p;
+		float cos_ang = dot(normalize(n), normalize(dir));
+		float relStr = 1 / (dis * RT_PI) * L.strength;
+		// isZero(float3) compares each component '< 1e-4' in double (template/precomp.h:885)
+		if (dis <= L.radius && ((double)cos_ang < 1e-4)) return L.strength * col;
+		return relStr * col;
+	}
+	if (L.kind == 1) {
+		const f3 pos(L.pos[0], L.pos[1], L.pos[2]), normal(L.normal[0], L.normal[1], L.normal[2]);
+		f3 dir = p - pos;
+		float sTheta = length(cross(dir, normal)) / length(dir) * length(normal);
+		if (dot(dir, normal) < 0) return f3(0.0f);
+		float dis = length(dir);
+		float str = L.sinAngle - sTheta > 0 ? x_asinf(L.sinAngle) - x_asinf(sTheta) : 0;
+		return f3(1 / dis * str * L.strength);
+	}
+	return f3(1.0f);
+}
+__device__ __forceinline__ f3 light_position(const DLight& L, bool raytracer, uint& seed)
+{
+	const f3 pos(L.pos[0], L.pos[1], L.pos[2]);
+	if (L.kind != 0 || raytracer) return pos;
+	float newRad = L.radius * sqrtf(RandomFloat(seed));
+	float theta = RandomFloat(seed) * 2 * RT_PI;
+	return f3(pos.x + newRad * x_cosf(theta), pos.y + newRad * x_sinf(theta), pos.z);
+}
+
+// Scene::GetSkyColor (template/scene.h:1312-1327)
+__device__ __forceinline__ f3 sky_color(const DScene& S, const f3& D)
+{
+	if (!S.sky) return f3(0.0f);
+	f3 horizontalProj(D.x, 0, D.z);
+	float cHeight = dot(D, f3(0, -1, 0));
+	f3 nh = normalize(horizontalProj);
+	float cOrient = dot(f3(0, 0, 1), nh);
+	float sOrient = dot(f3(1, 0, 0), nh);
+	sOrient = sOrient > 0 ? 1 : -1;
+	int y = f2i(((cHeight + 1) / 2) * (S.skyH - 1));
+	int x = f2i((((sOrient * x_acosf(cOrient)) + RT_PI) / RT_TWOPI) * (S.skyW - 1));
+	if (x >= S.skyW) x = S.skyW - 1;
+	if (y >= S.skyH) y = S.skyH - 1;
+	if (y < 0) y = 0;
+	if (x < 0) x = 0;
+	const unsigned char* p = S.sky + (size_t)(x + S.skyW * y) * S.skyN;
+	return f3((float)p[0], (float)p[1], (float)p[2]) / 255;
+}
+
+// diffuse::scatter (template/scene.h:605-620): att out, energy in/out
+__device__ __forceinline__ f3 diffuse_scatter(const DMaterial& m, const f3& rayD, const f3& lightDir, const f3& lightIntensity, const f3& normal, f3& energy)
+{
+	const f3 albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
+	f3 reflectionDirection = reflect(-lightDir, normal);
+	f3 specularColor = x_powf(libm_fmaxf(0.0f, -dot(reflectionDirection, rayD)), (float)m.N) * lightIntensity;
+	f3 att = albedo * lightIntensity * m.diffu + specularColor * m.specu;
+	f3 retention = f3(1.0f) - albedo;
+	f3 newEnergy = energy - retention;
+	energy = newEnergy.x > 0 ? newEnergy : f3(0.0f);
+	return att;
+}
+
+// wave-aggregated queue append: one atomic per wave (ballot + prefix popcount)
+__device__ __forceinline__ void queue_append(uint* q, int* count, bool want, uint value)
+{
+	const unsigned long long mask = __ballot(want);
+	if (mask == 0) return;
+	const uint lane = threadIdx.x & 63;
+	const int leader = __ffsll((long long)mask) - 1;
+	int base = 0;
+	if ((int)lane == leader) base = atomicAdd(count, __popcll(mask));
+	base = __shfl(base, leader);
+	if (want) q[base + __popcll(mask & ((1ull << lane) - 1))] = value;
+}
+
+// dynamic work fetch: each wave takes 64 queue entries at a time from a shared head
+__device__ __forceinline__ bool fetch_work(int* head, int n, int& idx)
+{
+	const uint lane = threadIdx.x & 63;
+	int base = 0;
+	if (lane == 0) base = atomicAdd(head, 64);
+	base = __shfl(base, 0);
+	if (base >= n) return false;
+	idx = base + (int)lane;
+	return true;
+}
+
+__device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* overflow)
+{
+	Stack st;
+	st.lds = ldsBase + threadIdx.x;
+	st.spillStride = gridDim.x * blockDim.x;
+	st.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	st.sp = 0;
+	st.overflow = overflow;
+	return st;
+}
+
+__device__ __forceinline__ void flush_counters(DCounters* g, const LaneCounters& lc, uint nearest, uint occluded)
+{
+	// wave reduction, then one atomic per field per wave
+	uint v[8] = { lc.inner, lc.prim, lc.tlasInner, lc.inst, nearest, occluded, lc.brute, lc.light };
+	unsigned long long* out = (unsigned long long*)g;
+	for (int k = 0; k < 8; k++) {
+		uint x = v[k];
+		for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+		if ((threadIdx.x & 63) == 0 && x) atomicAdd(out + k, (unsigned long long)x);
+	}
+}
+
+// Start (or restart) the sample of 'frame' in a slot: seed, jitter, primary ray (renderer.cpp:263-278)
+__device__ __forceinline__ void start_sample(const DCamera& C, const RenderParams& R, PathState& P, int slot, uint frame, int parityOut)
+{
+	f3 O, D;
+	uint seed = 0;
+	int depth;
+	if (R.customO) {
+		O = f3(R.customO[3 * slot], R.customO[3 * slot + 1], R.customO[3 * slot + 2]);
+		D = f3(R.customD[3 * slot], R.customD[3 * slot + 1], R.customD[3 * slot + 2]);
+		seed = InitSeed(R.seedBase + (uint)slot);
+		depth = R.customDepth;
+	} else {
+		const int pixel = R.y0 * C.width + slot;
+		const int x = pixel % C.width, y = pixel / C.width;
+		seed = InitSeed(R.seedBase + (uint)pixel + frame * (uint)(C.width * C.height));
+		if (R.mode == 0) {
+			primary_ray(C, x, y, O, D);
+			depth = R.maxDepth;
+		} else {
+			float newX = x + (RandomFloat(seed) * 2 - 1);
+			float newY = y + (RandomFloat(seed) * 2 - 1);
+			primary_ray(C, (int)newX, (int)newY, O, D); // jitter truncated by the int parameters (renderer.cpp:276-278)
+			depth = 4;
+		}
+	}
+	P.O[parityOut][slot] = mk4(O, 1e34f);
+	P.D[parityOut][slot] = mk4(D, 0.0f);
+	P.W[slot] = make_float4(1, 1, 1, __int_as_float(depth));
+	P.E[slot] = make_float4(1, 1, 1, __uint_as_float(seed));
+	P.L[slot] = make_float4(0, 0, 0, __uint_as_float(frame));
+	if (P.pendCount) P.pendCount[slot] = 0;
+}
+
+// The sample in 'slot' is complete: accumulate it (renderer.cpp:270 / :279-282).  Returns true
+// when the slot was restarted with the next frame (caller appends it to the next queue).
+__device__ __forceinline__ bool finish_sample(const DCamera& C, const RenderParams& R, PathState& P, int slot, const f3& Lsum, uint frame, int parityOut)
+{
+	if (R.customOut) {
+		R.customOut[slot] = mk4(Lsum, 0.0f);
+		return false;
+	}
+	const int pixel = R.y0 * C.width + slot;
+	if (R.mode == 0) {
+		f3 v = Lsum / (float)1;
+		R.accum[pixel] = mk4(v, 0.0f);
+		return false;
+	}
+	float4 a = R.accum[pixel];
+	a.x += x_powf(Lsum.x * 1, RT_GAMMA);
+	a.y += x_powf(Lsum.y * 1, RT_GAMMA);
+	a.z += x_powf(Lsum.z * 1, RT_GAMMA);
+	a.w += 0;
+	R.accum[pixel] = a;
+	if (frame + 1 < R.frameEnd) {
+		start_sample(C, R, P, slot, frame + 1, parityOut);
+		return true;
+	}
+	return false;
+}
+
+// A segment ended without a continuation ray: resume the most recent pending Whitted branch, or
+// finish the sample.  Returns true when the slot stays active.
+__device__ __forceinline__ bool next_segment(const DCamera& C, const RenderParams& R, PathState& P, int slot, const f3& Lsum, uint frame, int parityOut)
+{
+	if (P.pendCount) {
+		int n = P.pendCount[slot];
+		if (n > 0) {
+			n--;
+			const float4* e = P.pend + ((size_t)slot * RT_PEND_CAP + n) * 4;
+			const float4 o = e[0], d = e[1], w = e[2], en = e[3];
+			P.O[parityOut][slot] = make_float4(o.x, o.y, o.z, 1e34f);
+			P.D[parityOut][slot] = make_float4(d.x, d.y, d.z, 0.0f);
+			P.W[slot] = make_float4(w.x, w.y, w.z, o.w);
+			const float seedBits = P.E[slot].w;
+			P.E[slot] = make_float4(en.x, en.y, en.z, seedBits);
+			P.L[slot] = mk4(Lsum, __uint_as_float(frame));
+			P.pendCount[slot] = n;
+			return true;
+		}
+	}
+	return finish_sample(C, R, P, slot, Lsum, frame, parityOut);
+}
+
+__device__ __forceinline__ void push_pending(PathState& P, int slot, const f3& O, const f3& D, const f3& W, const f3& E, int depth, int* overflow)
+{
+	int n = P.pendCount[slot];
+	if (n >= RT_PEND_CAP) { *overflow = 2; return; }
+	float4* e = P.pend + ((size_t)slot * RT_PEND_CAP + n) * 4;
+	e[0] = mk4(O, __int_as_float(depth)), e[1] = mk4(D, 0.0f), e[2] = mk4(W, 0.0f), e[3] = mk4(E, 0.0f);
+	P.pendCount[slot] = n + 1;
+}
+
+// ---- kernels -----------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(RT_BLOCK) k_generate(DCamera C, RenderParams R, PathState P, Queues Q, uint frame0)
+{
+	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= P.nSlots) return;
+	start_sample(C, R, P, slot, frame0, 0);
+	Q.active[0][slot] = (uint)slot;
+	if (slot == 0) { Q.counts[0] = P.nSlots; Q.counts[1] = 0; Q.counts[2] = 0; }
+}
+
+// round bookkeeping between kernels: reset heads and the queues about to be refilled
+__global__ void k_round_begin(Queues Q, int parityIn)
+{
+	Q.counts[1 - parityIn] = 0;
+	Q.counts[2] = 0;
+	Q.counts[4] = 0, Q.counts[5] = 0, Q.counts[6] = 0;
+}
+
+// extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
+// (renderer.cpp:24, :131); it applies to lights and brute-force primitives, the BVH uses 0.0001.
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, uint* spill, DCounters* counters)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	const int n = Q.counts[parity];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	int idx;
+	while (fetch_work(&Q.counts[4], n, idx)) {
+		// no 'continue' here: the wave must be converged again when it reaches fetch_work's shuffle
+		if (idx < n) {
+			const int slot = (int)Q.active[parity][idx];
+			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
+			const f3 O = xyz(o4), D = xyz(d4);
+			Stack st = make_stack(ldsStack, spill, &Q.counts[3]);
+			HitRef hit;
+			find_nearest<COUNT>(S, O, D, o4.w, t_min, hit, st, lc);
+			int objIdx, mat;
+			f3 normal;
+			resolve_hit(S, hit, O, D, objIdx, mat, normal);
+			P.hitN[slot] = mk4(normal, hit.t);
+			P.hitId[slot] = make_int2(objIdx, mat);
+			rays++;
+		}
+	}
+	if (COUNT) flush_counters(counters, lc, rays, 0);
+}
+
+// shade: everything Trace / Sample do at a hit except the occlusion-dependent direct terms.
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, DCamera C, RenderParams R, PathState P, Queues Q, int parity)
+{
+	const int n = Q.counts[parity];
+	const int pout = 1 - parity;
+	int idx;
+	while (fetch_work(&Q.counts[5], n, idx)) {
+		bool live = idx < n;
+		bool keep = false, wantShadow = false;
+		int slot = 0;
+		if (live) {
+			slot = (int)Q.active[parity][idx];
+			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
+			const int2 id = P.hitId[slot];
+			float4 w4 = P.W[slot], e4 = P.E[slot], l4 = P.L[slot];
+			const f3 O = xyz(o4), D = xyz(d4), normal = xyz(hn);
+			const float t = hn.w;
+			f3 W = xyz(w4), E = xyz(e4), Lsum = xyz(l4);
+			const int depth = __float_as_int(w4.w);
+			uint seed = __float_as_uint(e4.w);
+			const uint frame = __float_as_uint(l4.w);
+			const bool path = R.mode != 0;
+			const f3 I = O + t * D; // ray.IntersectionPoint()
+
+			bool segmentEnds = true; // no continuation ray unless a material creates one
+			f3 nO(0.0f), nD(0.0f), nW(0.0f);
+			int nDepth = depth - 1;
+
+			if (id.x == -1) {
+				Lsum = Lsum + W * sky_color(S, D); // renderer.cpp:26 / :134
+			} else if (id.x >= 11 && id.x < 11 + S.nLights) {
+				Lsum = Lsum + W * light_intensity(S.lights[id.x - 11], I, normal, I); // :27-28 / :135-137
+			} else {
+				const DMaterial m = S.mats[id.y];
+				const f3 col(m.col[0], m.col[1], m.col[2]);
+				if (m.type == 3) { // GLASS, renderer.cpp:45-80 / :198-233
+					const float kr = glass_fresnel(normalize(D), normalize(normal), m.ir);
+					const bool outside = dot(D, normal) < 0;
+					const f3 bias = 0.0001f * normal;
+					const f3 norm = outside ? normal : -normal;
+					const float r = !outside ? m.ir : (1 / m.ir);
+					if (outside) {
+						E.x *= x_expf(m.absorption[0] * -t);
+						E.y *= x_expf(m.absorption[1] * -t);
+						E.z *= x_expf(m.absorption[2] * -t);
+					}
+					bool takeRefr, takeRefl;
+					if (path) {
+						const bool refr = kr < RandomFloat(seed);
+						takeRefr = refr, takeRefl = !refr;
+					} else {
+						takeRefr = kr < 1, takeRefl = true;
+					}
+					f3 refrO(0.0f), refrD(0.0f), refrW(0.0f), reflO(0.0f), reflD(0.0f), reflW(0.0f);
+					if (takeRefr) {
+						refrD = normalize(glass_refract(D, norm, r));
+						refrO = outside ? I - bias : I + bias;
+						const f3 tempCol = col * E;
+						refrW = W * (tempCol * (1 - kr));
+					}
+					if (takeRefl) {
+						reflD = normalize(reflect(D, norm));
+						reflO = outside ? I + bias : I - bias;
+						reflW = W * (col * kr);
+					}
+					// a child at depth-1 that cannot trace contributes its terminal value right here:
+					// Trace(depth <= 0) = 0 (renderer.cpp:23), Sample(depth < 0) = 0.05 (:129)
+					const bool childTraces = path ? (nDepth >= 0) : (nDepth > 0);
+					if (!childTraces) {
+						if (path) Lsum = Lsum + (takeRefr ? refrW : reflW) * f3(0.05f);
+					} else if (takeRefr) {
+						if (takeRefl) push_pending(P, slot, reflO, reflD, reflW, E, nDepth, &Q.counts[3]); // refraction first, reflection resumes later
+						nO = refrO, nD = refrD, nW = refrW, segmentEnds = false;
+					} else {
+						nO = reflO, nD = reflD, nW = reflW, segmentEnds = false;
+					}
+				} else if (m.type == 2) { // METAL, renderer.cpp:81-86 / :192-197, metal::scatter template/scene.h:630-635
+					const f3 dir = reflect(D, normal);
+					nO = I + normal * 0.001f, nD = dir;
+					nW = path ? W * col : W * (col * E);
+					const bool childTraces = path ? (nDepth >= 0) : (nDepth > 0);
+					if (childTraces) segmentEnds = false;
+					else if (path) Lsum = Lsum + nW * f3(0.05f);
+				} else { // DIFFUSE, renderer.cpp:87-122 / :156-191
+					for (int i = 0; i < S.nLights; i++) {
+						const f3 pickedPos = light_position(S.lights[i], !path, seed);
+						P.sh[(size_t)i * P.nSlots + slot] = mk4(pickedPos, 0.0f);
+					}
+					wantShadow = S.nLights > 0;
+					if (path) {
+						const f3 albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
+						const f3 rayToHemi = RandomInHemisphere(seed, normal);
+						const f3 cos_i(dot(rayToHemi, normal));
+						nO = I, nD = rayToHemi;
+						nW = W * ((2 * (col * cos_i)) * albedo); // child coefficient of (direct*INVPI + 2*indirect) * albedo
+						if (nDepth >= 0) segmentEnds = false;
+						else Lsum = Lsum + nW * f3(0.05f);
+					}
+				}
+			}
+
+			// write back; a diffuse hit hands the rest of its segment to connect
+			P.E[slot] = mk4(E, __uint_as_float(seed));
+			if (!segmentEnds) {
+				P.O[pout][slot] = mk4(nO, 1e34f);
+				P.D[pout][slot] = mk4(nD, 0.0f);
+				P.W[slot] = mk4(nW, __int_as_float(nDepth));
+				P.L[slot] = mk4(Lsum, __uint_as_float(frame));
+				keep = true;
+				if (wantShadow) P.sh[slot].w = 0.0f; // flag: segment continues after connect
+			} else if (wantShadow) {
+				P.L[slot] = mk4(Lsum, __uint_as_float(frame));
+				P.sh[slot].w = 1.0f; // flag: connect ends the segment
+			} else {
+				keep = next_segment(C, R, P, slot, Lsum, frame, pout);
+			}
+			// connect needs the weight of THIS segment; the continuation's weight was just stored, so
+			// keep the segment's own W beside the light samples
+			if (wantShadow) P.sh[(size_t)S.nLights * P.nSlots + slot] = mk4(W, 0.0f);
+		}
+		queue_append(Q.active[pout], &Q.counts[pout], keep, (uint)slot);
+		queue_append(Q.shadow, &Q.counts[2], wantShadow, (uint)slot);
+	}
+}
+
+// connect: shadow queries and the direct-light terms of a diffuse hit, in light order.
+// Whitted (renderer.cpp:89-105): scatter first (energy changes even when occluded), then the
+// occlusion test.  Path (renderer.cpp:158-176): occlusion test first, scatter only when visible.
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, DCamera C, RenderParams R, PathState P, Queues Q, int parity, uint* spill, DCounters* counters)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	const int n = Q.counts[2];
+	const int pout = 1 - parity;
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	int idx;
+	while (fetch_work(&Q.counts[6], n, idx)) {
+		bool keep = false;
+		int slot = 0;
+		if (idx < n) {
+			slot = (int)Q.shadow[idx];
+			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
+			const int2 id = P.hitId[slot];
+			const float4 e4 = P.E[slot], l4 = P.L[slot];
+			const f3 O = xyz(o4), D = xyz(d4), normal = xyz(hn);
+			const f3 I = O + hn.w * D;
+			const f3 W = xyz(P.sh[(size_t)S.nLights * P.nSlots + slot]);
+			f3 E = xyz(e4), Lsum = xyz(l4);
+			const uint frame = __float_as_uint(l4.w);
+			const bool path = R.mode != 0;
+			const DMaterial m = S.mats[id.y];
+			const f3 col(m.col[0], m.col[1], m.col[2]);
+			const bool endsHere = P.sh[slot].w != 0.0f;
+			const int depth = __float_as_int(P.W[slot].w); // Whitted: depth of this segment (no continuation stored)
+			f3 direct(0.0f);
+			for (int i = 0; i < S.nLights; i++) {
+				const f3 pickedPos = xyz(P.sh[(size_t)i * P.nSlots + slot]);
+				f3 lightRayDirection = pickedPos - I;
+				const float len2 = dot(lightRayDirection, lightRayDirection);
+				lightRayDirection = normalize(lightRayDirection);
+				const f3 sO = I + lightRayDirection * 1e-4f;
+				f3 att(0.0f);
+				if (!path) att = diffuse_scatter(m, D, lightRayDirection, light_intensity(S.lights[i], I, normal, pickedPos), normal, E);
+				Stack st = make_stack(ldsStack, spill, &Q.counts[3]);
+				rays++;
+				if (is_occluded<COUNT>(S, sO, lightRayDirection, sqrtf(len2), st, lc)) continue;
+				if (path) att = diffuse_scatter(m, D, lightRayDirection, light_intensity(S.lights[i], I, normal, pickedPos), normal, E);
+				if (!path && m.shinieness != 0 && depth - 1 > 0) // renderer.cpp:101-102: a mirror branch per visible light
+					push_pending(P, slot, I, reflect(D, normal), W * ((m.shinieness * col) * E), E, depth - 1, &Q.counts[3]);
+				direct = direct + (1 - m.shinieness) * col * att * E;
+			}
+			if (path) {
+				const f3 albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
+				Lsum = Lsum + W * ((direct * RT_INVPI) * albedo); // direct part of (direct*INVPI + 2*indirect) * albedo
+			} else {
+				Lsum = Lsum + W * direct;
+			}
+			P.E[slot] = mk4(E, e4.w);
+			if (endsHere) keep = next_segment(C, R, P, slot, Lsum, frame, pout);
+			else P.L[slot] = mk4(Lsum, l4.w);
+		}
+		queue_append(Q.active[pout], &Q.counts[pout], keep, (uint)slot);
+	}
+	if (COUNT) flush_counters(counters, lc, 0, rays);
+}
+
+// ---- batch queries -------------------------------------------------------------------------------
+struct QueryHit { float t; int objIdx; int mat; float nx, ny, nz; };
+
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, const float* O3, const float* D3, const float* tmax, float t_min,
+                                                            QueryHit* out, uint* spill, int* overflow, DCounters* counters)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const f3 O(O3[3 * i], O3[3 * i + 1], O3[3 * i + 2]), D(D3[3 * i], D3[3 * i + 1], D3[3 * i + 2]);
+		Stack st = make_stack(ldsStack, spill, overflow);
+		HitRef hit;
+		find_nearest<COUNT>(S, O, D, tmax ? tmax[i] : 1e34f, t_min, hit, st, lc);
+		int objIdx, mat;
+		f3 normal;
+		resolve_hit(S, hit, O, D, objIdx, mat, normal);
+		QueryHit q;
+		q.t = hit.t, q.objIdx = objIdx, q.mat = mat, q.nx = normal.x, q.ny = normal.y, q.nz = normal.z;
+		out[i] = q;
+		rays++;
+	}
+	if (COUNT) flush_counters(counters, lc, rays, 0);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax,
+                                                             unsigned char* out, uint* spill, int* overflow, DCounters* counters)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const f3 O(O3[3 * i], O3[3 * i + 1], O3[3 * i + 2]), D(D3[3 * i], D3[3 * i + 1], D3[3 * i + 2]);
+		Stack st = make_stack(ldsStack, spill, overflow);
+		out[i] = is_occluded<COUNT>(S, O, D, tmax ? tmax[i] : 1e34f, st, lc) ? 1 : 0;
+		rays++;
+	}
+	if (COUNT) flush_counters(counters, lc, 0, rays);
+}
+
+// Camera::GetPrimaryRay + Scene::FindNearest for every pixel
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, float t_min, int* objOut, float* tOut, uint* spill, int* overflow, DCounters* counters)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	const int n = C.width * C.height;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		f3 O, D;
+		primary_ray(C, i % C.width, i / C.width, O, D);
+		Stack st = make_stack(ldsStack, spill, overflow);
+		HitRef hit;
+		find_nearest<COUNT>(S, O, D, 1e34f, t_min, hit, st, lc);
+		int objIdx, mat;
+		f3 normal;
+		resolve_hit(S, hit, O, D, objIdx, mat, normal);
+		objOut[i] = objIdx, tOut[i] = hit.t;
+		rays++;
+	}
+	if (COUNT) flush_counters(counters, lc, rays, 0);
+}
+
+// RGBF32_to_RGB8(accumulator / it) (renderer.cpp:287-290, template/precomp.h:445-448)
+__global__ void k_resolve(const float4* accum, int first, int n, int it, uint* out)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float4 a = accum[first + i];
+	const float v[3] = { a.x / it, a.y / it, a.z / it };
+	uint c[3];
+	for (int k = 0; k < 3; k++) {
+		float m = std_min(1.0f, v[k]);
+		float s = 255.0f * m;
+		// (uint) of a negative / NaN float: x86-64 converts through a 64-bit cvttss2si and keeps the low half
+		long long q = (s > -9.2e18f && s < 9.2e18f) ? (long long)s : (long long)0x8000000000000000ull;
+		c[k] = (uint)q;
+	}
+	out[i] = (c[0] << 16) + (c[1] << 8) + c[2];
+}
+
+} // namespace rtd

@@ -1,0 +1,89 @@
+// Renderer (renderer.h, renderer.cpp of the reference): Init / Tick / Trace / Sample with the
+// reference's signatures.  The pixel loop of Tick (renderer.cpp:259-291) is one rt_render() +
+// rt_resolve() pair on the device; Trace and Sample evaluate a caller-supplied ray there too.
+#include "rapt.h"
+#include <stdexcept>
+
+namespace rapt {
+
+static void check(rt_ctx* ctx, int rc)
+{
+	if (rc != RT_OK) throw std::runtime_error(std::string("rt_amd: ") + rt_last_error(ctx));
+}
+
+Renderer::Renderer(int w, int h, int dev) : width(w), height(h), device(dev) { camera.Reset(w, h); }
+Renderer::~Renderer() { Shutdown(); }
+
+void Renderer::Init() // renderer.cpp:5-11: allocate and zero the float4 accumulator
+{
+	if (ctx) return;
+	ctx = rt_create(device, width, height);
+	if (!ctx) throw std::runtime_error(std::string("rt_amd: ") + rt_last_error(nullptr));
+	accumulator = new float4[(size_t)width * height];
+	memset(accumulator, 0, sizeof(float4) * (size_t)width * height);
+	screenPixels = new uint32_t[(size_t)width * height];
+	memset(screenPixels, 0, 4 * (size_t)width * height);
+	frame = 0;
+}
+
+void Renderer::Shutdown()
+{
+	if (ctx) rt_destroy(ctx);
+	ctx = nullptr;
+	delete[] accumulator;
+	delete[] screenPixels;
+	accumulator = nullptr, screenPixels = nullptr;
+}
+
+void Renderer::SyncCamera()
+{
+	rt_camera c;
+	memset(&c, 0, sizeof(c));
+	c.cam_pos[0] = camera.camPos.x, c.cam_pos[1] = camera.camPos.y, c.cam_pos[2] = camera.camPos.z;
+	c.top_left[0] = camera.topLeft.x, c.top_left[1] = camera.topLeft.y, c.top_left[2] = camera.topLeft.z;
+	c.top_right[0] = camera.topRight.x, c.top_right[1] = camera.topRight.y, c.top_right[2] = camera.topRight.z;
+	c.bottom_left[0] = camera.bottomLeft.x, c.bottom_left[1] = camera.bottomLeft.y, c.bottom_left[2] = camera.bottomLeft.z;
+	c.fisheye = camera.fishEye ? 1 : 0, c.view_angle = camera.viewAngle, c.y_angle = camera.yAngle;
+	check(ctx, rt_set_camera(ctx, &c));
+}
+
+// renderer.cpp:240-305 without the animation, input and printf parts
+void Renderer::Tick(float /*deltaTime*/)
+{
+	if (!ctx) Init();
+	scene.totIterationNumber++;
+	int it = scene.GetIterationNumber();
+	const bool camChanged = camera.GetChange() && frame > 0;
+	if (camChanged && !scene.raytracer) { // :253-255, :273-275
+		scene.SetIterationNumber(1);
+		it = 1;
+		check(ctx, rt_clear(ctx));
+	}
+	SyncCamera();
+	const int mode = scene.raytracer ? RT_MODE_WHITTED : RT_MODE_PATH;
+	check(ctx, rt_render(ctx, mode, frame, 1, seedBase, 0, height, 4));
+	if (!scene.raytracer) frame++;
+	check(ctx, rt_resolve(ctx, it, 0, height, screenPixels));
+	if (downloadEachTick) check(ctx, rt_download_accumulator(ctx, 0, height, &accumulator[0].x));
+	if (!scene.raytracer && !camChanged) scene.SetIterationNumber(it + 1); // :293-294
+	camera.SetChange(false);
+}
+
+static float3 eval(rt_ctx* ctx, int mode, const Ray& ray, int depth, uint32_t seed)
+{
+	float rgb[3];
+	check(ctx, rt_trace_batch(ctx, mode, 1, &ray.O.x, &ray.D.x, depth, seed, rgb));
+	return float3(rgb[0], rgb[1], rgb[2]);
+}
+float3 Renderer::Trace(Ray& ray, int depth, float3 energy)
+{
+	if (energy.x != 1 || energy.y != 1 || energy.z != 1) throw std::runtime_error("Renderer::Trace: energy must be float3(1) (its value at the only external call site, renderer.cpp:269)");
+	return eval(ctx, RT_MODE_WHITTED, ray, depth, seedBase);
+}
+float3 Renderer::Sample(Ray& ray, int depth, float3 energy)
+{
+	if (energy.x != 1 || energy.y != 1 || energy.z != 1) throw std::runtime_error("Renderer::Sample: energy must be float3(1) (renderer.cpp:278)");
+	return eval(ctx, RT_MODE_PATH, ray, depth, seedBase);
+}
+
+} // namespace rapt

@@ -1,0 +1,272 @@
+"""Parity of the HIP path (through the C ABI of include/rt_amd.h) with the oracle, on the GPU.
+
+Bar: hit ids (objIdx), material indices and occlusion flags bit-exact; t and normals bit-exact
+(same arithmetic, no contraction); accumulated radiance within 1e-4 relative (BASELINE.json
+north_star), non-finite pixels compared by class (a directly viewed light is +inf in
+the reference)."""
+import numpy as np
+import pytest
+
+from conftest import random_rays, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RADIANCE_TOL = 1e-4  # relative, north_star
+
+
+def make_pair(scene_fn, oracle_api, host_api, w, h, **kw):
+    o = oracle_api.OracleScene()
+    d = scene_fn(o, **kw)
+    r = host_api.HostRenderer(w, h)
+    scene_fn(r.scene, **kw)
+    r.commit()
+    orr = oracle_api.OracleRenderer(o, w, h)
+    if "camera" in d:
+        c = d["camera"]
+        orr.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+        r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+    return o, orr, r, d
+
+
+SCENES = [
+    ("background", {}),
+    ("mixed_small", {}),
+    ("mixed_small", {"split": 1}),
+    ("mixed_small", {"split": 2}),
+    ("mixed_small", {"split": 3}),
+    ("scene3", {"force_diffuse": False}),
+    ("tlas_test2", {}),
+    ("tlas_test2", {"mesh": "BigB"}),
+]
+
+
+@pytest.mark.parametrize("name,kw", SCENES)
+def test_find_nearest_and_occlusion(name, kw, scenes, oracle_api, host_api):
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 64, 48, **kw)
+    O, D = random_rays(6000, 42)
+    pO, pD = orr.primary_rays()
+    O, D = np.concatenate([O, pO]), np.concatenate([D, pD])
+    for t_min in (1e-6, 0.001):
+        ref = o.find_nearest(O, D, t_min=t_min)
+        r.set_counting(True)
+        r.counters()
+        got = r.find_nearest(O, D, t_min=t_min)
+        cnt = r.counters()
+        r.set_counting(False)
+        assert np.array_equal(got["obj"], ref["obj"])
+        assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+        hit = ref["obj"] != -1
+        assert np.array_equal(got["mat"][hit & (ref["mat"] >= 0)], ref["mat"][hit & (ref["mat"] >= 0)])
+        assert np.array_equal(got["normal"][hit].view(np.uint32), ref["normal"][hit].view(np.uint32))
+        for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits", "rays_nearest", "brute_tests", "light_tests"):
+            assert cnt[k] == ref["counters"][k], k
+    # shadow-style queries: bounded tmax
+    tmax = np.random.default_rng(3).uniform(0.1, 12.0, len(O)).astype(np.float32)
+    ref = o.is_occluded(O, D, tmax)
+    r.set_counting(True)
+    r.counters()
+    got = r.is_occluded(O, D, tmax)
+    cnt = r.counters()
+    assert np.array_equal(got, ref["occluded"])
+    for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits", "rays_occluded"):
+        assert cnt[k] == ref["counters"][k], k
+    # tmax on the nearest-hit query too
+    ref = o.find_nearest(O, D, tmax=tmax, t_min=1e-6)
+    got = r.find_nearest(O, D, tmax=tmax, t_min=1e-6)
+    assert np.array_equal(got["obj"], ref["obj"])
+    assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    r.close()
+
+
+def test_config1_primary_hits(scenes, oracle_api, host_api):
+    """BASELINE config 1: ico.obj scene, 256x256, primary rays only -> objIdx and t maps."""
+    o, orr, r, d = make_pair(scenes.config1, oracle_api, host_api, 256, 256)
+    obj_ref, t_ref, _ = orr.primary_hits(1e-6)
+    obj, t = r.primary_hits(1e-6)
+    assert np.array_equal(obj, obj_ref)
+    assert np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    assert len(np.unique(obj_ref)) >= 5  # sky, floor, light, spheres, icosahedra all visible
+    r.close()
+
+
+def check_frames(orr, r, mode, frames, host_api, tol=RADIANCE_TOL):
+    orr.scene.set_raytracer(mode == "whitted")
+    orr.clear()
+    orr.render(0, frames, nthreads=0)
+    ref = orr.accumulator()
+    r.clear()
+    r.render(host_api.RT_MODE_WHITTED if mode == "whitted" else host_api.RT_MODE_PATH, 0, frames)
+    got = r.accumulator()
+    err, cls_ok = rel_err(got[..., :3], ref[..., :3])
+    assert cls_ok, "non-finite pixels differ by class"
+    assert err.max() <= tol, "max relative radiance error %g" % err.max()
+    it = 1 if mode == "whitted" else frames
+    # resolved 8-bit pixels: identical wherever the float accumulators are identical
+    same = (got == ref).all(-1) | (~np.isfinite(ref).all(-1))
+    px, px_ref = r.resolve(it), orr.resolve(it)
+    assert np.array_equal(px[same], px_ref[same])
+    return err.max(), float((got[..., :3] == ref[..., :3]).mean())
+
+
+RENDER_SCENES = [
+    ("background", {}, 96, 64),
+    ("mixed_small", {}, 96, 64),
+    ("scene3", {"force_diffuse": False}, 96, 54),
+    ("scene3", {"force_diffuse": True, "split": 3}, 96, 54),
+    ("tlas_test2", {}, 96, 64),
+    ("pretty_tlas", {"n_instances": 4}, 96, 54),
+]
+
+
+@pytest.mark.parametrize("name,kw,w,h", RENDER_SCENES)
+def test_whitted_frame(name, kw, w, h, scenes, oracle_api, host_api):
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
+    check_frames(orr, r, "whitted", 1, host_api)
+    r.close()
+
+
+@pytest.mark.parametrize("name,kw,w,h", RENDER_SCENES)
+@pytest.mark.parametrize("frames", [1, 4, 16])
+def test_path_frames(name, kw, w, h, frames, scenes, oracle_api, host_api):
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
+    check_frames(orr, r, "path", frames, host_api)
+    r.close()
+
+
+def test_frames_one_by_one_equal_batch(scenes, oracle_api, host_api):
+    """Progressive accumulation: 6 calls of one frame == one call of 6 frames (path regeneration)."""
+    o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 64, 40)
+    r.clear()
+    for f in range(6):
+        r.render(host_api.RT_MODE_PATH, f, 1)
+    a = r.accumulator()
+    r.clear()
+    r.render(host_api.RT_MODE_PATH, 0, 6)
+    b = r.accumulator()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    r.close()
+
+
+def test_tiles_equal_full_frame(scenes, oracle_api, host_api):
+    """Pixel-tile sharding: rendering row bands separately gives the full frame bit for bit
+    (per-pixel RNG streams), which is what makes the multi-GPU shard exact."""
+    o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 64, 48)
+    for mode, frames in ((host_api.RT_MODE_WHITTED, 1), (host_api.RT_MODE_PATH, 3)):
+        r.clear()
+        r.render(mode, 0, frames)
+        full = r.accumulator()
+        r.clear()
+        for y0, y1 in ((0, 7), (7, 30), (30, 48)):
+            r.render(mode, 0, frames, y0=y0, y1=y1)
+        assert np.array_equal(full.view(np.uint32), r.accumulator().view(np.uint32))
+    r.close()
+
+
+def test_trace_batch_and_renderer_surface(scenes, oracle_api, host_api):
+    """Renderer::Trace / Sample on caller rays (rt_trace_batch), Renderer::Tick, and the single-ray
+    Scene::FindNearest / IsOccluded forms."""
+    o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 48, 32)
+    O, D = orr.primary_rays()
+    # Whitted on primary rays == one Whitted frame (no RNG involved)
+    orr.scene.set_raytracer(True)
+    orr.clear(); orr.render(0, 1, nthreads=0)
+    ref = orr.accumulator()[..., :3].reshape(-1, 3)
+    got = r.trace_batch(host_api.RT_MODE_WHITTED, O, D, depth=4)
+    err, cls_ok = rel_err(got, ref)
+    assert cls_ok and err.max() <= RADIANCE_TOL
+    assert np.array_equal(r.trace_batch(host_api.RT_MODE_WHITTED, O[:5], D[:5], depth=0), np.zeros((5, 3), np.float32))
+    one = r.trace_one(O[100], D[100], 4, path=False)
+    assert np.array_equal(one, got[100])
+    # Tick in Whitted mode fills accumulator and pixels
+    r.tick()
+    acc = r.tick_accumulator()
+    e2, c2 = rel_err(acc[..., :3].reshape(-1, 3), ref)
+    assert c2 and e2.max() <= RADIANCE_TOL
+    assert np.array_equal(r.tick_pixels(), r.resolve(1))
+    # Tick in path mode: three ticks == three frames
+    r.scene.set_raytracer(False)
+    r.clear()
+    for _ in range(3):
+        r.tick()
+    orr.scene.set_raytracer(False)
+    orr.clear(); orr.render(0, 3, nthreads=0)
+    e3, c3 = rel_err(r.tick_accumulator()[..., :3], orr.accumulator()[..., :3])
+    assert c3 and e3.max() <= RADIANCE_TOL
+    # single-ray forms
+    for i in (0, 500, 1000, 1535):
+        ref1 = o.find_nearest(O[i:i + 1], D[i:i + 1], t_min=1e-6)
+        t, obj, n = r.scene.find_nearest_one(O[i], D[i], t_min=1e-6)
+        assert obj == ref1["obj"][0] and np.float32(t) == ref1["t"][0]
+        occ = o.is_occluded(O[i:i + 1], D[i:i + 1], np.array([3.0], np.float32))["occluded"][0]
+        assert r.scene.is_occluded_one(O[i], D[i], 3.0) == bool(occ)
+    r.close()
+
+
+def test_edge_cases(scenes, oracle_api, host_api):
+    r = host_api.HostRenderer(16, 8)
+    # calls before a scene is uploaded fail loudly
+    with pytest.raises(RuntimeError):
+        r.render(host_api.RT_MODE_WHITTED)
+    # planes only (no triangles, no spheres): root is a single leaf
+    s = r.scene
+    m = s.diffuse(0.8, (1, 1, 1), 0.0, 1.0, 4)
+    s.plane(0, m, (0, 1, 0), 0)
+    s.area_light(11, (0, 5, 0), 10.0, (1, 1, 1), 1.0, (0, -1, 0))
+    s.build(0)
+    r.commit()
+    o = oracle_api.OracleScene()
+    mo = o.diffuse(0.8, (1, 1, 1), 0.0, 1.0, 4)
+    o.plane(0, mo, (0, 1, 0), 0)
+    o.area_light(11, (0, 5, 0), 10.0, (1, 1, 1), 1.0, (0, -1, 0))
+    o.build(0)
+    O, D = random_rays(512, 5)
+    ref = o.find_nearest(O, D)
+    got = r.find_nearest(O, D)
+    assert np.array_equal(got["obj"], ref["obj"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    # empty batches are accepted
+    assert len(r.find_nearest(np.zeros((0, 3)), np.zeros((0, 3)))["t"]) == 0
+    assert len(r.is_occluded(np.zeros((0, 3)), np.zeros((0, 3)))) == 0
+    # path mode refuses a shiny diffuse material (documented limit) and says why
+    r2 = host_api.HostRenderer(16, 8)
+    s2 = r2.scene
+    m2 = s2.diffuse(0.8, (1, 1, 1), 0.6, 0.4, 4, shininess=0.5)
+    s2.plane(0, m2, (0, 1, 0), 0)
+    s2.area_light(11, (0, 5, 0), 10.0, (1, 1, 1), 1.0, (0, -1, 0))
+    s2.build(0)
+    r2.commit()
+    with pytest.raises(RuntimeError, match="shinieness"):
+        r2.render(host_api.RT_MODE_PATH)
+    r2.render(host_api.RT_MODE_WHITTED)  # Whitted handles it (mirror branch per visible light)
+    o2 = oracle_api.OracleScene()
+    mo2 = o2.diffuse(0.8, (1, 1, 1), 0.6, 0.4, 4, shininess=0.5)
+    o2.plane(0, mo2, (0, 1, 0), 0)
+    o2.area_light(11, (0, 5, 0), 10.0, (1, 1, 1), 1.0, (0, -1, 0))
+    o2.build(0)
+    orr2 = oracle_api.OracleRenderer(o2, 16, 8)
+    orr2.render(0, 1)
+    err, cls_ok = rel_err(r2.accumulator()[..., :3], orr2.accumulator()[..., :3])
+    assert cls_ok and err.max() <= RADIANCE_TOL
+    r.close(); r2.close()
+
+
+def test_full_size_properties(scenes, oracle_api, host_api):
+    """1920x1080 (BASELINE size), where the oracle is too slow to run whole frames: determinism,
+    tile-shard equivalence, and oracle parity on a sampled set of rows."""
+    w, h = 1920, 1080
+    o, orr, r, d = make_pair(scenes.pretty_tlas, oracle_api, host_api, w, h, n_instances=8)
+    r.clear(); r.render(host_api.RT_MODE_PATH, 0, 2)
+    a = r.accumulator()
+    r.clear(); r.render(host_api.RT_MODE_PATH, 0, 2)
+    assert np.array_equal(a.view(np.uint32), r.accumulator().view(np.uint32))  # run-to-run deterministic
+    r.clear()
+    r.render(host_api.RT_MODE_PATH, 0, 2, y0=0, y1=540)
+    r.render(host_api.RT_MODE_PATH, 0, 2, y0=540, y1=1080)
+    assert np.array_equal(a.view(np.uint32), r.accumulator().view(np.uint32))  # two-way shard == whole
+    rows = [0, 333, 540, 777, 1079]
+    orr.scene.set_raytracer(False)
+    for y in rows:
+        orr.render(0, 2, y0=y, y1=y + 1, nthreads=0)
+    ref = orr.accumulator()
+    err, cls_ok = rel_err(a[rows][..., :3], ref[rows][..., :3])
+    assert cls_ok and err.max() <= RADIANCE_TOL
+    r.close()
