@@ -151,6 +151,9 @@ int rt_set_camera(rt_ctx* ctx, const rt_camera* cam);
  * RT_E_UNSUPPORTED in RT_MODE_PATH when a diffuse material has shinieness != 0 or
  * raytracer == 0 (their draws interleave with shadow queries). */
 int rt_render(rt_ctx* ctx, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int y0, int y1, int max_depth);
+/* Same for the rows row_first + k*row_stride, k < row_count: the row-interleaved pixel shard used
+ * when the frame is split over several GPUs (rank r of n renders row_first = r, row_stride = n). */
+int rt_render_rows(rt_ctx* ctx, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int row_first, int row_stride, int row_count, int max_depth);
 /* memset of the accumulator (renderer.cpp:9, :274) */
 int rt_clear(rt_ctx* ctx);
 /* rows [y0, y1) of the float4 accumulator -> host (Renderer::accumulator, renderer.h:98) */
@@ -179,6 +182,8 @@ int rt_trace_batch(rt_ctx* ctx, int mode, int n, const float* O, const float* D,
 /* counting != 0: kernels tally rt_counters (slower; keep off when timing) */
 int rt_set_counting(rt_ctx* ctx, int counting);
 int rt_get_counters(rt_ctx* ctx, rt_counters* out, int reset);
+/* the same tallies kept apart: nearest-hit queries (extend kernel) / occlusion queries (connect) */
+int rt_get_counters_split(rt_ctx* ctx, rt_counters* nearest, rt_counters* occluded, int reset);
 /* profiling != 0: HIP events bracket every kernel launch on the context's stream */
 int rt_set_profiling(rt_ctx* ctx, int profiling);
 int rt_get_profile(rt_ctx* ctx, rt_profile* out, int reset);

@@ -148,8 +148,8 @@ rt_ctx* rt_create(int device, int width, int height)
 	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->flags, 16 * sizeof(int)) == hipSuccess;
 	ok = ok && hipMemset(c->flags, 0, 16 * sizeof(int)) == hipSuccess;
-	ok = ok && hipMalloc((void**)&c->counters, sizeof(DCounters)) == hipSuccess;
-	ok = ok && hipMemset(c->counters, 0, sizeof(DCounters)) == hipSuccess;
+	ok = ok && hipMalloc((void**)&c->counters, 2 * sizeof(DCounters)) == hipSuccess;
+	ok = ok && hipMemset(c->counters, 0, 2 * sizeof(DCounters)) == hipSuccess;
 	ok = ok && hipHostMalloc((void**)&c->hostCounts, 16 * sizeof(int)) == hipSuccess;
 	if (!ok) { fail(nullptr, RT_E_HIP, "rt_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); rt_destroy(c); return nullptr; }
 	// default camera = Camera::Camera (camera.h:10-22) for this aspect
@@ -422,8 +422,8 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, uint frame0, int maxRoun
 		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity);
 		prof_end(c);
 		prof_begin(c, K_CONNECT);
-		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity, c->spill, c->counters);
-		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity, c->spill, c->counters);
+		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity, c->spill, c->counters + 1);
+		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity, c->spill, c->counters + 1);
 		prof_end(c);
 		parity = 1 - parity;
 		// look at the queue length every few rounds (one small D2H copy + sync); stop when it is empty
@@ -440,29 +440,38 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, uint frame0, int maxRoun
 	return RT_OK;
 }
 
-int rt_render(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int y0, int y1, int max_depth)
+int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int row_first, int row_stride, int row_count, int max_depth)
 {
 	if (!c) return RT_E_ARG;
 	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_render: no scene uploaded");
 	if (mode != RT_MODE_WHITTED && mode != RT_MODE_PATH) return fail(c, RT_E_ARG, "rt_render: mode %d", mode);
-	if (y0 < 0 || y1 > c->height || y0 >= y1) return fail(c, RT_E_ARG, "rt_render: rows [%d,%d) outside 0..%d", y0, y1, c->height);
+	if (row_first < 0 || row_stride < 1 || row_count < 1 || row_first + (row_count - 1) * row_stride >= c->height)
+		return fail(c, RT_E_ARG, "rt_render: rows %d + k*%d (k < %d) outside 0..%d", row_first, row_stride, row_count, c->height);
 	if (nframes < 1 || (mode == RT_MODE_WHITTED && nframes != 1)) return fail(c, RT_E_ARG, "rt_render: nframes %d (Whitted frames overwrite the accumulator: 1 only)", nframes);
 	if (mode == RT_MODE_PATH && c->pathUnsupported) return fail(c, RT_E_UNSUPPORTED, "rt_render: path mode unsupported for this scene: %s", c->pathUnsupportedWhy.c_str());
 	HIPCHK(c, hipSetDevice(c->device));
-	const int nSlots = c->width * (y1 - y0);
+	const int nSlots = c->width * row_count;
 	if (mode == RT_MODE_WHITTED && max_depth <= 0) { // Trace(depth <= 0) returns black without tracing
-		HIPCHK(c, hipMemsetAsync(c->accum + (size_t)y0 * c->width, 0, (size_t)nSlots * sizeof(float4), c->stream));
+		for (int k = 0; k < row_count; k++)
+			HIPCHK(c, hipMemsetAsync(c->accum + (size_t)(row_first + k * row_stride) * c->width, 0, (size_t)c->width * sizeof(float4), c->stream));
 		return RT_OK;
 	}
 	int rc = ensure_state(c, nSlots, mode == RT_MODE_WHITTED);
 	if (rc != RT_OK) return rc;
 	RenderParams R;
 	memset(&R, 0, sizeof(R));
-	R.mode = mode, R.frameEnd = frame0 + (uint)nframes, R.seedBase = seed_base, R.y0 = y0, R.maxDepth = max_depth, R.accum = c->accum;
+	R.mode = mode, R.frameEnd = frame0 + (uint)nframes, R.seedBase = seed_base, R.rowFirst = row_first, R.rowStride = row_stride, R.maxDepth = max_depth, R.accum = c->accum;
 	// upper bounds on rounds: a path sample has at most 5 segments (depth 4..0); a Whitted pixel at
 	// most 2^depth - 1 glass segments plus shiny-diffuse branches
 	int maxRounds = mode == RT_MODE_PATH ? 5 * nframes + 4 : ((1 << (max_depth < 12 ? max_depth : 12)) * (1 + c->S.nLights) + 4);
 	return run_rounds(c, R, frame0, maxRounds);
+}
+
+int rt_render(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int y0, int y1, int max_depth)
+{
+	if (!c) return RT_E_ARG;
+	if (y0 < 0 || y1 > c->height || y0 >= y1) return fail(c, RT_E_ARG, "rt_render: rows [%d,%d) outside 0..%d", y0, y1, c->height);
+	return rt_render_rows(c, mode, frame0, nframes, seed_base, y0, 1, y1 - y0, max_depth);
 }
 
 int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, float* rgb_out)
@@ -608,8 +617,8 @@ int rt_occluded_batch(rt_ctx* c, int n, const float* O, const float* D, const fl
 	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, dR, c->spill, c->flags, c->counters);
-		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, dR, c->spill, c->flags, c->counters);
+		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, dR, c->spill, c->flags, c->counters + 1);
+		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, dR, c->spill, c->flags, c->counters + 1);
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}
@@ -649,14 +658,27 @@ int rt_primary_hits(rt_ctx* c, float t_min, int32_t* obj_out, float* t_out)
 
 // ---- measurement ------------------------------------------------------------------------------
 int rt_set_counting(rt_ctx* c, int counting) { if (!c) return RT_E_ARG; c->counting = counting != 0; return RT_OK; }
-int rt_get_counters(rt_ctx* c, rt_counters* out, int reset)
+int rt_get_counters_split(rt_ctx* c, rt_counters* nearest, rt_counters* occluded, int reset)
 {
-	if (!c || !out) return fail(c, RT_E_ARG, "rt_get_counters: null argument");
+	if (!c || !nearest || !occluded) return fail(c, RT_E_ARG, "rt_get_counters: null argument");
 	static_assert(sizeof(rt_counters) == sizeof(DCounters), "rt_counters layout");
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	HIPCHK(c, hipMemcpy(out, c->counters, sizeof(DCounters), hipMemcpyDeviceToHost));
-	if (reset) HIPCHK(c, hipMemset(c->counters, 0, sizeof(DCounters)));
+	DCounters both[2];
+	HIPCHK(c, hipMemcpy(both, c->counters, 2 * sizeof(DCounters), hipMemcpyDeviceToHost));
+	memcpy(nearest, &both[0], sizeof(DCounters)), memcpy(occluded, &both[1], sizeof(DCounters));
+	if (reset) HIPCHK(c, hipMemset(c->counters, 0, 2 * sizeof(DCounters)));
+	return RT_OK;
+}
+int rt_get_counters(rt_ctx* c, rt_counters* out, int reset)
+{
+	if (!out) return fail(c, RT_E_ARG, "rt_get_counters: null argument");
+	rt_counters a, b;
+	int rc = rt_get_counters_split(c, &a, &b, reset);
+	if (rc != RT_OK) return rc;
+	const uint64_t *pa = (const uint64_t*)&a, *pb = (const uint64_t*)&b;
+	uint64_t* po = (uint64_t*)out;
+	for (int i = 0; i < 8; i++) po[i] = pa[i] + pb[i];
 	return RT_OK;
 }
 int rt_set_profiling(rt_ctx* c, int profiling) { if (!c) return RT_E_ARG; prof_collect(c); c->profiling = profiling != 0; return RT_OK; }

@@ -45,7 +45,7 @@ struct RenderParams {
 	int mode;          // RT_MODE_WHITTED / RT_MODE_PATH
 	uint frameEnd;     // frames [.., frameEnd) are rendered
 	uint seedBase;
-	int y0;            // first row of the tile; slot s is pixel y0*width + s
+	int rowFirst, rowStride; // slot s is pixel x = s % width, y = rowFirst + (s / width) * rowStride
 	int maxDepth;      // depth argument of Trace
 	float4* accum;     // accumulator, whole image
 	// rt_trace_batch: caller rays instead of camera rays, raw radiance out instead of accumulation
@@ -223,8 +223,8 @@ __device__ __forceinline__ void start_sample(const DCamera& C, const RenderParam
 		seed = InitSeed(R.seedBase + (uint)slot);
 		depth = R.customDepth;
 	} else {
-		const int pixel = R.y0 * C.width + slot;
-		const int x = pixel % C.width, y = pixel / C.width;
+		const int x = slot % C.width, y = R.rowFirst + (slot / C.width) * R.rowStride;
+		const int pixel = y * C.width + x;
 		seed = InitSeed(R.seedBase + (uint)pixel + frame * (uint)(C.width * C.height));
 		if (R.mode == 0) {
 			primary_ray(C, x, y, O, D);
@@ -252,7 +252,7 @@ __device__ __forceinline__ bool finish_sample(const DCamera& C, const RenderPara
 		R.customOut[slot] = mk4(Lsum, 0.0f);
 		return false;
 	}
-	const int pixel = R.y0 * C.width + slot;
+	const int pixel = (R.rowFirst + (slot / C.width) * R.rowStride) * C.width + slot % C.width;
 	if (R.mode == 0) {
 		f3 v = Lsum / (float)1;
 		R.accum[pixel] = mk4(v, 0.0f);

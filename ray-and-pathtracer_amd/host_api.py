@@ -20,9 +20,9 @@ COUNTER_NAMES = ["inner_visits", "prim_tests", "tlas_inner", "instance_visits",
 
 # every symbol include/rt_amd.h declares
 RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
-              "rt_render", "rt_clear", "rt_download_accumulator", "rt_resolve", "rt_accumulator_device_ptr",
+              "rt_render", "rt_render_rows", "rt_clear", "rt_download_accumulator", "rt_resolve", "rt_accumulator_device_ptr",
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
-              "rt_set_counting", "rt_get_counters", "rt_set_profiling", "rt_get_profile", "rt_synchronize"]
+              "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize"]
 
 
 class RtCamera(C.Structure):
@@ -73,6 +73,8 @@ def rt_lib():
         for name in ["rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_clear", "rt_synchronize"]:
             getattr(L, name).argtypes = [C.c_void_p] + ([C.c_void_p] if name in ("rt_upload_scene", "rt_set_camera") else [])
         L.rt_render.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]
+        L.rt_render_rows.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.rt_get_counters_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.rt_download_accumulator.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.rt_resolve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.rt_bind_accumulator.argtypes = [C.c_void_p, C.c_void_p]
@@ -303,6 +305,9 @@ class HostRenderer:
     def render(self, mode, frame0=0, nframes=1, seed_base=0x12345678, y0=0, y1=None, max_depth=4):
         self._rt(self.rt.rt_render(self.ctx, mode, frame0, nframes, seed_base, y0, self.hgt if y1 is None else y1, max_depth))
 
+    def render_rows(self, mode, frame0, nframes, row_first, row_stride, row_count, seed_base=0x12345678, max_depth=4):
+        self._rt(self.rt.rt_render_rows(self.ctx, mode, frame0, nframes, seed_base, row_first, row_stride, row_count, max_depth))
+
     def clear(self):
         self._rt(self.rt.rt_clear(self.ctx))
 
@@ -363,6 +368,12 @@ class HostRenderer:
         c = np.zeros(8, dtype=np.uint64)
         self._rt(self.rt.rt_get_counters(self.ctx, _p(c), int(reset)))
         return dict(zip(COUNTER_NAMES, [int(x) for x in c]))
+
+    def counters_split(self, reset=True):
+        a = np.zeros(8, dtype=np.uint64)
+        b = np.zeros(8, dtype=np.uint64)
+        self._rt(self.rt.rt_get_counters_split(self.ctx, _p(a), _p(b), int(reset)))
+        return dict(zip(COUNTER_NAMES, [int(x) for x in a])), dict(zip(COUNTER_NAMES, [int(x) for x in b]))
 
     def set_profiling(self, on):
         self._rt(self.rt.rt_set_profiling(self.ctx, int(on)))
