@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,8 @@ struct rt_ctx {
 	std::vector<Timer> timers; // pending event pairs, resolved lazily
 	std::vector<int> timerKind;
 	int* hostCounts = nullptr; // pinned
+	float4* samples = nullptr; // finished samples of the current batch, [frame][tile pixel]
+	size_t sampleCap = 0;
 };
 
 static int fail(rt_ctx* c, int code, const char* fmt, ...)
@@ -173,6 +176,7 @@ void rt_destroy(rt_ctx* c)
 	free_pool(c->stateAllocs);
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
+	if (c->samples) (void)hipFree(c->samples);
 	if (c->flags) (void)hipFree(c->flags);
 	if (c->counters) (void)hipFree(c->counters);
 	if (c->hostCounts) (void)hipHostFree(c->hostCounts);
@@ -368,7 +372,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 // ---- path state -------------------------------------------------------------------------------
 static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 {
-	if (c->stateSlots >= nSlots && c->stateLights == c->S.nLights && (c->statePend || !pend)) { c->P.nSlots = nSlots; if (!pend) {} return RT_OK; }
+	if (c->stateSlots >= nSlots && c->stateLights == c->S.nLights && (c->statePend || !pend)) { c->P.nSlots = nSlots; return RT_OK; }
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	free_pool(c->stateAllocs);
 	c->stateSlots = 0;
@@ -382,6 +386,7 @@ static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 	HIPCHK(c, dalloc(c->stateAllocs, &P.E, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &P.L, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &P.sh, n * (size_t)(c->S.nLights + 1)));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.vis, n));
 	if (pend) {
 		HIPCHK(c, dalloc(c->stateAllocs, &P.pend, n * RT_PEND_CAP * 4));
 		HIPCHK(c, dalloc(c->stateAllocs, &P.pendCount, n));
@@ -391,6 +396,7 @@ static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.active[0], n));
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.active[1], n));
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.shadow, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &Q.done, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.counts, 16));
 	HIPCHK(c, hipMemset(Q.counts, 0, 16 * sizeof(int)));
 	P.nSlots = nSlots;
@@ -398,9 +404,19 @@ static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 	c->stateSlots = nSlots, c->stateLights = c->S.nLights, c->statePend = pend;
 	return RT_OK;
 }
+static int ensure_samples(rt_ctx* c, size_t count)
+{
+	if (c->sampleCap >= count) return RT_OK;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (c->samples) (void)hipFree(c->samples);
+	c->samples = nullptr, c->sampleCap = 0;
+	HIPCHK(c, hipMalloc((void**)&c->samples, count * sizeof(float4)));
+	c->sampleCap = count;
+	return RT_OK;
+}
 
-// The round loop shared by rt_render and rt_trace_batch.
-static int run_rounds(rt_ctx* c, const RenderParams& R, uint frame0, int maxRounds)
+// The round loop shared by rt_render_rows and rt_trace_batch: one pool of R.nSamples samples.
+static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 {
 	PathState P = c->P;
 	if (R.mode != RT_MODE_WHITTED) P.pend = nullptr, P.pendCount = nullptr;
@@ -409,7 +425,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, uint frame0, int maxRoun
 	const float t_min = R.mode == RT_MODE_WHITTED ? (float)1e-6 : 0.001f; // renderer.cpp:24, :131
 	const int grid = c->gridBlocks;
 	prof_begin(c, K_GENERATE);
-	hipLaunchKernelGGL(k_generate, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->C, R, P, Q, frame0);
+	hipLaunchKernelGGL(k_generate, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->C, R, P, Q);
 	prof_end(c);
 	int parity = 0;
 	for (int round = 0; round < maxRounds; round++) {
@@ -419,11 +435,15 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, uint frame0, int maxRoun
 		else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->spill, c->counters);
 		prof_end(c);
 		prof_begin(c, K_SHADE);
-		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity);
+		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
 		prof_end(c);
 		prof_begin(c, K_CONNECT);
-		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity, c->spill, c->counters + 1);
-		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity, c->spill, c->counters + 1);
+		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->spill, c->counters + 1);
+		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->spill, c->counters + 1);
+		prof_end(c);
+		prof_begin(c, K_SHADE);
+		hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
+		hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->C, R, P, Q, parity);
 		prof_end(c);
 		parity = 1 - parity;
 		// look at the queue length every few rounds (one small D2H copy + sync); stop when it is empty
@@ -438,6 +458,21 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, uint frame0, int maxRoun
 	}
 	HIPCHK(c, hipGetLastError());
 	return RT_OK;
+}
+
+static int slot_budget()
+{
+	// slots in flight; more slots = fewer, fuller rounds but more state traffic.  RT_SLOTS overrides.
+	const char* e = getenv("RT_SLOTS");
+	long v = e ? atol(e) : 0;
+	return v > 0 ? (int)v : (1 << 21);
+}
+static int segments_per_sample(int mode, int depth, int nLights)
+{
+	// path: at most 5 segments (depth 4..0); Whitted: at most 2^depth - 1 glass segments, times the
+	// mirror branches of shiny diffuse hits
+	if (mode == RT_MODE_PATH) return depth + 1;
+	return (1 << (depth < 12 ? depth : 12)) * (1 + nLights);
 }
 
 int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int row_first, int row_stride, int row_count, int max_depth)
@@ -456,15 +491,31 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 			HIPCHK(c, hipMemsetAsync(c->accum + (size_t)(row_first + k * row_stride) * c->width, 0, (size_t)c->width * sizeof(float4), c->stream));
 		return RT_OK;
 	}
-	int rc = ensure_state(c, nSlots, mode == RT_MODE_WHITTED);
+	// batches of frames: the finished samples of a batch live in a [frame][pixel] buffer (<= 4 GiB)
+	const size_t tilePixels = (size_t)nSlots;
+	int batchFrames = (int)(((size_t)4 << 30) / (tilePixels * sizeof(float4)));
+	if (batchFrames < 1) batchFrames = 1;
+	if (batchFrames > nframes) batchFrames = nframes;
+	int rc = ensure_samples(c, tilePixels * batchFrames);
 	if (rc != RT_OK) return rc;
-	RenderParams R;
-	memset(&R, 0, sizeof(R));
-	R.mode = mode, R.frameEnd = frame0 + (uint)nframes, R.seedBase = seed_base, R.rowFirst = row_first, R.rowStride = row_stride, R.maxDepth = max_depth, R.accum = c->accum;
-	// upper bounds on rounds: a path sample has at most 5 segments (depth 4..0); a Whitted pixel at
-	// most 2^depth - 1 glass segments plus shiny-diffuse branches
-	int maxRounds = mode == RT_MODE_PATH ? 5 * nframes + 4 : ((1 << (max_depth < 12 ? max_depth : 12)) * (1 + c->S.nLights) + 4);
-	return run_rounds(c, R, frame0, maxRounds);
+	for (int f = 0; f < nframes; f += batchFrames) {
+		const int bf = nframes - f < batchFrames ? nframes - f : batchFrames;
+		const size_t total = tilePixels * bf;
+		const int slots = (int)(total < (size_t)slot_budget() ? total : (size_t)slot_budget());
+		rc = ensure_state(c, slots, mode == RT_MODE_WHITTED);
+		if (rc != RT_OK) return rc;
+		RenderParams R;
+		memset(&R, 0, sizeof(R));
+		R.mode = mode, R.frame0 = frame0 + (uint)f, R.nSamples = (uint)total, R.tilePixels = (uint)tilePixels, R.samples = c->samples;
+		R.seedBase = seed_base, R.rowFirst = row_first, R.rowStride = row_stride, R.maxDepth = max_depth, R.accum = c->accum;
+		const int seg = segments_per_sample(mode, mode == RT_MODE_PATH ? 4 : max_depth, c->S.nLights);
+		const int maxRounds = (int)((total + slots - 1) / slots) * seg + seg + 4;
+		rc = run_rounds(c, R, maxRounds);
+		if (rc != RT_OK) return rc;
+		hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
+	}
+	HIPCHK(c, hipGetLastError());
+	return RT_OK;
 }
 
 int rt_render(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int y0, int y1, int max_depth)
@@ -486,7 +537,8 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 		for (int i = 0; i < 3 * n; i++) rgb_out[i] = v;
 		return RT_OK;
 	}
-	int rc = ensure_state(c, n, mode == RT_MODE_WHITTED);
+	const int slots = n < slot_budget() ? n : slot_budget();
+	int rc = ensure_state(c, slots, mode == RT_MODE_WHITTED);
 	if (rc != RT_OK) return rc;
 	float *dO = nullptr, *dD = nullptr;
 	float4* dOut = nullptr;
@@ -498,10 +550,10 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 	HIPCHK(c, hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream));
 	RenderParams R;
 	memset(&R, 0, sizeof(R));
-	R.mode = mode, R.frameEnd = 1, R.seedBase = seed_base, R.maxDepth = depth, R.accum = c->accum;
+	R.mode = mode, R.nSamples = (uint)n, R.tilePixels = (uint)n, R.seedBase = seed_base, R.maxDepth = depth, R.accum = c->accum;
 	R.customO = dO, R.customD = dD, R.customOut = dOut, R.customDepth = depth;
-	int maxRounds = mode == RT_MODE_PATH ? depth + 6 : ((1 << (depth < 12 ? depth : 12)) * (1 + c->S.nLights) + 4);
-	rc = run_rounds(c, R, 0, maxRounds);
+	const int seg = segments_per_sample(mode, depth, c->S.nLights);
+	rc = run_rounds(c, R, ((n + slots - 1) / slots) * seg + seg + 4);
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);
 		hipError_t e = hipMemcpy(out4.data(), dOut, (size_t)16 * n, hipMemcpyDeviceToHost);

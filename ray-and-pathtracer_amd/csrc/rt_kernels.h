@@ -1,19 +1,22 @@
-// Wavefront kernels of the pixel loop: generate -> [extend -> shade -> connect]* .
+// Wavefront kernels of the pixel loop: generate -> [extend -> shade -> connect -> light -> finish]* -> accumulate.
 //
-// One *slot* per pixel of the rendered tile holds the state of the path currently being traced
-// for that pixel (SoA arrays in HBM, 16-byte elements so every lane moves whole dwordx4s).  Each
-// round runs three kernels over compacted queues of slot ids:
+// Work unit: one *sample* = (pixel, frame).  The samples of a render call form a pool ordered
+// frame-major; a fixed set of *slots* (SoA path state in HBM, 16-byte elements so every lane moves
+// whole dwordx4s) pulls samples from the pool, so queues stay full until the pool is empty no matter
+// how path lengths vary over the image.  Each round runs over compacted queues of slot ids:
 //   extend   Scene::FindNearest for every active slot                       (the dominant kernel)
-//   shade    the body of Renderer::Trace / Renderer::Sample at the hit: leaf terms, material
-//            switch, light sampling, the next ray; survivors are appended to the next queue with a
-//            wave-wide ballot + prefix count and one atomic per wave
-//   connect  Scene::IsOccluded for the slots that sampled lights, then the direct-light terms in
-//            light order (their energy bookkeeping feeds the next bounce)
-// A finished path adds its sample to the accumulator and, while frames remain, the slot is
-// re-seeded with the next frame's primary ray in the same step (path regeneration), so queues stay
-// full until the last frames.  Sums are carried forward as path weights (W) instead of being
-// combined on return from recursion; per pixel the segment order is the reference's depth-first
-// order, so no atomics touch radiance and results do not depend on queue order.
+//   shade    the body of Renderer::Trace / Renderer::Sample at the hit: leaf terms, material switch,
+//            light sampling, the next ray
+//   connect  Scene::IsOccluded towards every sampled light (traversal only, one bit per light)
+//   light    the direct-light terms of a diffuse hit, in light order (their energy bookkeeping
+//            feeds the next bounce)
+//   finish   slots whose segment ended: resume a pending Whitted branch, or store the finished
+//            sample and pull the next one from the pool (new primary ray)
+// Queue appends use a wave-wide ballot + prefix count and one atomic per wave.  Finished samples go
+// to a [frame][pixel] buffer; accumulate adds them to the accumulator in frame order, so the sum is
+// the one a sequential Tick loop produces (renderer.cpp:279-282) and nothing depends on queue order.
+// Radiance is carried forward as path weights (W) instead of being combined on return from
+// recursion; per sample the segment order is the reference's depth-first order.
 #pragma once
 #include "rt_scene_dev.h"
 
@@ -34,8 +37,9 @@ struct PathState {
 	int2* hitId;     // objIdx, material
 	float4* W;       // path weight xyz, w = depth (int bits)
 	float4* E;       // energy xyz, w = RNG state (uint bits)
-	float4* L;       // radiance of the current sample xyz, w = frame (uint bits)
+	float4* L;       // radiance of the current sample xyz, w = sample id in the pool (uint bits)
 	float4* sh;      // [light][slot] sampled light position xyz (plane 0: w = flags); plane nLights: weight of the segment
+	uint* vis;       // [slot] bit i set: light i is occluded
 	float4* pend;    // [slot][RT_PEND_CAP][4]: pending Whitted branches {O,depth} {D,-} {W,-} {E,-}
 	int* pendCount;  // [slot]
 	int nSlots;
@@ -43,7 +47,10 @@ struct PathState {
 
 struct RenderParams {
 	int mode;          // RT_MODE_WHITTED / RT_MODE_PATH
-	uint frameEnd;     // frames [.., frameEnd) are rendered
+	uint frame0;       // first frame of this batch
+	uint nSamples;     // pool size = batch frames * tile pixels
+	uint tilePixels;   // pixels in the tile (rows of this shard * width)
+	float4* samples;   // [batch frame][tile pixel] finished samples (gamma applied in path mode)
 	uint seedBase;
 	int rowFirst, rowStride; // slot s is pixel x = s % width, y = rowFirst + (s / width) * rowStride
 	int maxDepth;      // depth argument of Trace
@@ -55,7 +62,9 @@ struct RenderParams {
 struct Queues {
 	uint* active[2];
 	uint* shadow;
-	int* counts; // [0],[1]: active sizes by parity, [2]: shadow size, [3]: overflow flag, [4..6]: work heads
+	uint* done;  // slots whose segment ended this round
+	int* counts; // [0],[1] active sizes by parity, [2] shadow size, [3] overflow flag, [4] extend head, [5] shade head,
+	             // [6] connect head, [7] next sample in the pool, [8] done size, [9] light head, [10] finish head
 };
 
 // ---- camera (camera.h:24-41) ---------------------------------------------------------------
@@ -163,29 +172,45 @@ __device__ __forceinline__ f3 diffuse_scatter(const DMaterial& m, const f3& rayD
 	return att;
 }
 
-// wave-aggregated queue append: one atomic per wave (ballot + prefix popcount)
-__device__ __forceinline__ void queue_append(uint* q, int* count, bool want, uint value)
+// wave-aggregated queue append: one atomic per wave (ballot + prefix popcount).  Must be reached by
+// every lane of the wave (it shuffles).
+__device__ __forceinline__ int queue_reserve(int* count, bool want)
 {
 	const unsigned long long mask = __ballot(want);
-	if (mask == 0) return;
+	if (mask == 0) return -1;
 	const uint lane = threadIdx.x & 63;
 	const int leader = __ffsll((long long)mask) - 1;
 	int base = 0;
 	if ((int)lane == leader) base = atomicAdd(count, __popcll(mask));
 	base = __shfl(base, leader);
-	if (want) q[base + __popcll(mask & ((1ull << lane) - 1))] = value;
+	return base + __popcll(mask & ((1ull << lane) - 1));
+}
+__device__ __forceinline__ void queue_append(uint* q, int* count, bool want, uint value)
+{
+	const int pos = queue_reserve(count, want);
+	if (want) q[pos] = value;
 }
 
-// dynamic work fetch: each wave takes 64 queue entries at a time from a shared head
-__device__ __forceinline__ bool fetch_work(int* head, int n, int& idx)
+// Dynamic work distribution: a wave takes RT_FETCH * 64 consecutive queue entries per atomic on the
+// kernel's work head and calls body(idx, live) for each of them with the whole wave converged
+// (live == false pads the last batch, so bodies may use wave-wide operations).
+#define RT_FETCH 4
+template <typename F>
+__device__ __forceinline__ void for_each_work(int* head, int n, F body)
 {
 	const uint lane = threadIdx.x & 63;
-	int base = 0;
-	if (lane == 0) base = atomicAdd(head, 64);
-	base = __shfl(base, 0);
-	if (base >= n) return false;
-	idx = base + (int)lane;
-	return true;
+	while (true) {
+		int base = 0;
+		if (lane == 0) base = atomicAdd(head, 64 * RT_FETCH);
+		base = __shfl(base, 0);
+		if (base >= n) break;
+		for (int k = 0; k < RT_FETCH; k++) {
+			const int first = base + 64 * k;
+			if (first >= n) break;
+			const int idx = first + (int)lane;
+			body(idx, idx < n);
+		}
+	}
 }
 
 __device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* overflow)
@@ -211,19 +236,20 @@ __device__ __forceinline__ void flush_counters(DCounters* g, const LaneCounters&
 	}
 }
 
-// Start (or restart) the sample of 'frame' in a slot: seed, jitter, primary ray (renderer.cpp:263-278)
-__device__ __forceinline__ void start_sample(const DCamera& C, const RenderParams& R, PathState& P, int slot, uint frame, int parityOut)
+// Put sample 'sid' of the pool into a slot: seed, jitter, primary ray (renderer.cpp:263-278)
+__device__ __forceinline__ void start_sample(const DCamera& C, const RenderParams& R, PathState& P, int slot, uint sid, int parityOut)
 {
 	f3 O, D;
 	uint seed = 0;
 	int depth;
 	if (R.customO) {
-		O = f3(R.customO[3 * slot], R.customO[3 * slot + 1], R.customO[3 * slot + 2]);
-		D = f3(R.customD[3 * slot], R.customD[3 * slot + 1], R.customD[3 * slot + 2]);
-		seed = InitSeed(R.seedBase + (uint)slot);
+		O = f3(R.customO[3 * sid], R.customO[3 * sid + 1], R.customO[3 * sid + 2]);
+		D = f3(R.customD[3 * sid], R.customD[3 * sid + 1], R.customD[3 * sid + 2]);
+		seed = InitSeed(R.seedBase + sid);
 		depth = R.customDepth;
 	} else {
-		const int x = slot % C.width, y = R.rowFirst + (slot / C.width) * R.rowStride;
+		const uint lp = sid % R.tilePixels, frame = R.frame0 + sid / R.tilePixels;
+		const int x = (int)(lp % (uint)C.width), y = R.rowFirst + (int)(lp / (uint)C.width) * R.rowStride;
 		const int pixel = y * C.width + x;
 		seed = InitSeed(R.seedBase + (uint)pixel + frame * (uint)(C.width * C.height));
 		if (R.mode == 0) {
@@ -240,58 +266,8 @@ __device__ __forceinline__ void start_sample(const DCamera& C, const RenderParam
 	P.D[parityOut][slot] = mk4(D, 0.0f);
 	P.W[slot] = make_float4(1, 1, 1, __int_as_float(depth));
 	P.E[slot] = make_float4(1, 1, 1, __uint_as_float(seed));
-	P.L[slot] = make_float4(0, 0, 0, __uint_as_float(frame));
+	P.L[slot] = make_float4(0, 0, 0, __uint_as_float(sid));
 	if (P.pendCount) P.pendCount[slot] = 0;
-}
-
-// The sample in 'slot' is complete: accumulate it (renderer.cpp:270 / :279-282).  Returns true
-// when the slot was restarted with the next frame (caller appends it to the next queue).
-__device__ __forceinline__ bool finish_sample(const DCamera& C, const RenderParams& R, PathState& P, int slot, const f3& Lsum, uint frame, int parityOut)
-{
-	if (R.customOut) {
-		R.customOut[slot] = mk4(Lsum, 0.0f);
-		return false;
-	}
-	const int pixel = (R.rowFirst + (slot / C.width) * R.rowStride) * C.width + slot % C.width;
-	if (R.mode == 0) {
-		f3 v = Lsum / (float)1;
-		R.accum[pixel] = mk4(v, 0.0f);
-		return false;
-	}
-	float4 a = R.accum[pixel];
-	a.x += x_powf(Lsum.x * 1, RT_GAMMA);
-	a.y += x_powf(Lsum.y * 1, RT_GAMMA);
-	a.z += x_powf(Lsum.z * 1, RT_GAMMA);
-	a.w += 0;
-	R.accum[pixel] = a;
-	if (frame + 1 < R.frameEnd) {
-		start_sample(C, R, P, slot, frame + 1, parityOut);
-		return true;
-	}
-	return false;
-}
-
-// A segment ended without a continuation ray: resume the most recent pending Whitted branch, or
-// finish the sample.  Returns true when the slot stays active.
-__device__ __forceinline__ bool next_segment(const DCamera& C, const RenderParams& R, PathState& P, int slot, const f3& Lsum, uint frame, int parityOut)
-{
-	if (P.pendCount) {
-		int n = P.pendCount[slot];
-		if (n > 0) {
-			n--;
-			const float4* e = P.pend + ((size_t)slot * RT_PEND_CAP + n) * 4;
-			const float4 o = e[0], d = e[1], w = e[2], en = e[3];
-			P.O[parityOut][slot] = make_float4(o.x, o.y, o.z, 1e34f);
-			P.D[parityOut][slot] = make_float4(d.x, d.y, d.z, 0.0f);
-			P.W[slot] = make_float4(w.x, w.y, w.z, o.w);
-			const float seedBits = P.E[slot].w;
-			P.E[slot] = make_float4(en.x, en.y, en.z, seedBits);
-			P.L[slot] = mk4(Lsum, __uint_as_float(frame));
-			P.pendCount[slot] = n;
-			return true;
-		}
-	}
-	return finish_sample(C, R, P, slot, Lsum, frame, parityOut);
 }
 
 __device__ __forceinline__ void push_pending(PathState& P, int slot, const f3& O, const f3& D, const f3& W, const f3& E, int depth, int* overflow)
@@ -305,21 +281,21 @@ __device__ __forceinline__ void push_pending(PathState& P, int slot, const f3& O
 
 // ---- kernels -----------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(RT_BLOCK) k_generate(DCamera C, RenderParams R, PathState P, Queues Q, uint frame0)
+__global__ void __launch_bounds__(RT_BLOCK) k_generate(DCamera C, RenderParams R, PathState P, Queues Q)
 {
 	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= P.nSlots) return;
-	start_sample(C, R, P, slot, frame0, 0);
+	start_sample(C, R, P, slot, (uint)slot, 0); // slots take the first nSlots samples of the pool
 	Q.active[0][slot] = (uint)slot;
-	if (slot == 0) { Q.counts[0] = P.nSlots; Q.counts[1] = 0; Q.counts[2] = 0; }
+	if (slot == 0) { Q.counts[0] = P.nSlots; Q.counts[1] = 0; Q.counts[2] = 0; Q.counts[7] = P.nSlots; Q.counts[8] = 0; }
 }
 
 // round bookkeeping between kernels: reset heads and the queues about to be refilled
 __global__ void k_round_begin(Queues Q, int parityIn)
 {
 	Q.counts[1 - parityIn] = 0;
-	Q.counts[2] = 0;
-	Q.counts[4] = 0, Q.counts[5] = 0, Q.counts[6] = 0;
+	Q.counts[2] = 0, Q.counts[8] = 0;
+	Q.counts[4] = 0, Q.counts[5] = 0, Q.counts[6] = 0, Q.counts[9] = 0, Q.counts[10] = 0;
 }
 
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
@@ -332,10 +308,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queu
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	int idx;
-	while (fetch_work(&Q.counts[4], n, idx)) {
-		// no 'continue' here: the wave must be converged again when it reaches fetch_work's shuffle
-		if (idx < n) {
+	for_each_work(&Q.counts[4], n, [&](int idx, bool live) {
+		if (live) {
 			const int slot = (int)Q.active[parity][idx];
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
 			const f3 O = xyz(o4), D = xyz(d4);
@@ -349,37 +323,39 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queu
 			P.hitId[slot] = make_int2(objIdx, mat);
 			rays++;
 		}
-	}
+	});
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
 // shade: everything Trace / Sample do at a hit except the occlusion-dependent direct terms.
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, DCamera C, RenderParams R, PathState P, Queues Q, int parity)
+// Outcomes per slot: continue with a new ray (next active queue), hand the diffuse direct terms to
+// connect + light (shadow queue), or end the segment (done queue).
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity)
 {
 	const int n = Q.counts[parity];
 	const int pout = 1 - parity;
-	int idx;
-	while (fetch_work(&Q.counts[5], n, idx)) {
-		bool live = idx < n;
-		bool keep = false, wantShadow = false;
+	for_each_work(&Q.counts[5], n, [&](int idx, bool live) {
+		bool keep = false, wantShadow = false, ended = false;
 		int slot = 0;
 		if (live) {
 			slot = (int)Q.active[parity][idx];
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
 			const int2 id = P.hitId[slot];
-			float4 w4 = P.W[slot], e4 = P.E[slot], l4 = P.L[slot];
+			const float4 w4 = P.W[slot], e4 = P.E[slot], l4 = P.L[slot];
 			const f3 O = xyz(o4), D = xyz(d4), normal = xyz(hn);
 			const float t = hn.w;
 			f3 W = xyz(w4), E = xyz(e4), Lsum = xyz(l4);
 			const int depth = __float_as_int(w4.w);
 			uint seed = __float_as_uint(e4.w);
-			const uint frame = __float_as_uint(l4.w);
 			const bool path = R.mode != 0;
 			const f3 I = O + t * D; // ray.IntersectionPoint()
 
 			bool segmentEnds = true; // no continuation ray unless a material creates one
 			f3 nO(0.0f), nD(0.0f), nW(0.0f);
-			int nDepth = depth - 1;
+			const int nDepth = depth - 1;
+			// a child at depth-1 that cannot trace contributes its terminal value right here:
+			// Trace(depth <= 0) = 0 (renderer.cpp:23), Sample(depth < 0) = 0.05 (:129)
+			const bool childTraces = path ? (nDepth >= 0) : (nDepth > 0);
 
 			if (id.x == -1) {
 				Lsum = Lsum + W * sky_color(S, D); // renderer.cpp:26 / :134
@@ -418,9 +394,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, DCamera C, RenderP
 						reflO = outside ? I + bias : I - bias;
 						reflW = W * (col * kr);
 					}
-					// a child at depth-1 that cannot trace contributes its terminal value right here:
-					// Trace(depth <= 0) = 0 (renderer.cpp:23), Sample(depth < 0) = 0.05 (:129)
-					const bool childTraces = path ? (nDepth >= 0) : (nDepth > 0);
 					if (!childTraces) {
 						if (path) Lsum = Lsum + (takeRefr ? refrW : reflW) * f3(0.05f);
 					} else if (takeRefr) {
@@ -430,10 +403,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, DCamera C, RenderP
 						nO = reflO, nD = reflD, nW = reflW, segmentEnds = false;
 					}
 				} else if (m.type == 2) { // METAL, renderer.cpp:81-86 / :192-197, metal::scatter template/scene.h:630-635
-					const f3 dir = reflect(D, normal);
-					nO = I + normal * 0.001f, nD = dir;
+					nO = I + normal * 0.001f, nD = reflect(D, normal);
 					nW = path ? W * col : W * (col * E);
-					const bool childTraces = path ? (nDepth >= 0) : (nDepth > 0);
 					if (childTraces) segmentEnds = false;
 					else if (path) Lsum = Lsum + nW * f3(0.05f);
 				} else { // DIFFUSE, renderer.cpp:87-122 / :156-191
@@ -448,79 +419,98 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, DCamera C, RenderP
 						const f3 cos_i(dot(rayToHemi, normal));
 						nO = I, nD = rayToHemi;
 						nW = W * ((2 * (col * cos_i)) * albedo); // child coefficient of (direct*INVPI + 2*indirect) * albedo
-						if (nDepth >= 0) segmentEnds = false;
+						if (childTraces) segmentEnds = false;
 						else Lsum = Lsum + nW * f3(0.05f);
 					}
 				}
 			}
 
-			// write back; a diffuse hit hands the rest of its segment to connect
 			P.E[slot] = mk4(E, __uint_as_float(seed));
+			P.L[slot] = mk4(Lsum, l4.w);
+			if (wantShadow) {
+				// light keeps working on THIS segment: it needs the segment's own weight and whether the
+				// segment ends there (the continuation's weight goes to P.W below)
+				P.sh[(size_t)S.nLights * P.nSlots + slot] = mk4(W, segmentEnds ? 1.0f : 0.0f);
+			}
 			if (!segmentEnds) {
 				P.O[pout][slot] = mk4(nO, 1e34f);
 				P.D[pout][slot] = mk4(nD, 0.0f);
 				P.W[slot] = mk4(nW, __int_as_float(nDepth));
-				P.L[slot] = mk4(Lsum, __uint_as_float(frame));
 				keep = true;
-				if (wantShadow) P.sh[slot].w = 0.0f; // flag: segment continues after connect
-			} else if (wantShadow) {
-				P.L[slot] = mk4(Lsum, __uint_as_float(frame));
-				P.sh[slot].w = 1.0f; // flag: connect ends the segment
-			} else {
-				keep = next_segment(C, R, P, slot, Lsum, frame, pout);
+			} else if (!wantShadow) {
+				ended = true;
 			}
-			// connect needs the weight of THIS segment; the continuation's weight was just stored, so
-			// keep the segment's own W beside the light samples
-			if (wantShadow) P.sh[(size_t)S.nLights * P.nSlots + slot] = mk4(W, 0.0f);
 		}
 		queue_append(Q.active[pout], &Q.counts[pout], keep, (uint)slot);
 		queue_append(Q.shadow, &Q.counts[2], wantShadow, (uint)slot);
-	}
+		queue_append(Q.done, &Q.counts[8], ended, (uint)slot);
+	});
 }
 
-// connect: shadow queries and the direct-light terms of a diffuse hit, in light order.
-// Whitted (renderer.cpp:89-105): scatter first (energy changes even when occluded), then the
-// occlusion test.  Path (renderer.cpp:158-176): occlusion test first, scatter only when visible.
+// connect: Scene::IsOccluded from the hit point towards each sampled light position
+// (renderer.cpp:93-99 / :161-165).  Traversal only; bit i of vis[slot] = light i occluded.
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, DCamera C, RenderParams R, PathState P, Queues Q, int parity, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Queues Q, int parity, uint* spill, DCounters* counters)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
 	const int n = Q.counts[2];
-	const int pout = 1 - parity;
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	int idx;
-	while (fetch_work(&Q.counts[6], n, idx)) {
-		bool keep = false;
-		int slot = 0;
-		if (idx < n) {
-			slot = (int)Q.shadow[idx];
+	for_each_work(&Q.counts[6], n, [&](int idx, bool live) {
+		if (live) {
+			const int slot = (int)Q.shadow[idx];
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
-			const int2 id = P.hitId[slot];
-			const float4 e4 = P.E[slot], l4 = P.L[slot];
-			const f3 O = xyz(o4), D = xyz(d4), normal = xyz(hn);
-			const f3 I = O + hn.w * D;
-			const f3 W = xyz(P.sh[(size_t)S.nLights * P.nSlots + slot]);
-			f3 E = xyz(e4), Lsum = xyz(l4);
-			const uint frame = __float_as_uint(l4.w);
-			const bool path = R.mode != 0;
-			const DMaterial m = S.mats[id.y];
-			const f3 col(m.col[0], m.col[1], m.col[2]);
-			const bool endsHere = P.sh[slot].w != 0.0f;
-			const int depth = __float_as_int(P.W[slot].w); // Whitted: depth of this segment (no continuation stored)
-			f3 direct(0.0f);
+			const f3 I = xyz(o4) + hn.w * xyz(d4);
+			uint bits = 0;
 			for (int i = 0; i < S.nLights; i++) {
 				const f3 pickedPos = xyz(P.sh[(size_t)i * P.nSlots + slot]);
 				f3 lightRayDirection = pickedPos - I;
 				const float len2 = dot(lightRayDirection, lightRayDirection);
 				lightRayDirection = normalize(lightRayDirection);
 				const f3 sO = I + lightRayDirection * 1e-4f;
+				Stack st = make_stack(ldsStack, spill, &Q.counts[3]);
+				if (is_occluded<COUNT>(S, sO, lightRayDirection, sqrtf(len2), st, lc)) bits |= 1u << i;
+				rays++;
+			}
+			P.vis[slot] = bits;
+		}
+	});
+	if (COUNT) flush_counters(counters, lc, 0, rays);
+}
+
+// light: the direct-light terms of a diffuse hit, in light order.
+// Whitted (renderer.cpp:89-105): scatter first (energy changes even when occluded), then the
+// occlusion test.  Path (renderer.cpp:158-176): occlusion test first, scatter only when visible.
+__global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, PathState P, Queues Q, int parity)
+{
+	const int n = Q.counts[2];
+	for_each_work(&Q.counts[9], n, [&](int idx, bool live) {
+		bool ended = false;
+		int slot = 0;
+		if (live) {
+			slot = (int)Q.shadow[idx];
+			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
+			const int2 id = P.hitId[slot];
+			const float4 e4 = P.E[slot], l4 = P.L[slot];
+			const float4 w4 = P.sh[(size_t)S.nLights * P.nSlots + slot];
+			const f3 D = xyz(d4), normal = xyz(hn);
+			const f3 I = xyz(o4) + hn.w * D;
+			const f3 W = xyz(w4);
+			f3 E = xyz(e4), Lsum = xyz(l4);
+			const bool path = R.mode != 0;
+			const DMaterial m = S.mats[id.y];
+			const f3 col(m.col[0], m.col[1], m.col[2]);
+			const uint bits = P.vis[slot];
+			const int depth = __float_as_int(P.W[slot].w); // Whitted: depth of this segment (a diffuse hit stores no continuation)
+			f3 direct(0.0f);
+			for (int i = 0; i < S.nLights; i++) {
+				const f3 pickedPos = xyz(P.sh[(size_t)i * P.nSlots + slot]);
+				const f3 lightRayDirection = normalize(pickedPos - I);
+				const bool occluded = (bits >> i) & 1;
 				f3 att(0.0f);
 				if (!path) att = diffuse_scatter(m, D, lightRayDirection, light_intensity(S.lights[i], I, normal, pickedPos), normal, E);
-				Stack st = make_stack(ldsStack, spill, &Q.counts[3]);
-				rays++;
-				if (is_occluded<COUNT>(S, sO, lightRayDirection, sqrtf(len2), st, lc)) continue;
+				if (occluded) continue;
 				if (path) att = diffuse_scatter(m, D, lightRayDirection, light_intensity(S.lights[i], I, normal, pickedPos), normal, E);
 				if (!path && m.shinieness != 0 && depth - 1 > 0) // renderer.cpp:101-102: a mirror branch per visible light
 					push_pending(P, slot, I, reflect(D, normal), W * ((m.shinieness * col) * E), E, depth - 1, &Q.counts[3]);
@@ -533,12 +523,74 @@ __global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, DCamera C, Rende
 				Lsum = Lsum + W * direct;
 			}
 			P.E[slot] = mk4(E, e4.w);
-			if (endsHere) keep = next_segment(C, R, P, slot, Lsum, frame, pout);
-			else P.L[slot] = mk4(Lsum, l4.w);
+			P.L[slot] = mk4(Lsum, l4.w);
+			ended = w4.w != 0.0f;
+		}
+		queue_append(Q.done, &Q.counts[8], ended, (uint)slot);
+	});
+}
+
+// finish: a slot's segment ended without a continuation ray.  Resume the most recent pending
+// Whitted branch if there is one; otherwise the sample is complete: store it (renderer.cpp:270 /
+// :279-282, gamma per sample) and pull the next sample from the pool.
+__global__ void __launch_bounds__(RT_BLOCK) k_finish(DCamera C, RenderParams R, PathState P, Queues Q, int parity)
+{
+	const int n = Q.counts[8];
+	const int pout = 1 - parity;
+	for_each_work(&Q.counts[10], n, [&](int idx, bool live) {
+		bool keep = false, wantSample = false;
+		int slot = 0;
+		if (live) {
+			slot = (int)Q.done[idx];
+			int np = P.pendCount ? P.pendCount[slot] : 0;
+			if (np > 0) {
+				np--;
+				const float4* e = P.pend + ((size_t)slot * RT_PEND_CAP + np) * 4;
+				const float4 o = e[0], d = e[1], w = e[2], en = e[3];
+				P.O[pout][slot] = make_float4(o.x, o.y, o.z, 1e34f);
+				P.D[pout][slot] = make_float4(d.x, d.y, d.z, 0.0f);
+				P.W[slot] = make_float4(w.x, w.y, w.z, o.w);
+				P.E[slot] = make_float4(en.x, en.y, en.z, P.E[slot].w);
+				P.pendCount[slot] = np;
+				keep = true;
+			} else {
+				const float4 l4 = P.L[slot];
+				const uint sid = __float_as_uint(l4.w);
+				float4 v;
+				if (R.customOut) { R.customOut[sid] = make_float4(l4.x, l4.y, l4.z, 0.0f); }
+				else {
+					if (R.mode == 0) v = make_float4(l4.x / (float)1, l4.y / (float)1, l4.z / (float)1, 0.0f);
+					else v = make_float4(x_powf(l4.x * 1, RT_GAMMA), x_powf(l4.y * 1, RT_GAMMA), x_powf(l4.z * 1, RT_GAMMA), 0.0f);
+					R.samples[sid] = v;
+				}
+				wantSample = true;
+			}
+		}
+		// next sample of the pool for every slot that just completed one (one atomic per wave)
+		const int sidNext = queue_reserve(&Q.counts[7], wantSample);
+		if (wantSample && (uint)sidNext < R.nSamples) {
+			start_sample(C, R, P, slot, (uint)sidNext, pout);
+			keep = true;
 		}
 		queue_append(Q.active[pout], &Q.counts[pout], keep, (uint)slot);
+	});
+}
+
+// accumulate: add the finished samples of a batch to the accumulator in frame order
+// (renderer.cpp:270: overwrite in Whitted mode; :282: += in path mode)
+__global__ void k_accumulate(DCamera C, RenderParams R, int batchFrames)
+{
+	const uint lp = blockIdx.x * blockDim.x + threadIdx.x;
+	if (lp >= R.tilePixels) return;
+	const int x = (int)(lp % (uint)C.width), y = R.rowFirst + (int)(lp / (uint)C.width) * R.rowStride;
+	const int pixel = y * C.width + x;
+	if (R.mode == 0) { R.accum[pixel] = R.samples[lp]; return; }
+	float4 a = R.accum[pixel];
+	for (int f = 0; f < batchFrames; f++) {
+		const float4 s = R.samples[(size_t)f * R.tilePixels + lp];
+		a.x += s.x, a.y += s.y, a.z += s.z, a.w += 0;
 	}
-	if (COUNT) flush_counters(counters, lc, 0, rays);
+	R.accum[pixel] = a;
 }
 
 // ---- batch queries -------------------------------------------------------------------------------
