@@ -43,6 +43,7 @@ struct rt_ctx {
 	// traversal stack spill + flags
 	uint* spill = nullptr;
 	int gridBlocks = 0;
+	int refillMin = 16; // idle lanes a wave waits for before it refills them (RT_REFILL)
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
 	bool counting = false, profiling = false;
@@ -148,6 +149,9 @@ rt_ctx* rt_create(int device, int width, int height)
 	// launch geometry: enough 256-lane blocks to fill 256 CUs at 8 blocks per CU; queues are drained
 	// through shared work heads, so the same grid serves every queue length
 	c->gridBlocks = prop.multiProcessorCount * 8;
+	if (getenv("RT_REFILL")) c->refillMin = atoi(getenv("RT_REFILL"));
+	if (c->refillMin < 1) c->refillMin = 1;
+	if (c->refillMin > 64) c->refillMin = 64;
 	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->flags, 16 * sizeof(int)) == hipSuccess;
 	ok = ok && hipMemset(c->flags, 0, 16 * sizeof(int)) == hipSuccess;
@@ -386,7 +390,7 @@ static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 	HIPCHK(c, dalloc(c->stateAllocs, &P.E, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &P.L, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &P.sh, n * (size_t)(c->S.nLights + 1)));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.vis, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.vis, n * (size_t)(c->S.nLights + 1)));
 	if (pend) {
 		HIPCHK(c, dalloc(c->stateAllocs, &P.pend, n * RT_PEND_CAP * 4));
 		HIPCHK(c, dalloc(c->stateAllocs, &P.pendCount, n));
@@ -431,15 +435,15 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 	for (int round = 0; round < maxRounds; round++) {
 		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, c->stream, Q, parity);
 		prof_begin(c, K_EXTEND);
-		if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->spill, c->counters);
-		else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->spill, c->counters);
+		if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
+		else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
 		prof_end(c);
 		prof_begin(c, K_SHADE);
 		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
 		prof_end(c);
 		prof_begin(c, K_CONNECT);
-		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->spill, c->counters + 1);
-		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->spill, c->counters + 1);
+		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->refillMin, c->spill, c->counters + 1);
+		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->refillMin, c->spill, c->counters + 1);
 		prof_end(c);
 		prof_begin(c, K_SHADE);
 		hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
@@ -612,11 +616,11 @@ int rt_bind_accumulator(rt_ctx* c, void* p)
 static int check_overflow(rt_ctx* c)
 {
 	int f = 0;
-	HIPCHK(c, hipMemcpy(&f, c->flags, sizeof(int), hipMemcpyDeviceToHost));
-	if (f) { (void)hipMemset(c->flags, 0, sizeof(int)); return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX); }
+	HIPCHK(c, hipMemcpy(&f, c->flags + 1, sizeof(int), hipMemcpyDeviceToHost));
+	if (f) { (void)hipMemset(c->flags, 0, 2 * sizeof(int)); return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX); }
 	return RT_OK;
 }
-static int query_grid(rt_ctx* c, int n) { int g = (n + RT_BLOCK - 1) / RT_BLOCK; return g < 1 ? 1 : (g > c->gridBlocks ? c->gridBlocks : g); }
+static int query_grid(rt_ctx* c, int n) { int g = (n + RT_CHUNK - 1) / RT_CHUNK / 4 + 1; return g > c->gridBlocks ? c->gridBlocks : g; }
 
 int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out)
 {
@@ -636,9 +640,10 @@ int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const f
 	if (e == hipSuccess) e = hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
+		(void)hipMemsetAsync(c->flags, 0, sizeof(int), c->stream); // queue head
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_query_nearest<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, dH, c->spill, c->flags, c->counters);
-		else hipLaunchKernelGGL(k_query_nearest<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, dH, c->spill, c->flags, c->counters);
+		if (c->counting) hipLaunchKernelGGL(k_query_nearest<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, c->refillMin, dH, c->spill, c->flags, c->counters);
+		else hipLaunchKernelGGL(k_query_nearest<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, c->refillMin, dH, c->spill, c->flags, c->counters);
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}
@@ -668,9 +673,10 @@ int rt_occluded_batch(rt_ctx* c, int n, const float* O, const float* D, const fl
 	if (e == hipSuccess) e = hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
+		(void)hipMemsetAsync(c->flags, 0, sizeof(int), c->stream); // queue head
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, dR, c->spill, c->flags, c->counters + 1);
-		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, dR, c->spill, c->flags, c->counters + 1);
+		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, c->refillMin, dR, c->spill, c->flags, c->counters + 1);
+		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, c->refillMin, dR, c->spill, c->flags, c->counters + 1);
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}
@@ -694,9 +700,10 @@ int rt_primary_hits(rt_ctx* c, float t_min, int32_t* obj_out, float* t_out)
 	hipError_t e = dalloc(tmp, &dO, (size_t)n);
 	if (e == hipSuccess) e = dalloc(tmp, &dT, (size_t)n);
 	if (e == hipSuccess) {
+		(void)hipMemsetAsync(c->flags, 0, sizeof(int), c->stream); // queue head
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_primary_hits<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, dO, dT, c->spill, c->flags, c->counters);
-		else hipLaunchKernelGGL(k_primary_hits<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, dO, dT, c->spill, c->flags, c->counters);
+		if (c->counting) hipLaunchKernelGGL(k_primary_hits<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, c->refillMin, dO, dT, c->spill, c->flags, c->counters);
+		else hipLaunchKernelGGL(k_primary_hits<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, c->refillMin, dO, dT, c->spill, c->flags, c->counters);
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}

@@ -39,7 +39,7 @@ struct PathState {
 	float4* E;       // energy xyz, w = RNG state (uint bits)
 	float4* L;       // radiance of the current sample xyz, w = sample id in the pool (uint bits)
 	float4* sh;      // [light][slot] sampled light position xyz (plane 0: w = flags); plane nLights: weight of the segment
-	uint* vis;       // [slot] bit i set: light i is occluded
+	unsigned char* vis; // [light][slot] 1: the light is occluded
 	float4* pend;    // [slot][RT_PEND_CAP][4]: pending Whitted branches {O,depth} {D,-} {W,-} {E,-}
 	int* pendCount;  // [slot]
 	int nSlots;
@@ -213,17 +213,6 @@ __device__ __forceinline__ void for_each_work(int* head, int n, F body)
 	}
 }
 
-__device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* overflow)
-{
-	Stack st;
-	st.lds = ldsBase + threadIdx.x;
-	st.spillStride = gridDim.x * blockDim.x;
-	st.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
-	st.sp = 0;
-	st.overflow = overflow;
-	return st;
-}
-
 __device__ __forceinline__ void flush_counters(DCounters* g, const LaneCounters& lc, uint nearest, uint occluded)
 {
 	// wave reduction, then one atomic per field per wave
@@ -300,30 +289,38 @@ __global__ void k_round_begin(Queues Q, int parityIn)
 
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
 // (renderer.cpp:24, :131); it applies to lights and brute-force primitives, the BVH uses 0.0001.
+struct ExtendPolicy {
+	const DScene& S;
+	PathState& P;
+	const uint* queue;
+	int parity;
+	__device__ __forceinline__ void load(int work, f3& O, f3& D, float& tmax) const
+	{
+		const int slot = (int)queue[work];
+		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
+		O = xyz(o4), D = xyz(d4), tmax = o4.w;
+	}
+	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
+	{
+		// the ray in registers may be the object-space one; the sphere normal needs the world ray
+		const int slot = (int)queue[work];
+		const f3 O = xyz(P.O[parity][slot]), D = xyz(P.D[parity][slot]);
+		int objIdx, mat;
+		f3 normal;
+		resolve_hit(S, hit, O, D, objIdx, mat, normal);
+		P.hitN[slot] = mk4(normal, hit.t);
+		P.hitId[slot] = make_int2(objIdx, mat);
+	}
+};
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
-	const int n = Q.counts[parity];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	for_each_work(&Q.counts[4], n, [&](int idx, bool live) {
-		if (live) {
-			const int slot = (int)Q.active[parity][idx];
-			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
-			const f3 O = xyz(o4), D = xyz(d4);
-			Stack st = make_stack(ldsStack, spill, &Q.counts[3]);
-			HitRef hit;
-			find_nearest<COUNT>(S, O, D, o4.w, t_min, hit, st, lc);
-			int objIdx, mat;
-			f3 normal;
-			resolve_hit(S, hit, O, D, objIdx, mat, normal);
-			P.hitN[slot] = mk4(normal, hit.t);
-			P.hitId[slot] = make_int2(objIdx, mat);
-			rays++;
-		}
-	});
+	ExtendPolicy pol{ S, P, Q.active[parity], parity };
+	trace_persistent<false, COUNT>(S, pol, Q.counts[parity], &Q.counts[4], t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
@@ -448,34 +445,38 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, Pa
 }
 
 // connect: Scene::IsOccluded from the hit point towards each sampled light position
-// (renderer.cpp:93-99 / :161-165).  Traversal only; bit i of vis[slot] = light i occluded.
+// (renderer.cpp:93-99 / :161-165).  Traversal only.  Work item = (shadow-queue entry, light);
+// vis[light][slot] = 1 when that light is occluded.
+struct ConnectPolicy {
+	PathState& P;
+	const uint* queue;
+	int parity, nLights;
+	__device__ __forceinline__ void load(int work, f3& O, f3& D, float& tmax) const
+	{
+		const int slot = (int)queue[work / nLights], li = work % nLights;
+		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
+		const f3 I = xyz(o4) + hn.w * xyz(d4);
+		const f3 pickedPos = xyz(P.sh[(size_t)li * P.nSlots + slot]);
+		f3 lightRayDirection = pickedPos - I;
+		const float len2 = dot(lightRayDirection, lightRayDirection);
+		lightRayDirection = normalize(lightRayDirection);
+		O = I + lightRayDirection * 1e-4f, D = lightRayDirection, tmax = sqrtf(len2);
+	}
+	__device__ __forceinline__ void store(int work, bool occluded) const
+	{
+		const int slot = (int)queue[work / nLights], li = work % nLights;
+		P.vis[(size_t)li * P.nSlots + slot] = occluded ? 1 : 0;
+	}
+};
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Queues Q, int parity, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Queues Q, int parity, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
-	const int n = Q.counts[2];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	for_each_work(&Q.counts[6], n, [&](int idx, bool live) {
-		if (live) {
-			const int slot = (int)Q.shadow[idx];
-			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
-			const f3 I = xyz(o4) + hn.w * xyz(d4);
-			uint bits = 0;
-			for (int i = 0; i < S.nLights; i++) {
-				const f3 pickedPos = xyz(P.sh[(size_t)i * P.nSlots + slot]);
-				f3 lightRayDirection = pickedPos - I;
-				const float len2 = dot(lightRayDirection, lightRayDirection);
-				lightRayDirection = normalize(lightRayDirection);
-				const f3 sO = I + lightRayDirection * 1e-4f;
-				Stack st = make_stack(ldsStack, spill, &Q.counts[3]);
-				if (is_occluded<COUNT>(S, sO, lightRayDirection, sqrtf(len2), st, lc)) bits |= 1u << i;
-				rays++;
-			}
-			P.vis[slot] = bits;
-		}
-	});
+	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights };
+	trace_persistent<true, COUNT>(S, pol, Q.counts[2] * S.nLights, &Q.counts[6], 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -501,13 +502,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 			const bool path = R.mode != 0;
 			const DMaterial m = S.mats[id.y];
 			const f3 col(m.col[0], m.col[1], m.col[2]);
-			const uint bits = P.vis[slot];
 			const int depth = __float_as_int(P.W[slot].w); // Whitted: depth of this segment (a diffuse hit stores no continuation)
 			f3 direct(0.0f);
 			for (int i = 0; i < S.nLights; i++) {
 				const f3 pickedPos = xyz(P.sh[(size_t)i * P.nSlots + slot]);
 				const f3 lightRayDirection = normalize(pickedPos - I);
-				const bool occluded = (bits >> i) & 1;
+				const bool occluded = P.vis[(size_t)i * P.nSlots + slot] != 0;
 				f3 att(0.0f);
 				if (!path) att = diffuse_scatter(m, D, lightRayDirection, light_intensity(S.lights[i], I, normal, pickedPos), normal, E);
 				if (occluded) continue;
@@ -596,68 +596,87 @@ __global__ void k_accumulate(DCamera C, RenderParams R, int batchFrames)
 // ---- batch queries -------------------------------------------------------------------------------
 struct QueryHit { float t; int objIdx; int mat; float nx, ny, nz; };
 
-template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, const float* O3, const float* D3, const float* tmax, float t_min,
-                                                            QueryHit* out, uint* spill, int* overflow, DCounters* counters)
-{
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
-	LaneCounters lc;
-	lc.clear();
-	uint rays = 0;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const f3 O(O3[3 * i], O3[3 * i + 1], O3[3 * i + 2]), D(D3[3 * i], D3[3 * i + 1], D3[3 * i + 2]);
-		Stack st = make_stack(ldsStack, spill, overflow);
-		HitRef hit;
-		find_nearest<COUNT>(S, O, D, tmax ? tmax[i] : 1e34f, t_min, hit, st, lc);
+struct ArrayRays {
+	const float* O3; const float* D3; const float* tmax;
+	__device__ __forceinline__ void load(int i, f3& O, f3& D, float& tm) const
+	{
+		O = f3(O3[3 * i], O3[3 * i + 1], O3[3 * i + 2]), D = f3(D3[3 * i], D3[3 * i + 1], D3[3 * i + 2]);
+		tm = tmax ? tmax[i] : 1e34f;
+	}
+};
+struct NearestQueryPolicy : ArrayRays {
+	const DScene& S; QueryHit* out;
+	__device__ __forceinline__ NearestQueryPolicy(const DScene& s, const float* o, const float* d, const float* t, QueryHit* q) : ArrayRays{ o, d, t }, S(s), out(q) {}
+	__device__ __forceinline__ void store(int i, const HitRef& hit, const f3&, const f3&) const
+	{
+		f3 O, D;
+		float tm;
+		load(i, O, D, tm);
 		int objIdx, mat;
 		f3 normal;
 		resolve_hit(S, hit, O, D, objIdx, mat, normal);
 		QueryHit q;
 		q.t = hit.t, q.objIdx = objIdx, q.mat = mat, q.nx = normal.x, q.ny = normal.y, q.nz = normal.z;
 		out[i] = q;
-		rays++;
 	}
-	if (COUNT) flush_counters(counters, lc, rays, 0);
-}
-
-template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax,
-                                                             unsigned char* out, uint* spill, int* overflow, DCounters* counters)
-{
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
-	LaneCounters lc;
-	lc.clear();
-	uint rays = 0;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const f3 O(O3[3 * i], O3[3 * i + 1], O3[3 * i + 2]), D(D3[3 * i], D3[3 * i + 1], D3[3 * i + 2]);
-		Stack st = make_stack(ldsStack, spill, overflow);
-		out[i] = is_occluded<COUNT>(S, O, D, tmax ? tmax[i] : 1e34f, st, lc) ? 1 : 0;
-		rays++;
-	}
-	if (COUNT) flush_counters(counters, lc, 0, rays);
-}
-
+};
+struct OccludedQueryPolicy : ArrayRays {
+	unsigned char* out;
+	__device__ __forceinline__ OccludedQueryPolicy(const float* o, const float* d, const float* t, unsigned char* q) : ArrayRays{ o, d, t }, out(q) {}
+	__device__ __forceinline__ void store(int i, bool occluded) const { out[i] = occluded ? 1 : 0; }
+};
 // Camera::GetPrimaryRay + Scene::FindNearest for every pixel
-template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, float t_min, int* objOut, float* tOut, uint* spill, int* overflow, DCounters* counters)
-{
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
-	LaneCounters lc;
-	lc.clear();
-	uint rays = 0;
-	const int n = C.width * C.height;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+struct PrimaryPolicy {
+	const DScene& S; const DCamera& C; int* objOut; float* tOut;
+	__device__ __forceinline__ void load(int i, f3& O, f3& D, float& tm) const { primary_ray(C, i % C.width, i / C.width, O, D); tm = 1e34f; }
+	__device__ __forceinline__ void store(int i, const HitRef& hit, const f3&, const f3&) const
+	{
 		f3 O, D;
-		primary_ray(C, i % C.width, i / C.width, O, D);
-		Stack st = make_stack(ldsStack, spill, overflow);
-		HitRef hit;
-		find_nearest<COUNT>(S, O, D, 1e34f, t_min, hit, st, lc);
+		float tm;
+		load(i, O, D, tm);
 		int objIdx, mat;
 		f3 normal;
 		resolve_hit(S, hit, O, D, objIdx, mat, normal);
 		objOut[i] = objIdx, tOut[i] = hit.t;
-		rays++;
 	}
+};
+
+// work[0] is the queue head (zeroed by the host before the launch), work[1] the overflow flag
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, const float* O3, const float* D3, const float* tmax, float t_min, int refillMin,
+                                                            QueryHit* out, uint* spill, int* work, DCounters* counters)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	NearestQueryPolicy pol(S, O3, D3, tmax, out);
+	trace_persistent<false, COUNT>(S, pol, n, &work[0], t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
+	if (COUNT) flush_counters(counters, lc, rays, 0);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax, int refillMin,
+                                                             unsigned char* out, uint* spill, int* work, DCounters* counters)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	OccludedQueryPolicy pol(O3, D3, tmax, out);
+	trace_persistent<true, COUNT>(S, pol, n, &work[0], 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	if (COUNT) flush_counters(counters, lc, 0, rays);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, float t_min, int refillMin, int* objOut, float* tOut, uint* spill, int* work, DCounters* counters)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	PrimaryPolicy pol{ S, C, objOut, tOut };
+	trace_persistent<false, COUNT>(S, pol, C.width * C.height, &work[0], t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 

@@ -98,6 +98,17 @@ struct Stack {
 	}
 };
 
+__device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* overflow)
+{
+	Stack st;
+	st.lds = ldsBase + threadIdx.x;
+	st.spillStride = gridDim.x * blockDim.x;
+	st.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	st.sp = 0;
+	st.overflow = overflow;
+	return st;
+}
+
 // What a nearest-hit query tracks while it runs; resolved to normal / ids once at the end.
 struct HitRef {
 	float t;
@@ -107,116 +118,6 @@ struct HitRef {
 };
 
 __device__ __forceinline__ f3 rcp3(const f3& D) { return f3(1 / D.x, 1 / D.y, 1 / D.z); } // template/scene.h:47
-
-// Leaf loop shared by both traversals (bvh.cpp:616-629 / :770-783).  ANY: return true at the first
-// occluder.  t_min is the BVH's hard-coded 0.0001f (bvh.cpp:607, :764).
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool leaf_prims(const float4* __restrict__ prims, uint first, const f3& O, const f3& D, float& rayT,
-                                           HitRef& hit, int inst, LaneCounters& lc)
-{
-	const float t_min = 0.0001f;
-	uint slot = first;
-	while (true) {
-		const float4 r0 = prims[4 * slot + 0];
-		const float4 r3 = prims[4 * slot + 3];
-		const int kl = __float_as_int(r3.w);
-		const int kind = kl & 3;
-		if (COUNT) lc.prim++;
-		float t;
-		bool h;
-		if (kind == RT_KIND_TRI) {
-			const float4 r1 = prims[4 * slot + 1];
-			const float4 r2 = prims[4 * slot + 2];
-			h = tri_hit(O, D, rayT, t_min, xyz(r0), xyz(r1), xyz(r2), f3(r0.w, r1.w, r2.w), r3.x, t);
-		} else if (kind == RT_KIND_SPHERE) {
-			if (ANY) h = sphere_occludes(O, D, rayT, t_min, xyz(r0), r0.w);
-			else h = sphere_hit(O, D, rayT, t_min, xyz(r0), r0.w, t);
-		} else {
-			h = plane_hit(O, D, rayT, t_min, xyz(r0), r0.w, t);
-		}
-		if (h) {
-			if (ANY) return true;
-			rayT = t, hit.t = t, hit.prim = slot, hit.inst = inst, hit.kind = 0;
-		}
-		if (kl & RT_LAST_BIT) break;
-		slot++;
-	}
-	return false;
-}
-
-// bvh::BIntersect / BIsOccluded (bvh.cpp:606-656, 763-806) on one BLAS, entered with an empty
-// sub-stack (stack.sp == base).  Ordered traversal: near child first, far child pushed when hit.
-// Returns true (ANY only) when an occluder was found.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse_blas(const DScene& S, uint link, const f3& O, const f3& D, const f3& rD, float& rayT,
-                                              HitRef& hit, int inst, Stack& st, uint base, LaneCounters& lc)
-{
-	if (link == RT_EMPTY) return false;
-	while (true) {
-		if (link & RT_LEAF_BIT) {
-			if (leaf_prims<ANY, COUNT>(S.prims, link & ~RT_LEAF_BIT, O, D, rayT, hit, inst, lc)) return true;
-			if (st.sp == base) return false;
-			link = st.pop();
-			continue;
-		}
-		if (COUNT) lc.inner++;
-		const float4* p = S.pairs + 4 * (size_t)link;
-		const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-		float dist1 = intersect_aabb(O, rD, rayT, xyz(a0), xyz(a1));
-		float dist2 = intersect_aabb(O, rD, rayT, xyz(b0), xyz(b1));
-		uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
-		if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
-		if (dist1 == 1e30f) {
-			if (st.sp == base) return false;
-			link = st.pop();
-		} else {
-			link = c1;
-			if (dist2 != 1e30f) st.push(c2);
-		}
-	}
-}
-
-// tlas::Intersect / IsOccluded (tlas.cpp:65-122) with bvhInstance::BIntersect / IsOccluded
-// (bvhInstance.cpp:3-35) inlined: the ray is taken to object space with invTransform (direction not
-// renormalised, so t is shared by both spaces), the BLAS is walked on the same stack above the
-// TLAS entries, and the world-space ray is re-derived from (Ow, Dw) on the way out.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse_tlas(const DScene& S, const f3& Ow, const f3& Dw, const f3& rDw, float& rayT,
-                                              HitRef& hit, Stack& st, LaneCounters& lc)
-{
-	uint node = 0;
-	const uint base = st.sp;
-	while (true) {
-		const float4 n0 = S.tlas[2 * node], n1 = S.tlas[2 * node + 1];
-		const uint leftRight = __float_as_uint(n0.w);
-		if (leftRight == 0) {
-			const int inst = (int)__float_as_uint(n1.w);
-			if (COUNT) lc.inst++;
-			const DInstance* I = S.inst + inst;
-			const f3 O = xform_pos(I->invT, Ow);
-			const f3 D = xform_vec(I->invT, Dw);
-			const f3 rD = rcp3(D);
-			if (traverse_blas<ANY, COUNT>(S, I->rootLink, O, D, rD, rayT, hit, inst, st, st.sp, lc)) return true;
-			if (st.sp == base) return false;
-			node = st.pop();
-			continue;
-		}
-		if (COUNT) lc.tlasInner++;
-		uint c1 = leftRight & 0xFFFFu, c2 = leftRight >> 16;
-		const float4 a0 = S.tlas[2 * c1], a1 = S.tlas[2 * c1 + 1];
-		const float4 b0 = S.tlas[2 * c2], b1 = S.tlas[2 * c2 + 1];
-		float dist1 = intersect_aabb(Ow, rDw, rayT, xyz(a0), xyz(a1));
-		float dist2 = intersect_aabb(Ow, rDw, rayT, xyz(b0), xyz(b1));
-		if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
-		if (dist1 == 1e30f) {
-			if (st.sp == base) return false;
-			node = st.pop();
-		} else {
-			node = c1;
-			if (dist2 != 1e30f) st.push(c2);
-		}
-	}
-}
 
 // AreaLight::Intersect (template/scene.h:105-120): overwrites t without comparing it to the
 // current one, and evaluates 't - 1e-6' in double.
@@ -238,40 +139,197 @@ __device__ __forceinline__ void light_intersect(const DLight& L, int li, const f
 	}
 }
 
-// Scene::FindNearest (template/scene.h:1248-1267)
-template <bool COUNT>
-__device__ __forceinline__ void find_nearest(const DScene& S, const f3& O, const f3& D, float rayT, float t_min, HitRef& hit, Stack& st, LaneCounters& lc)
-{
-	hit.kind = -1, hit.inst = -1, hit.prim = 0, hit.t = rayT;
-	for (int i = 0; i < S.nLights; i++) {
-		light_intersect(S.lights[i], i, O, D, t_min, rayT, hit);
-		if (COUNT) lc.light++;
-	}
-	const f3 rD = rcp3(D);
-	if (S.useTLAS) {
-		const int nb = S.nBruteSph + S.nBrutePla;
-		for (int i = 0; i < nb; i++) {
-			const float4 r0 = S.brute[4 * i];
-			float t;
-			bool h = i < S.nBruteSph ? sphere_hit(O, D, rayT, t_min, xyz(r0), r0.w, t) : plane_hit(O, D, rayT, t_min, xyz(r0), r0.w, t);
-			if (COUNT) lc.brute++;
-			if (h) rayT = t, hit.t = t, hit.kind = 1, hit.prim = (uint)i, hit.inst = -1;
-		}
-		traverse_tlas<false, COUNT>(S, O, D, rD, rayT, hit, st, lc);
-	} else {
-		traverse_blas<false, COUNT>(S, S.rootLink, O, D, rD, rayT, hit, -1, st, st.sp, lc);
-	}
-	hit.t = rayT;
-}
+// ---- persistent, lane-granular traversal --------------------------------------------------------
+// Rays in one wave need very different numbers of node visits, so a wave that walks 64 rays to
+// completion idles most of its lanes most of the time (measured: 12 % VALU lane utilisation).
+// Here every lane runs a small state machine -- one step = one sibling-pair test, one primitive
+// test or one TLAS node -- and a lane whose ray is finished takes the next ray of the queue while
+// the others keep walking.  The visiting ORDER per ray is exactly the reference's
+// (bvh.cpp:606-656, 763-806; tlas.cpp:65-122; bvhInstance.cpp:3-35): near child first, far child
+// pushed, leaf primitives in primitiveIdx order, t_min 0.0001 inside the BVH.
+//
+// A *policy* supplies the rays and takes the results:
+//   bool load(int work, f3& O, f3& D, float& tmax)   world-space ray of work item 'work'
+//   void store(int work, const HitRef&, O, D)         nearest-hit result      (ANY == false)
+//   void store(int work, bool occluded)               occlusion result        (ANY == true)
+#define RT_TLAS_BIT 0x40000000u
+#define RT_LINK_POP 0xFFFFFFFDu
+#define RT_CHUNK 256 // queue entries a wave reserves per atomic on the work head
 
-// Scene::IsOccluded(Ray&) (template/scene.h:1286-1291)
-template <bool COUNT>
-__device__ __forceinline__ bool is_occluded(const DScene& S, const f3& O, const f3& D, float rayT, Stack& st, LaneCounters& lc)
+template <bool ANY, bool COUNT, class Policy>
+__device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* head, float t_min, int refillMin,
+                                                 uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
-	HitRef dummy;
-	const f3 rD = rcp3(D);
-	if (S.useTLAS) return traverse_tlas<true, COUNT>(S, O, D, rD, rayT, dummy, st, lc);
-	return traverse_blas<true, COUNT>(S, S.rootLink, O, D, rD, rayT, dummy, -1, st, st.sp, lc);
+	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
+	const uint lane = threadIdx.x & 63;
+	const unsigned long long below = (1ull << lane) - 1;
+	Stack st = make_stack(ldsStack, spill, overflow);
+	int work = -1;           // queue entry this lane is tracing, -1 = idle
+	int chunkNext = 0, chunkEnd = 0; // wave-uniform: reserved, not yet handed out
+	bool exhausted = false;  // wave-uniform: the queue has no more entries
+	f3 O(0.0f), D(0.0f), rD(0.0f);
+	float rayT = 0;
+	uint link = RT_LINK_POP;
+	HitRef hit;
+	hit.kind = -1, hit.inst = -1, hit.prim = 0, hit.t = 0;
+	int inst = -1;
+
+	while (true) {
+		// ---- refill idle lanes ----
+		const bool idle = work < 0;
+		const unsigned long long idleMask = __ballot(idle);
+		if (idleMask != 0 && !exhausted) {
+			const int cnt = __popcll(idleMask);
+			if (cnt >= refillMin || idleMask == ~0ull) {
+				if (chunkNext >= chunkEnd) {
+					int base = 0;
+					if (lane == 0) base = atomicAdd(head, RT_CHUNK);
+					base = __shfl(base, 0);
+					chunkNext = base, chunkEnd = base + RT_CHUNK < n ? base + RT_CHUNK : n;
+					if (base >= n) exhausted = true;
+				}
+				if (!exhausted) {
+					const int mine = chunkNext + __popcll(idleMask & below);
+					const int avail = chunkEnd - chunkNext;
+					if (idle && mine < chunkEnd) {
+						work = mine;
+						float tmax;
+						pol.load(work, O, D, tmax);
+						rayT = tmax;
+						st.sp = 0, inst = -1;
+						hit.kind = -1, hit.inst = -1, hit.prim = 0;
+						if (!ANY) {
+							// Scene::FindNearest head (template/scene.h:1257-1261): lights, then in TLAS mode the
+							// brute-force spheres and planes, all with the caller's t_min
+							for (int i = 0; i < S.nLights; i++) {
+								light_intersect(S.lights[i], i, O, D, t_min, rayT, hit);
+								if (COUNT) lc.light++;
+							}
+							if (S.useTLAS) {
+								const int nb = S.nBruteSph + S.nBrutePla;
+								for (int i = 0; i < nb; i++) {
+									const float4 r0 = S.brute[4 * i];
+									float t;
+									const bool h = i < S.nBruteSph ? sphere_hit(O, D, rayT, t_min, xyz(r0), r0.w, t) : plane_hit(O, D, rayT, t_min, xyz(r0), r0.w, t);
+									if (COUNT) lc.brute++;
+									if (h) rayT = t, hit.kind = 1, hit.prim = (uint)i, hit.inst = -1;
+								}
+							}
+						}
+						rD = rcp3(D);
+						link = S.useTLAS ? RT_TLAS_BIT : S.rootLink;
+						if (link == RT_EMPTY) link = RT_LINK_POP;
+						rays++;
+					}
+					chunkNext += cnt < avail ? cnt : avail;
+				}
+			}
+		}
+		if (__ballot(work >= 0) == 0) {
+			if (exhausted) break;
+			continue;
+		}
+
+		// ---- one step of the state machine ----
+		if (work >= 0) {
+			bool needPop = false, finished = false, occluded = false;
+			const uint lk = link;
+			if (lk == RT_LINK_POP) {
+				needPop = true;
+			} else if (lk & RT_LEAF_BIT) {
+				// one primitive of a leaf (bvh.cpp:616-629 / :770-783)
+				const uint slot = lk & ~RT_LEAF_BIT;
+				const float4 r0 = S.prims[4 * (size_t)slot + 0];
+				const float4 r3 = S.prims[4 * (size_t)slot + 3];
+				const int kl = __float_as_int(r3.w);
+				const int kind = kl & 3;
+				if (COUNT) lc.prim++;
+				float t;
+				bool h;
+				if (kind == RT_KIND_TRI) {
+					const float4 r1 = S.prims[4 * (size_t)slot + 1];
+					const float4 r2 = S.prims[4 * (size_t)slot + 2];
+					h = tri_hit(O, D, rayT, bvh_t_min, xyz(r0), xyz(r1), xyz(r2), f3(r0.w, r1.w, r2.w), r3.x, t);
+				} else if (kind == RT_KIND_SPHERE) {
+					if (ANY) h = sphere_occludes(O, D, rayT, bvh_t_min, xyz(r0), r0.w);
+					else h = sphere_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
+				} else {
+					h = plane_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
+				}
+				if (h) {
+					if (ANY) finished = true, occluded = true;
+					else rayT = t, hit.prim = slot, hit.inst = inst, hit.kind = 0;
+				}
+				if (kl & RT_LAST_BIT) needPop = true;
+				else link = lk + 1;
+			} else if (lk & RT_TLAS_BIT) {
+				// tlas::Intersect / IsOccluded (tlas.cpp:65-122)
+				const uint node = lk & ~RT_TLAS_BIT;
+				const float4 n0 = S.tlas[2 * node], n1 = S.tlas[2 * node + 1];
+				const uint leftRight = __float_as_uint(n0.w);
+				if (leftRight == 0) {
+					// bvhInstance::BIntersect / IsOccluded (bvhInstance.cpp:3-35): ray to object space with
+					// invTransform (direction not renormalised: t is shared by both spaces); the BLAS is walked
+					// above a sentinel on the same stack
+					inst = (int)__float_as_uint(n1.w);
+					if (COUNT) lc.inst++;
+					const DInstance* I = S.inst + inst;
+					const f3 Oo = xform_pos(I->invT, O);
+					const f3 Do = xform_vec(I->invT, D);
+					O = Oo, D = Do, rD = rcp3(Do);
+					st.push(RT_SENTINEL);
+					link = I->rootLink;
+					if (link == RT_EMPTY) link = RT_LINK_POP;
+				} else {
+					if (COUNT) lc.tlasInner++;
+					uint c1 = leftRight & 0xFFFFu, c2 = leftRight >> 16;
+					const float4 a0 = S.tlas[2 * c1], a1 = S.tlas[2 * c1 + 1];
+					const float4 b0 = S.tlas[2 * c2], b1 = S.tlas[2 * c2 + 1];
+					float dist1 = intersect_aabb(O, rD, rayT, xyz(a0), xyz(a1));
+					float dist2 = intersect_aabb(O, rD, rayT, xyz(b0), xyz(b1));
+					if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
+					if (dist1 == 1e30f) needPop = true;
+					else {
+						link = RT_TLAS_BIT | c1;
+						if (dist2 != 1e30f) st.push(RT_TLAS_BIT | c2);
+					}
+				}
+			} else {
+				// one sibling pair of the BLAS (bvh.cpp:638-654 / :788-804)
+				if (COUNT) lc.inner++;
+				const float4* p = S.pairs + 4 * (size_t)lk;
+				const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+				float dist1 = intersect_aabb(O, rD, rayT, xyz(a0), xyz(a1));
+				float dist2 = intersect_aabb(O, rD, rayT, xyz(b0), xyz(b1));
+				uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
+				if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
+				if (dist1 == 1e30f) needPop = true;
+				else {
+					link = c1;
+					if (dist2 != 1e30f) st.push(c2);
+				}
+			}
+			if (needPop && !finished) {
+				if (st.sp == 0) finished = true;
+				else {
+					const uint v = st.pop();
+					if (v == RT_SENTINEL) {
+						// back to world space (the backup ray of bvhInstance.cpp:6, :20), then keep popping
+						float tmaxUnused;
+						pol.load(work, O, D, tmaxUnused);
+						rD = rcp3(D);
+						inst = -1;
+						link = RT_LINK_POP;
+					} else link = v;
+				}
+			}
+			if (finished) {
+				if constexpr (ANY) pol.store(work, occluded);
+				else { hit.t = rayT; pol.store(work, hit, O, D); }
+				work = -1;
+			}
+		}
+	}
 }
 
 // Fill the fields FindNearest leaves in the Ray: objIdx, material, hitNormal (for the sphere the
