@@ -397,10 +397,7 @@ static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 	}
 	Queues Q;
 	memset(&Q, 0, sizeof(Q));
-	HIPCHK(c, dalloc(c->stateAllocs, &Q.active[0], n));
-	HIPCHK(c, dalloc(c->stateAllocs, &Q.active[1], n));
-	HIPCHK(c, dalloc(c->stateAllocs, &Q.shadow, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &Q.done, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.status, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.counts, 16));
 	HIPCHK(c, hipMemset(Q.counts, 0, 16 * sizeof(int)));
 	P.nSlots = nSlots;
@@ -433,7 +430,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 	prof_end(c);
 	int parity = 0;
 	for (int round = 0; round < maxRounds; round++) {
-		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, c->stream, Q, parity);
+		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, c->stream, Q);
 		prof_begin(c, K_EXTEND);
 		if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
 		else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
@@ -456,7 +453,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			if (c->hostCounts[3] == 1) return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 			if (c->hostCounts[3] == 2) return fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
-			if (c->hostCounts[parity] == 0) break;
+			if (c->hostCounts[0] == 0) break;
 			if (round + 1 == maxRounds) return fail(c, RT_E_STATE, "paths still active after %d rounds", maxRounds);
 		}
 	}

@@ -2,21 +2,23 @@
 //
 // Work unit: one *sample* = (pixel, frame).  The samples of a render call form a pool ordered
 // frame-major; a fixed set of *slots* (SoA path state in HBM, 16-byte elements so every lane moves
-// whole dwordx4s) pulls samples from the pool, so queues stay full until the pool is empty no matter
-// how path lengths vary over the image.  Each round runs over compacted queues of slot ids:
-//   extend   Scene::FindNearest for every active slot                       (the dominant kernel)
+// whole dwordx4s) pulls samples from the pool, so every round has work for (nearly) every slot until
+// the pool is empty, however path lengths vary over the image.  A status byte per slot says what the
+// slot needs in the current round; there are no compacted queues (appending to one costs a same-
+// address atomic per wave, which measured as THE cost of the shading kernels), so the shading kernels
+// are plain one-thread-per-slot passes with coalesced loads and stores:
+//   extend   Scene::FindNearest for every ACTIVE slot   (persistent waves, the dominant kernel)
 //   shade    the body of Renderer::Trace / Renderer::Sample at the hit: leaf terms, material switch,
 //            light sampling, the next ray
-//   connect  Scene::IsOccluded towards every sampled light (traversal only, one bit per light)
+//   connect  Scene::IsOccluded towards every sampled light (traversal only, one byte per light)
 //   light    the direct-light terms of a diffuse hit, in light order (their energy bookkeeping
 //            feeds the next bounce)
 //   finish   slots whose segment ended: resume a pending Whitted branch, or store the finished
 //            sample and pull the next one from the pool (new primary ray)
-// Queue appends use a wave-wide ballot + prefix count and one atomic per wave.  Finished samples go
-// to a [frame][pixel] buffer; accumulate adds them to the accumulator in frame order, so the sum is
-// the one a sequential Tick loop produces (renderer.cpp:279-282) and nothing depends on queue order.
-// Radiance is carried forward as path weights (W) instead of being combined on return from
-// recursion; per sample the segment order is the reference's depth-first order.
+// Finished samples go to a [frame][pixel] buffer; accumulate adds them to the accumulator in frame
+// order, so the sum is the one a sequential Tick loop produces (renderer.cpp:279-282).  Radiance is
+// carried forward as path weights (W) instead of being combined on return from recursion; per sample
+// the segment order is the reference's depth-first order.
 #pragma once
 #include "rt_scene_dev.h"
 
@@ -40,6 +42,7 @@ struct PathState {
 	float4* L;       // radiance of the current sample xyz, w = sample id in the pool (uint bits)
 	float4* sh;      // [light][slot] sampled light position xyz (plane 0: w = flags); plane nLights: weight of the segment
 	unsigned char* vis; // [light][slot] 1: the light is occluded
+	unsigned char* status; // [slot] ST_* bits: what the slot needs this round
 	float4* pend;    // [slot][RT_PEND_CAP][4]: pending Whitted branches {O,depth} {D,-} {W,-} {E,-}
 	int* pendCount;  // [slot]
 	int nSlots;
@@ -59,12 +62,13 @@ struct RenderParams {
 	const float* customO; const float* customD; float4* customOut; int customDepth;
 };
 
+#define ST_ACTIVE 1      // has a ray for extend + shade
+#define ST_SHADOW 2      // diffuse hit: connect + light
+#define ST_ENDS_AFTER 4  // ... and the segment ends once light has run
+#define ST_ENDED 8       // segment ended: finish resumes a pending branch or starts a new sample
+
 struct Queues {
-	uint* active[2];
-	uint* shadow;
-	uint* done;  // slots whose segment ended this round
-	int* counts; // [0],[1] active sizes by parity, [2] shadow size, [3] overflow flag, [4] extend head, [5] shade head,
-	             // [6] connect head, [7] next sample in the pool, [8] done size, [9] light head, [10] finish head
+	int* counts; // [0] any slot still active (flag), [3] overflow flag, [4] extend head, [6] connect head, [7] next sample in the pool
 };
 
 // ---- camera (camera.h:24-41) ---------------------------------------------------------------
@@ -172,45 +176,24 @@ __device__ __forceinline__ f3 diffuse_scatter(const DMaterial& m, const f3& rayD
 	return att;
 }
 
-// wave-aggregated queue append: one atomic per wave (ballot + prefix popcount).  Must be reached by
-// every lane of the wave (it shuffles).
-__device__ __forceinline__ int queue_reserve(int* count, bool want)
+// Reserve 'want' consecutive pool entries for the lanes that ask: ballot + prefix count inside the
+// wave, one LDS add per wave, ONE global atomic per block.  Every thread of the block must call it.
+__device__ __forceinline__ int block_reserve(int* counter, bool want, int* ldsScratch /* [RT_BLOCK/64 + 1] */)
 {
+	const uint lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const unsigned long long mask = __ballot(want);
-	if (mask == 0) return -1;
-	const uint lane = threadIdx.x & 63;
-	const int leader = __ffsll((long long)mask) - 1;
-	int base = 0;
-	if ((int)lane == leader) base = atomicAdd(count, __popcll(mask));
-	base = __shfl(base, leader);
-	return base + __popcll(mask & ((1ull << lane) - 1));
-}
-__device__ __forceinline__ void queue_append(uint* q, int* count, bool want, uint value)
-{
-	const int pos = queue_reserve(count, want);
-	if (want) q[pos] = value;
-}
-
-// Dynamic work distribution: a wave takes RT_FETCH * 64 consecutive queue entries per atomic on the
-// kernel's work head and calls body(idx, live) for each of them with the whole wave converged
-// (live == false pads the last batch, so bodies may use wave-wide operations).
-#define RT_FETCH 4
-template <typename F>
-__device__ __forceinline__ void for_each_work(int* head, int n, F body)
-{
-	const uint lane = threadIdx.x & 63;
-	while (true) {
-		int base = 0;
-		if (lane == 0) base = atomicAdd(head, 64 * RT_FETCH);
-		base = __shfl(base, 0);
-		if (base >= n) break;
-		for (int k = 0; k < RT_FETCH; k++) {
-			const int first = base + 64 * k;
-			if (first >= n) break;
-			const int idx = first + (int)lane;
-			body(idx, idx < n);
-		}
+	const int inWave = __popcll(mask & ((1ull << lane) - 1));
+	if (lane == 0) ldsScratch[wave] = __popcll(mask);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int total = 0;
+		for (int w = 0; w < RT_BLOCK / 64; w++) { const int c = ldsScratch[w]; ldsScratch[w] = total; total += c; }
+		ldsScratch[RT_BLOCK / 64] = total > 0 ? atomicAdd(counter, total) : 0;
 	}
+	__syncthreads();
+	const int pos = ldsScratch[RT_BLOCK / 64] + ldsScratch[wave] + inWave;
+	__syncthreads();
+	return pos;
 }
 
 __device__ __forceinline__ void flush_counters(DCounters* g, const LaneCounters& lc, uint nearest, uint occluded)
@@ -275,16 +258,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DCamera C, RenderParams R
 	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= P.nSlots) return;
 	start_sample(C, R, P, slot, (uint)slot, 0); // slots take the first nSlots samples of the pool
-	Q.active[0][slot] = (uint)slot;
-	if (slot == 0) { Q.counts[0] = P.nSlots; Q.counts[1] = 0; Q.counts[2] = 0; Q.counts[7] = P.nSlots; Q.counts[8] = 0; }
+	P.status[slot] = ST_ACTIVE;
+	if (slot == 0) { Q.counts[0] = 1; Q.counts[7] = P.nSlots; }
 }
 
-// round bookkeeping between kernels: reset heads and the queues about to be refilled
-__global__ void k_round_begin(Queues Q, int parityIn)
+// round bookkeeping between kernels: reset the work heads and the "anything left" flag
+__global__ void k_round_begin(Queues Q)
 {
-	Q.counts[1 - parityIn] = 0;
-	Q.counts[2] = 0, Q.counts[8] = 0;
-	Q.counts[4] = 0, Q.counts[5] = 0, Q.counts[6] = 0, Q.counts[9] = 0, Q.counts[10] = 0;
+	Q.counts[0] = 0;
+	Q.counts[4] = 0, Q.counts[6] = 0;
 }
 
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
@@ -292,18 +274,17 @@ __global__ void k_round_begin(Queues Q, int parityIn)
 struct ExtendPolicy {
 	const DScene& S;
 	PathState& P;
-	const uint* queue;
 	int parity;
-	__device__ __forceinline__ void load(int work, f3& O, f3& D, float& tmax) const
+	__device__ __forceinline__ bool load(int slot, f3& O, f3& D, float& tmax) const
 	{
-		const int slot = (int)queue[work];
+		if (!(P.status[slot] & ST_ACTIVE)) return false;
 		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
 		O = xyz(o4), D = xyz(d4), tmax = o4.w;
+		return true;
 	}
-	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
+	__device__ __forceinline__ void store(int slot, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
 	{
 		// the ray in registers may be the object-space one; the sphere normal needs the world ray
-		const int slot = (int)queue[work];
 		const f3 O = xyz(P.O[parity][slot]), D = xyz(P.D[parity][slot]);
 		int objIdx, mat;
 		f3 normal;
@@ -319,8 +300,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queu
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	ExtendPolicy pol{ S, P, Q.active[parity], parity };
-	trace_persistent<false, COUNT>(S, pol, Q.counts[parity], &Q.counts[4], t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	ExtendPolicy pol{ S, P, parity };
+	trace_persistent<false, COUNT>(S, pol, P.nSlots, &Q.counts[4], t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
@@ -329,13 +310,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queu
 // connect + light (shadow queue), or end the segment (done queue).
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity)
 {
-	const int n = Q.counts[parity];
 	const int pout = 1 - parity;
-	for_each_work(&Q.counts[5], n, [&](int idx, bool live) {
+	for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < P.nSlots; slot += gridDim.x * blockDim.x) {
+		if (!(P.status[slot] & ST_ACTIVE)) continue;
 		bool keep = false, wantShadow = false, ended = false;
-		int slot = 0;
-		if (live) {
-			slot = (int)Q.active[parity][idx];
+		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
 			const int2 id = P.hitId[slot];
 			const float4 w4 = P.W[slot], e4 = P.E[slot], l4 = P.L[slot];
@@ -438,10 +417,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, Pa
 				ended = true;
 			}
 		}
-		queue_append(Q.active[pout], &Q.counts[pout], keep, (uint)slot);
-		queue_append(Q.shadow, &Q.counts[2], wantShadow, (uint)slot);
-		queue_append(Q.done, &Q.counts[8], ended, (uint)slot);
-	});
+		P.status[slot] = (keep ? ST_ACTIVE : 0) | (wantShadow ? ST_SHADOW : 0) | (wantShadow && !keep ? ST_ENDS_AFTER : 0) | (ended ? ST_ENDED : 0);
+	}
 }
 
 // connect: Scene::IsOccluded from the hit point towards each sampled light position
@@ -449,11 +426,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, Pa
 // vis[light][slot] = 1 when that light is occluded.
 struct ConnectPolicy {
 	PathState& P;
-	const uint* queue;
 	int parity, nLights;
-	__device__ __forceinline__ void load(int work, f3& O, f3& D, float& tmax) const
+	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax) const
 	{
-		const int slot = (int)queue[work / nLights], li = work % nLights;
+		const int slot = work / nLights, li = work % nLights;
+		if (!(P.status[slot] & ST_SHADOW)) return false;
 		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
 		const f3 I = xyz(o4) + hn.w * xyz(d4);
 		const f3 pickedPos = xyz(P.sh[(size_t)li * P.nSlots + slot]);
@@ -461,10 +438,11 @@ struct ConnectPolicy {
 		const float len2 = dot(lightRayDirection, lightRayDirection);
 		lightRayDirection = normalize(lightRayDirection);
 		O = I + lightRayDirection * 1e-4f, D = lightRayDirection, tmax = sqrtf(len2);
+		return true;
 	}
 	__device__ __forceinline__ void store(int work, bool occluded) const
 	{
-		const int slot = (int)queue[work / nLights], li = work % nLights;
+		const int slot = work / nLights, li = work % nLights;
 		P.vis[(size_t)li * P.nSlots + slot] = occluded ? 1 : 0;
 	}
 };
@@ -475,8 +453,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Que
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights };
-	trace_persistent<true, COUNT>(S, pol, Q.counts[2] * S.nLights, &Q.counts[6], 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	ConnectPolicy pol{ P, parity, S.nLights };
+	trace_persistent<true, COUNT>(S, pol, P.nSlots * S.nLights, &Q.counts[6], 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -485,12 +463,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Que
 // occlusion test.  Path (renderer.cpp:158-176): occlusion test first, scatter only when visible.
 __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, PathState P, Queues Q, int parity)
 {
-	const int n = Q.counts[2];
-	for_each_work(&Q.counts[9], n, [&](int idx, bool live) {
-		bool ended = false;
-		int slot = 0;
-		if (live) {
-			slot = (int)Q.shadow[idx];
+	for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < P.nSlots; slot += gridDim.x * blockDim.x) {
+		const unsigned char stBits = P.status[slot];
+		if (!(stBits & ST_SHADOW)) continue;
+		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
 			const int2 id = P.hitId[slot];
 			const float4 e4 = P.E[slot], l4 = P.L[slot];
@@ -524,10 +500,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 			}
 			P.E[slot] = mk4(E, e4.w);
 			P.L[slot] = mk4(Lsum, l4.w);
-			ended = w4.w != 0.0f;
+			P.status[slot] = (stBits & ST_ACTIVE) | ((stBits & ST_ENDS_AFTER) ? ST_ENDED : 0);
 		}
-		queue_append(Q.done, &Q.counts[8], ended, (uint)slot);
-	});
+	}
 }
 
 // finish: a slot's segment ended without a continuation ray.  Resume the most recent pending
@@ -535,13 +510,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 // :279-282, gamma per sample) and pull the next sample from the pool.
 __global__ void __launch_bounds__(RT_BLOCK) k_finish(DCamera C, RenderParams R, PathState P, Queues Q, int parity)
 {
-	const int n = Q.counts[8];
+	__shared__ int scratch[RT_BLOCK / 64 + 1];
 	const int pout = 1 - parity;
-	for_each_work(&Q.counts[10], n, [&](int idx, bool live) {
-		bool keep = false, wantSample = false;
-		int slot = 0;
-		if (live) {
-			slot = (int)Q.done[idx];
+	const int stride = gridDim.x * blockDim.x;
+	// every thread of a block runs the same number of iterations (block_reserve synchronises)
+	for (int base = blockIdx.x * blockDim.x; base < P.nSlots; base += stride) {
+		const int slot = base + threadIdx.x;
+		const bool inRange = slot < P.nSlots;
+		unsigned char stBits = inRange ? P.status[slot] : 0;
+		bool wantSample = false;
+		if (stBits & ST_ENDED) {
+			stBits &= ~ST_ENDED;
 			int np = P.pendCount ? P.pendCount[slot] : 0;
 			if (np > 0) {
 				np--;
@@ -552,28 +531,27 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DCamera C, RenderParams R, 
 				P.W[slot] = make_float4(w.x, w.y, w.z, o.w);
 				P.E[slot] = make_float4(en.x, en.y, en.z, P.E[slot].w);
 				P.pendCount[slot] = np;
-				keep = true;
+				stBits |= ST_ACTIVE;
 			} else {
 				const float4 l4 = P.L[slot];
 				const uint sid = __float_as_uint(l4.w);
-				float4 v;
-				if (R.customOut) { R.customOut[sid] = make_float4(l4.x, l4.y, l4.z, 0.0f); }
-				else {
-					if (R.mode == 0) v = make_float4(l4.x / (float)1, l4.y / (float)1, l4.z / (float)1, 0.0f);
-					else v = make_float4(x_powf(l4.x * 1, RT_GAMMA), x_powf(l4.y * 1, RT_GAMMA), x_powf(l4.z * 1, RT_GAMMA), 0.0f);
-					R.samples[sid] = v;
-				}
+				if (R.customOut) R.customOut[sid] = make_float4(l4.x, l4.y, l4.z, 0.0f);
+				else if (R.mode == 0) R.samples[sid] = make_float4(l4.x / (float)1, l4.y / (float)1, l4.z / (float)1, 0.0f);
+				else R.samples[sid] = make_float4(x_powf(l4.x * 1, RT_GAMMA), x_powf(l4.y * 1, RT_GAMMA), x_powf(l4.z * 1, RT_GAMMA), 0.0f);
 				wantSample = true;
 			}
 		}
-		// next sample of the pool for every slot that just completed one (one atomic per wave)
-		const int sidNext = queue_reserve(&Q.counts[7], wantSample);
+		// next sample of the pool for every slot that just completed one (one atomic per block)
+		const int sidNext = block_reserve(&Q.counts[7], wantSample, scratch);
 		if (wantSample && (uint)sidNext < R.nSamples) {
 			start_sample(C, R, P, slot, (uint)sidNext, pout);
-			keep = true;
+			stBits |= ST_ACTIVE;
 		}
-		queue_append(Q.active[pout], &Q.counts[pout], keep, (uint)slot);
-	});
+		if (inRange) {
+			P.status[slot] = stBits;
+			if (stBits & ST_ACTIVE) Q.counts[0] = 1; // benign same-value race: "something is still running"
+		}
+	}
 }
 
 // accumulate: add the finished samples of a batch to the accumulator in frame order
@@ -598,10 +576,11 @@ struct QueryHit { float t; int objIdx; int mat; float nx, ny, nz; };
 
 struct ArrayRays {
 	const float* O3; const float* D3; const float* tmax;
-	__device__ __forceinline__ void load(int i, f3& O, f3& D, float& tm) const
+	__device__ __forceinline__ bool load(int i, f3& O, f3& D, float& tm) const
 	{
 		O = f3(O3[3 * i], O3[3 * i + 1], O3[3 * i + 2]), D = f3(D3[3 * i], D3[3 * i + 1], D3[3 * i + 2]);
 		tm = tmax ? tmax[i] : 1e34f;
+		return true;
 	}
 };
 struct NearestQueryPolicy : ArrayRays {
@@ -628,7 +607,7 @@ struct OccludedQueryPolicy : ArrayRays {
 // Camera::GetPrimaryRay + Scene::FindNearest for every pixel
 struct PrimaryPolicy {
 	const DScene& S; const DCamera& C; int* objOut; float* tOut;
-	__device__ __forceinline__ void load(int i, f3& O, f3& D, float& tm) const { primary_ray(C, i % C.width, i / C.width, O, D); tm = 1e34f; }
+	__device__ __forceinline__ bool load(int i, f3& O, f3& D, float& tm) const { primary_ray(C, i % C.width, i / C.width, O, D); tm = 1e34f; return true; }
 	__device__ __forceinline__ void store(int i, const HitRef& hit, const f3&, const f3&) const
 	{
 		f3 O, D;

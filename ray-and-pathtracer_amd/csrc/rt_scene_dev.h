@@ -149,7 +149,7 @@ __device__ __forceinline__ void light_intersect(const DLight& L, int li, const f
 // pushed, leaf primitives in primitiveIdx order, t_min 0.0001 inside the BVH.
 //
 // A *policy* supplies the rays and takes the results:
-//   bool load(int work, f3& O, f3& D, float& tmax)   world-space ray of work item 'work'
+//   bool load(int work, f3& O, f3& D, float& tmax)   world-space ray of work item 'work'; false = nothing to trace
 //   void store(int work, const HitRef&, O, D)         nearest-hit result      (ANY == false)
 //   void store(int work, bool occluded)               occlusion result        (ANY == true)
 #define RT_TLAS_BIT 0x40000000u
@@ -191,10 +191,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				if (!exhausted) {
 					const int mine = chunkNext + __popcll(idleMask & below);
 					const int avail = chunkEnd - chunkNext;
-					if (idle && mine < chunkEnd) {
+					float tmax = 0;
+					// a work item may turn out to be nothing to trace (slot not in this state): the lane stays idle
+					if (idle && mine < chunkEnd && pol.load(mine, O, D, tmax)) {
 						work = mine;
-						float tmax;
-						pol.load(work, O, D, tmax);
 						rayT = tmax;
 						st.sp = 0, inst = -1;
 						hit.kind = -1, hit.inst = -1, hit.prim = 0;
