@@ -105,8 +105,8 @@ __device__ __forceinline__ f3 xform_vec(const float* c, const f3& a)
 	          c[8] * a.x + c[9] * a.y + c[10] * a.z + c[11] * 0.0f);
 }
 
-// bvh::IntersectAABB (bvh.cpp:819-828)
-__device__ __forceinline__ float intersect_aabb(const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
+// bvh::IntersectAABB (bvh.cpp:819-828), literal form: std::min / std::max ternaries
+__device__ __forceinline__ float intersect_aabb_exact(const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
 {
 	float tx1 = (bmin.x - O.x) * rD.x, tx2 = (bmax.x - O.x) * rD.x;
 	float tmin = std_min(tx1, tx2), tmax = std_max(tx1, tx2);
@@ -114,6 +114,24 @@ __device__ __forceinline__ float intersect_aabb(const f3& O, const f3& rD, float
 	tmin = std_max(tmin, std_min(ty1, ty2)), tmax = std_min(tmax, std_max(ty1, ty2));
 	float tz1 = (bmin.z - O.z) * rD.z, tz2 = (bmax.z - O.z) * rD.z;
 	tmin = std_max(tmin, std_min(tz1, tz2)), tmax = std_min(tmax, std_max(tz1, tz2));
+	if (tmax >= tmin && tmin < rayT && tmax > 0) return tmin;
+	return 1e30f;
+}
+// Same function on the hardware min/max.  v_min_f32 / v_max_f32 select one of their operands and
+// differ from the ternaries only when an operand is NaN (and in the sign of a zero result, which no
+// comparison below can see), so: if none of the six slab products is NaN the selection network
+// returns the same tmin / tmax; otherwise the literal form runs.  NaN products need 0 * inf
+// (a ray running exactly along a box face) and are rare.  The sum of the six is NaN whenever one of
+// them is (it may also be NaN for inf - inf: that only sends a clean case to the literal form).
+__device__ __forceinline__ float intersect_aabb(const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
+{
+	const float tx1 = (bmin.x - O.x) * rD.x, tx2 = (bmax.x - O.x) * rD.x;
+	const float ty1 = (bmin.y - O.y) * rD.y, ty2 = (bmax.y - O.y) * rD.y;
+	const float tz1 = (bmin.z - O.z) * rD.z, tz2 = (bmax.z - O.z) * rD.z;
+	const float probe = ((tx1 + tx2) + (ty1 + ty2)) + (tz1 + tz2);
+	if (probe != probe) return intersect_aabb_exact(O, rD, rayT, bmin, bmax);
+	const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
+	const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
 	if (tmax >= tmin && tmin < rayT && tmax > 0) return tmin;
 	return 1e30f;
 }

@@ -157,10 +157,11 @@ __device__ __forceinline__ void light_intersect(const DLight& L, int li, const f
 #define RT_CHUNK 256 // queue entries a wave reserves per atomic on the work head
 
 template <bool ANY, bool COUNT, class Policy>
-__device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* head, float t_min, int refillMin,
+__device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* head, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
+	const int refillMin = tuning & 0xFF, stepMin = (tuning >> 8) & 0xFF;
 	const uint lane = threadIdx.x & 63;
 	const unsigned long long below = (1ull << lane) - 1;
 	Stack st = make_stack(ldsStack, spill, overflow);
@@ -231,9 +232,20 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		}
 
 		// ---- one step of the state machine ----
-		if (work >= 0) {
+		// The two common step kinds (primitive test, sibling-pair test) are different code; a kind that
+		// only a few lanes want this iteration is postponed until at least stepMin lanes want it (or it
+		// is the majority), so its instructions run with more lanes enabled.
+		const uint lk = link;
+		const bool wantLeaf = work >= 0 && lk != RT_LINK_POP && (lk & RT_LEAF_BIT);
+		const bool wantPair = work >= 0 && !(lk & (RT_LEAF_BIT | RT_TLAS_BIT));
+		bool runLeaf = true, runPair = true;
+		if (stepMin > 0) {
+			const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(wantPair));
+			runLeaf = nL >= stepMin || nL >= nP;
+			runPair = nP >= stepMin || nP > nL;
+		}
+		if (work >= 0 && !(wantLeaf && !runLeaf) && !(wantPair && !runPair)) {
 			bool needPop = false, finished = false, occluded = false;
-			const uint lk = link;
 			if (lk == RT_LINK_POP) {
 				needPop = true;
 			} else if (lk & RT_LEAF_BIT) {
