@@ -399,6 +399,8 @@ static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 	Queues Q;
 	memset(&Q, 0, sizeof(Q));
 	HIPCHK(c, dalloc(c->stateAllocs, &P.status, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &Q.active, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &Q.shadow, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.counts, 16));
 	HIPCHK(c, hipMemset(Q.counts, 0, 16 * sizeof(int)));
 	P.nSlots = nSlots;
@@ -432,6 +434,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 	int parity = 0;
 	for (int round = 0; round < maxRounds; round++) {
 		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, c->stream, Q);
+		hipLaunchKernelGGL(k_compact, dim3(grid), dim3(RT_BLOCK), 0, c->stream, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
 		prof_begin(c, K_EXTEND);
 		if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
 		else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
@@ -439,6 +442,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 		prof_begin(c, K_SHADE);
 		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
 		prof_end(c);
+		hipLaunchKernelGGL(k_compact, dim3(grid), dim3(RT_BLOCK), 0, c->stream, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
 		prof_begin(c, K_CONNECT);
 		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->refillMin, c->spill, c->counters + 1);
 		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->refillMin, c->spill, c->counters + 1);

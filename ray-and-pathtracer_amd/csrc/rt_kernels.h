@@ -68,7 +68,9 @@ struct RenderParams {
 #define ST_ENDED 8       // segment ended: finish resumes a pending branch or starts a new sample
 
 struct Queues {
-	int* counts; // [0] any slot still active (flag), [3] overflow flag, [4] extend head, [6] connect head, [7] next sample in the pool
+	uint* active; // compacted ACTIVE slots (built per round by k_compact)
+	uint* shadow; // compacted SHADOW slots
+	int* counts;  // [0] active count, [2] shadow count, [3] overflow flag, [4] extend head, [6] connect head, [7] next sample in the pool
 };
 
 // ---- camera (camera.h:24-41) ---------------------------------------------------------------
@@ -176,24 +178,45 @@ __device__ __forceinline__ f3 diffuse_scatter(const DMaterial& m, const f3& rayD
 	return att;
 }
 
-// Reserve 'want' consecutive pool entries for the lanes that ask: ballot + prefix count inside the
-// wave, one LDS add per wave, ONE global atomic per block.  Every thread of the block must call it.
-__device__ __forceinline__ int block_reserve(int* counter, bool want, int* ldsScratch /* [RT_BLOCK/64 + 1] */)
+// Per-wave ranges: wave w of the grid owns the contiguous slots [w*R, (w+1)*R), R a multiple of 64.
+// A pass that must hand out consecutive ids (queue positions, pool samples) to the slots that ask
+// runs over its range twice: count the askers, reserve them with ONE atomic per wave per launch,
+// then assign base + running prefix.  (One atomic per 64 slots on a single counter measured as the
+// whole cost of such passes: ~88 same-address atomics per microsecond.)
+__device__ __forceinline__ void wave_range(int nSlots, int& first, int& last)
 {
-	const uint lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const unsigned long long mask = __ballot(want);
-	const int inWave = __popcll(mask & ((1ull << lane) - 1));
-	if (lane == 0) ldsScratch[wave] = __popcll(mask);
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		int total = 0;
-		for (int w = 0; w < RT_BLOCK / 64; w++) { const int c = ldsScratch[w]; ldsScratch[w] = total; total += c; }
-		ldsScratch[RT_BLOCK / 64] = total > 0 ? atomicAdd(counter, total) : 0;
+	const int waves = (gridDim.x * blockDim.x) >> 6;
+	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	int per = (nSlots + waves - 1) / waves;
+	per = (per + 63) & ~63;
+	first = wave * per;
+	last = first + per < nSlots ? first + per : nSlots;
+	if (first > nSlots) first = nSlots;
+}
+
+// compact: queue <- slots of this wave's range whose status has any bit of 'mask', in slot order
+__global__ void __launch_bounds__(RT_BLOCK) k_compact(PathState P, int mask, uint* queue, int* count)
+{
+	const uint lane = threadIdx.x & 63;
+	int first, last;
+	wave_range(P.nSlots, first, last);
+	int total = 0;
+	for (int s0 = first; s0 < last; s0 += 64) {
+		const int slot = s0 + (int)lane;
+		const bool want = slot < last && (P.status[slot] & mask);
+		total += __popcll(__ballot(want));
 	}
-	__syncthreads();
-	const int pos = ldsScratch[RT_BLOCK / 64] + ldsScratch[wave] + inWave;
-	__syncthreads();
-	return pos;
+	if (total == 0) return;
+	int base = 0;
+	if (lane == 0) base = atomicAdd(count, total);
+	base = __shfl(base, 0);
+	for (int s0 = first; s0 < last; s0 += 64) {
+		const int slot = s0 + (int)lane;
+		const bool want = slot < last && (P.status[slot] & mask);
+		const unsigned long long m = __ballot(want);
+		if (want) queue[base + __popcll(m & ((1ull << lane) - 1))] = (uint)slot;
+		base += __popcll(m);
+	}
 }
 
 __device__ __forceinline__ void flush_counters(DCounters* g, const LaneCounters& lc, uint nearest, uint occluded)
@@ -259,13 +282,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DCamera C, RenderParams R
 	if (slot >= P.nSlots) return;
 	start_sample(C, R, P, slot, (uint)slot, 0); // slots take the first nSlots samples of the pool
 	P.status[slot] = ST_ACTIVE;
-	if (slot == 0) { Q.counts[0] = 1; Q.counts[7] = P.nSlots; }
+	if (slot == 0) Q.counts[7] = P.nSlots;
 }
 
-// round bookkeeping between kernels: reset the work heads and the "anything left" flag
+// round bookkeeping between kernels: reset the work heads and the queue counts
 __global__ void k_round_begin(Queues Q)
 {
-	Q.counts[0] = 0;
+	Q.counts[0] = 0, Q.counts[2] = 0;
 	Q.counts[4] = 0, Q.counts[6] = 0;
 }
 
@@ -274,17 +297,19 @@ __global__ void k_round_begin(Queues Q)
 struct ExtendPolicy {
 	const DScene& S;
 	PathState& P;
+	const uint* queue;
 	int parity;
-	__device__ __forceinline__ bool load(int slot, f3& O, f3& D, float& tmax) const
+	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax) const
 	{
-		if (!(P.status[slot] & ST_ACTIVE)) return false;
+		const int slot = (int)queue[work];
 		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
 		O = xyz(o4), D = xyz(d4), tmax = o4.w;
 		return true;
 	}
-	__device__ __forceinline__ void store(int slot, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
+	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
 	{
 		// the ray in registers may be the object-space one; the sphere normal needs the world ray
+		const int slot = (int)queue[work];
 		const f3 O = xyz(P.O[parity][slot]), D = xyz(P.D[parity][slot]);
 		int objIdx, mat;
 		f3 normal;
@@ -300,8 +325,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queu
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	ExtendPolicy pol{ S, P, parity };
-	trace_persistent<false, COUNT>(S, pol, P.nSlots, &Q.counts[4], t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	ExtendPolicy pol{ S, P, Q.active, parity };
+	trace_persistent<false, COUNT>(S, pol, Q.counts[0], &Q.counts[4], t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
@@ -426,11 +451,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, Pa
 // vis[light][slot] = 1 when that light is occluded.
 struct ConnectPolicy {
 	PathState& P;
+	const uint* queue;
 	int parity, nLights;
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax) const
 	{
-		const int slot = work / nLights, li = work % nLights;
-		if (!(P.status[slot] & ST_SHADOW)) return false;
+		const int slot = (int)queue[work / nLights], li = work % nLights;
 		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
 		const f3 I = xyz(o4) + hn.w * xyz(d4);
 		const f3 pickedPos = xyz(P.sh[(size_t)li * P.nSlots + slot]);
@@ -442,7 +467,7 @@ struct ConnectPolicy {
 	}
 	__device__ __forceinline__ void store(int work, bool occluded) const
 	{
-		const int slot = work / nLights, li = work % nLights;
+		const int slot = (int)queue[work / nLights], li = work % nLights;
 		P.vis[(size_t)li * P.nSlots + slot] = occluded ? 1 : 0;
 	}
 };
@@ -453,8 +478,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Que
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	ConnectPolicy pol{ P, parity, S.nLights };
-	trace_persistent<true, COUNT>(S, pol, P.nSlots * S.nLights, &Q.counts[6], 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights };
+	trace_persistent<true, COUNT>(S, pol, Q.counts[2] * S.nLights, &Q.counts[6], 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -510,15 +535,28 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 // :279-282, gamma per sample) and pull the next sample from the pool.
 __global__ void __launch_bounds__(RT_BLOCK) k_finish(DCamera C, RenderParams R, PathState P, Queues Q, int parity)
 {
-	__shared__ int scratch[RT_BLOCK / 64 + 1];
+	const uint lane = threadIdx.x & 63;
 	const int pout = 1 - parity;
-	const int stride = gridDim.x * blockDim.x;
-	// every thread of a block runs the same number of iterations (block_reserve synchronises)
-	for (int base = blockIdx.x * blockDim.x; base < P.nSlots; base += stride) {
-		const int slot = base + threadIdx.x;
-		const bool inRange = slot < P.nSlots;
-		unsigned char stBits = inRange ? P.status[slot] : 0;
-		bool wantSample = false;
+	int first, last;
+	wave_range(P.nSlots, first, last);
+	// pass 1: how many slots of this wave's range complete a sample (ENDED, no pending branch)
+	int total = 0;
+	for (int s0 = first; s0 < last; s0 += 64) {
+		const int slot = s0 + (int)lane;
+		const bool completes = slot < last && (P.status[slot] & ST_ENDED) && !(P.pendCount && P.pendCount[slot] > 0);
+		total += __popcll(__ballot(completes));
+	}
+	// one atomic per wave: the next 'total' samples of the pool
+	int base = 0;
+	if (total > 0) {
+		if (lane == 0) base = atomicAdd(&Q.counts[7], total);
+		base = __shfl(base, 0);
+	}
+	// pass 2
+	for (int s0 = first; s0 < last; s0 += 64) {
+		const int slot = s0 + (int)lane;
+		unsigned char stBits = slot < last ? P.status[slot] : 0;
+		bool completes = false;
 		if (stBits & ST_ENDED) {
 			stBits &= ~ST_ENDED;
 			int np = P.pendCount ? P.pendCount[slot] : 0;
@@ -538,19 +576,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DCamera C, RenderParams R, 
 				if (R.customOut) R.customOut[sid] = make_float4(l4.x, l4.y, l4.z, 0.0f);
 				else if (R.mode == 0) R.samples[sid] = make_float4(l4.x / (float)1, l4.y / (float)1, l4.z / (float)1, 0.0f);
 				else R.samples[sid] = make_float4(x_powf(l4.x * 1, RT_GAMMA), x_powf(l4.y * 1, RT_GAMMA), x_powf(l4.z * 1, RT_GAMMA), 0.0f);
-				wantSample = true;
+				completes = true;
 			}
 		}
-		// next sample of the pool for every slot that just completed one (one atomic per block)
-		const int sidNext = block_reserve(&Q.counts[7], wantSample, scratch);
-		if (wantSample && (uint)sidNext < R.nSamples) {
-			start_sample(C, R, P, slot, (uint)sidNext, pout);
-			stBits |= ST_ACTIVE;
+		const unsigned long long m = __ballot(completes);
+		if (completes) {
+			const uint sidNext = (uint)(base + __popcll(m & ((1ull << lane) - 1)));
+			if (sidNext < R.nSamples) {
+				start_sample(C, R, P, slot, sidNext, pout);
+				stBits |= ST_ACTIVE;
+			}
 		}
-		if (inRange) {
-			P.status[slot] = stBits;
-			if (stBits & ST_ACTIVE) Q.counts[0] = 1; // benign same-value race: "something is still running"
-		}
+		base += __popcll(m);
+		if (slot < last) P.status[slot] = stBits;
 	}
 }
 
