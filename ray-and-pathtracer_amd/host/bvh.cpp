@@ -308,8 +308,7 @@ void bvh::Build(bool isQ)
 	delete[] primitiveIdx;
 	delete[] bvhNode;
 	primitiveIdx = new uint[N ? N : 1];
-	bvhNode = new BVHNode[2 * (N + 1)];
-	memset(bvhNode, 0, sizeof(BVHNode) * 2 * (N + 1));
+	bvhNode = new BVHNode[2 * (N + 1)]();
 	for (uint i = 0; i < N; ++i) primitiveIdx[i] = i;
 	nodesUsed = 2, treeDepth = 0;
 	bvhNode[rootNodeIdx].primCount = N;
@@ -365,8 +364,7 @@ void bvhInstance::SetTransform(mat4& transform)
 // ---- tlas ------------------------------------------------------------------------------------
 tlas::tlas(bvhInstance* bvhList, int Ncount) : blas(bvhList), blasCount((uint)Ncount)
 {
-	tlasNode = new TLASNode[2 * Ncount + 1];
-	memset(tlasNode, 0, sizeof(TLASNode) * (2 * Ncount + 1));
+	tlasNode = new TLASNode[2 * Ncount + 1]();
 	nodesUsed = 2;
 }
 tlas::~tlas() { delete[] tlasNode; }

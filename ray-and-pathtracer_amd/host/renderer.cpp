@@ -19,8 +19,7 @@ void Renderer::Init() // renderer.cpp:5-11: allocate and zero the float4 accumul
 	if (ctx) return;
 	ctx = rt_create(device, width, height);
 	if (!ctx) throw std::runtime_error(std::string("rt_amd: ") + rt_last_error(nullptr));
-	accumulator = new float4[(size_t)width * height];
-	memset(accumulator, 0, sizeof(float4) * (size_t)width * height);
+	accumulator = new float4[(size_t)width * height]();
 	screenPixels = new uint32_t[(size_t)width * height];
 	memset(screenPixels, 0, 4 * (size_t)width * height);
 	frame = 0;

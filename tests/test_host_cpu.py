@@ -1,0 +1,120 @@
+"""CPU tier for the product's host side: the C++ host mirror's loaders and BVH / TLAS builders
+against the oracle (bit-exact node arrays), the C ABI library's exports, and loud failure without a
+GPU.  No device compute happens here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol(host_api):
+    hdr = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|void\*?|rt_ctx\*|const char\*)\s+\*?(rt_[a-z_]+)\s*\(", hdr, re.M))
+    assert declared == set(host_api.RT_SYMBOLS), declared ^ set(host_api.RT_SYMBOLS)
+    L = host_api.rt_lib()
+    for sym in declared:
+        assert hasattr(L, sym), sym
+
+
+def test_no_gpu_fails_loudly(host_api):
+    """On a box without a GPU the product refuses to run (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = host_api.rt_lib()
+    assert L.rt_create(0, 64, 64) is None
+    msg = L.rt_last_error(None).decode()
+    assert "no HIP device" in msg or "gfx950" in msg
+    with pytest.raises(RuntimeError):
+        host_api.HostRenderer(64, 64)
+
+
+def test_product_does_not_load_the_oracle():
+    """The product path (package + bench's GPU leg) must not import, link or load oracle/."""
+    pkg_dir = os.path.join(ROOT, "ray-and-pathtracer_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt and "orc_" not in txt, os.path.join(dirpath, f)
+
+
+SCENES = [("background", {}), ("scene3", {"force_diffuse": False, "split": 0}), ("scene3", {"force_diffuse": False, "split": 1}),
+          ("scene3", {"force_diffuse": False, "split": 2}), ("scene3", {"force_diffuse": False, "split": 3}),
+          ("mixed_small", {"split": 0}), ("mixed_small", {"split": 3}), ("tlas_test2", {}), ("tlas_test2", {"mesh": "BigB"}),
+          ("pretty_tlas", {"n_instances": 8}), ("tower", {}), ("bigb_instanced", {"n": 16})]
+
+
+@pytest.mark.parametrize("name,kw", SCENES)
+def test_builders_match_oracle(name, kw, scenes, oracle_api, host_api):
+    o = oracle_api.OracleScene()
+    h = host_api.HostScene()
+    d = scenes.REGISTRY[name](o, **kw)
+    scenes.REGISTRY[name](h, **kw)
+    blas_ids = range(o.blas_count()) if d["tlas"] else [-1]
+    if d["tlas"]:
+        assert o.blas_count() == h.blas_count()
+    for b in blas_ids:
+        A, B = o.bvh_dump(b), h.bvh_dump(b)
+        assert A["nodes_used"] == B["nodes_used"] and A["N"] == B["N"] and A["max_depth"] == B["max_depth"]
+        assert np.array_equal(A["prim_idx"], B["prim_idx"])
+        assert np.array_equal(np.delete(A["nodes"], 1, axis=0), np.delete(B["nodes"], 1, axis=0))  # node 1 is never written (Q4)
+    if d["tlas"]:
+        assert np.array_equal(o.tlas_dump(), h.tlas_dump())
+        n_inst = kw.get("n_instances", kw.get("n", 3))
+        for i in range(n_inst):
+            a, b = o.instance_dump(i), h.instance_dump(i)
+            assert a["blas"] == b["blas"]
+            for k in ("T", "invT", "bounds"):
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (i, k)
+    assert h.describe()  # flattening to rt_scene_desc works without a device
+    o.close(); h.close()
+
+
+def test_mesh_loaders_match_oracle_and_quirks(tmp_path, oracle_api, host_api):
+    """OBJ ('v' / 'f a//n b//n c//n' only) and .tri loaders: same triangles as the oracle, ids
+    1000*group + i, scale-then-offset, and the .tri end-of-file quirk (last record twice, Q10)."""
+    obj = tmp_path / "m.obj"
+    obj.write_text("# comment\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nv 0.25 0.5 -1.5\nusemtl x\nf 1//1 2//1 3//1\nf 2//1 4//1 3//1\n")
+    tri = tmp_path / "m.tri"
+    tri.write_text("0 0 0 1 0 0 0 1 0\n0 0 1 1 0 1 0 1 1\n999 999 999 999 999 999 999 999 999")
+    o, h = oracle_api.OracleScene(), host_api.HostScene()
+    for s in (o, h):
+        m = s.diffuse(0.8, (1, 1, 1))
+        s.mesh_obj(7, str(obj), m, (0.5, -1.0, 2.0), 2.0)
+        s.mesh_tri(3, str(tri), m)
+    for mesh in (0, 1):
+        (ta, ia), (tb, ib) = o.mesh_tris(mesh), h.mesh_tris(mesh)
+        assert np.array_equal(ia, ib) and np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    t, ids = h.mesh_tris(0)
+    assert ids.tolist() == [7000, 7001]
+    assert np.allclose(t[0, 0:9], [0.5, -1, 2, 2.5, -1, 2, 0.5, 1, 2])
+    assert np.allclose(t[0, 9:12], [0, 0, 1])  # N = normalize(cross(e1, e2))
+    t, ids = h.mesh_tris(1)
+    assert ids.tolist() == [3000, 3001, 3002, 3003]  # 3 records + the duplicated last one
+    assert np.array_equal(t[2].view(np.uint32), t[3].view(np.uint32))
+    assert np.isnan(t[3, 9:12]).all()  # degenerate sentinel triangle: NaN normal
+    with pytest.raises(RuntimeError):
+        h.mesh_obj(1, str(tmp_path / "missing.obj"), 0, (0, 0, 0), 1.0)
+    o.close(); h.close()
+
+
+def test_mat4_products_and_inverse(oracle_api, host_api):
+    rng = np.random.default_rng(0)
+    Lh, Lo = host_api.host_lib(), oracle_api.lib()
+    o, h = oracle_api.OracleScene(), host_api.HostScene()
+    for _ in range(50):
+        t = rng.uniform(-5, 5, 3)
+        s, rx, ry, rz = rng.uniform(0.1, 4), *rng.uniform(-3.2, 3.2, 3)
+        A, B = o.trs(t, s, rx, ry, rz), h.trs(t, s, rx, ry, rz)
+        assert np.array_equal(A.view(np.uint32), B.view(np.uint32))
+        ia, ib = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        Lo.orc_mat4_inverse(A.ctypes.data_as(C.c_void_p), ia.ctypes.data_as(C.c_void_p))
+        Lh.rth_mat4_inverse(B.ctypes.data_as(C.c_void_p), ib.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(ia.view(np.uint32), ib.view(np.uint32))
+        assert np.allclose(A.reshape(4, 4).astype(np.float64) @ ia.reshape(4, 4).astype(np.float64), np.eye(4), atol=1e-4)
+    o.close(); h.close()
