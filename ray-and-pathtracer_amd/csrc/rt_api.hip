@@ -429,7 +429,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 	const float t_min = R.mode == RT_MODE_WHITTED ? (float)1e-6 : 0.001f; // renderer.cpp:24, :131
 	const int grid = c->gridBlocks;
 	prof_begin(c, K_GENERATE);
-	hipLaunchKernelGGL(k_generate, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->C, R, P, Q);
+	hipLaunchKernelGGL(k_generate, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q);
 	prof_end(c);
 	int parity = 0;
 	for (int round = 0; round < maxRounds; round++) {
@@ -449,7 +449,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 		prof_end(c);
 		prof_begin(c, K_SHADE);
 		hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
-		hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->C, R, P, Q, parity);
+		hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity);
 		prof_end(c);
 		parity = 1 - parity;
 		// look at the queue length every few rounds (one small D2H copy + sync); stop when it is empty

@@ -231,8 +231,22 @@ __device__ __forceinline__ void flush_counters(DCounters* g, const LaneCounters&
 	}
 }
 
+// Store a freshly created ray: run the head tests of Scene::FindNearest on it now (dense kernel), keep
+// the shortened ray.t in O.w and the candidate hit in D.w for extend.
+__device__ __forceinline__ void emit_ray(const DScene& S, PathState& P, int buf, int slot, const f3& O, const f3& D, float t_min)
+{
+	float rayT = 1e34f; // Ray constructor default (template/scene.h:42)
+	HitRef head;
+	head.kind = -1, head.inst = -1, head.prim = 0, head.t = 0;
+	LaneCounters unused;
+	find_nearest_head<false>(S, O, D, t_min, rayT, head, unused);
+	P.O[buf][slot] = mk4(O, rayT);
+	P.D[buf][slot] = mk4(D, __uint_as_float(pack_head(head)));
+}
+__device__ __forceinline__ float mode_t_min(int mode) { return mode == 0 ? (float)1e-6 : 0.001f; } // renderer.cpp:24, :131
+
 // Put sample 'sid' of the pool into a slot: seed, jitter, primary ray (renderer.cpp:263-278)
-__device__ __forceinline__ void start_sample(const DCamera& C, const RenderParams& R, PathState& P, int slot, uint sid, int parityOut)
+__device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, const RenderParams& R, PathState& P, int slot, uint sid, int parityOut)
 {
 	f3 O, D;
 	uint seed = 0;
@@ -257,8 +271,7 @@ __device__ __forceinline__ void start_sample(const DCamera& C, const RenderParam
 			depth = 4;
 		}
 	}
-	P.O[parityOut][slot] = mk4(O, 1e34f);
-	P.D[parityOut][slot] = mk4(D, 0.0f);
+	emit_ray(S, P, parityOut, slot, O, D, mode_t_min(R.mode));
 	P.W[slot] = make_float4(1, 1, 1, __int_as_float(depth));
 	P.E[slot] = make_float4(1, 1, 1, __uint_as_float(seed));
 	P.L[slot] = make_float4(0, 0, 0, __uint_as_float(sid));
@@ -276,11 +289,11 @@ __device__ __forceinline__ void push_pending(PathState& P, int slot, const f3& O
 
 // ---- kernels -----------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(RT_BLOCK) k_generate(DCamera C, RenderParams R, PathState P, Queues Q)
+__global__ void __launch_bounds__(RT_BLOCK) k_generate(DScene S, DCamera C, RenderParams R, PathState P, Queues Q)
 {
 	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= P.nSlots) return;
-	start_sample(C, R, P, slot, (uint)slot, 0); // slots take the first nSlots samples of the pool
+	start_sample(S, C, R, P, slot, (uint)slot, 0); // slots take the first nSlots samples of the pool
 	P.status[slot] = ST_ACTIVE;
 	if (slot == 0) Q.counts[7] = P.nSlots;
 }
@@ -299,11 +312,12 @@ struct ExtendPolicy {
 	PathState& P;
 	const uint* queue;
 	int parity;
-	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax) const
+	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
 	{
 		const int slot = (int)queue[work];
 		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
-		O = xyz(o4), D = xyz(d4), tmax = o4.w;
+		O = xyz(o4), D = xyz(d4), tmax = o4.w; // o4.w: ray.t after the head tests made when the ray was created
+		unpack_head(__float_as_uint(d4.w), head);
 		return true;
 	}
 	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
@@ -326,8 +340,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queu
 	lc.clear();
 	uint rays = 0;
 	ExtendPolicy pol{ S, P, Q.active, parity };
-	trace_persistent<false, COUNT>(S, pol, Q.counts[0], &Q.counts[4], t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
-	if (COUNT) flush_counters(counters, lc, rays, 0);
+	trace_persistent<false, COUNT, false>(S, pol, Q.counts[0], &Q.counts[4], t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	if (COUNT) {
+		// the head tests ran where the rays were created: per ray, every light and every brute-force primitive
+		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
+		flush_counters(counters, lc, rays, 0);
+	}
 }
 
 // shade: everything Trace / Sample do at a hit except the occlusion-dependent direct terms.
@@ -434,8 +452,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, Pa
 				P.sh[(size_t)S.nLights * P.nSlots + slot] = mk4(W, segmentEnds ? 1.0f : 0.0f);
 			}
 			if (!segmentEnds) {
-				P.O[pout][slot] = mk4(nO, 1e34f);
-				P.D[pout][slot] = mk4(nD, 0.0f);
+				emit_ray(S, P, pout, slot, nO, nD, mode_t_min(R.mode));
 				P.W[slot] = mk4(nW, __int_as_float(nDepth));
 				keep = true;
 			} else if (!wantShadow) {
@@ -453,7 +470,7 @@ struct ConnectPolicy {
 	PathState& P;
 	const uint* queue;
 	int parity, nLights;
-	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax) const
+	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef&) const
 	{
 		const int slot = (int)queue[work / nLights], li = work % nLights;
 		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
@@ -479,7 +496,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Que
 	lc.clear();
 	uint rays = 0;
 	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights };
-	trace_persistent<true, COUNT>(S, pol, Q.counts[2] * S.nLights, &Q.counts[6], 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	trace_persistent<true, COUNT, false>(S, pol, Q.counts[2] * S.nLights, &Q.counts[6], 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -533,7 +550,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 // finish: a slot's segment ended without a continuation ray.  Resume the most recent pending
 // Whitted branch if there is one; otherwise the sample is complete: store it (renderer.cpp:270 /
 // :279-282, gamma per sample) and pull the next sample from the pool.
-__global__ void __launch_bounds__(RT_BLOCK) k_finish(DCamera C, RenderParams R, PathState P, Queues Q, int parity)
+__global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, RenderParams R, PathState P, Queues Q, int parity)
 {
 	const uint lane = threadIdx.x & 63;
 	const int pout = 1 - parity;
@@ -564,8 +581,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DCamera C, RenderParams R, 
 				np--;
 				const float4* e = P.pend + ((size_t)slot * RT_PEND_CAP + np) * 4;
 				const float4 o = e[0], d = e[1], w = e[2], en = e[3];
-				P.O[pout][slot] = make_float4(o.x, o.y, o.z, 1e34f);
-				P.D[pout][slot] = make_float4(d.x, d.y, d.z, 0.0f);
+				emit_ray(S, P, pout, slot, xyz(o), xyz(d), mode_t_min(R.mode));
 				P.W[slot] = make_float4(w.x, w.y, w.z, o.w);
 				P.E[slot] = make_float4(en.x, en.y, en.z, P.E[slot].w);
 				P.pendCount[slot] = np;
@@ -583,7 +599,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DCamera C, RenderParams R, 
 		if (completes) {
 			const uint sidNext = (uint)(base + __popcll(m & ((1ull << lane) - 1)));
 			if (sidNext < R.nSamples) {
-				start_sample(C, R, P, slot, sidNext, pout);
+				start_sample(S, C, R, P, slot, sidNext, pout);
 				stBits |= ST_ACTIVE;
 			}
 		}
@@ -614,7 +630,7 @@ struct QueryHit { float t; int objIdx; int mat; float nx, ny, nz; };
 
 struct ArrayRays {
 	const float* O3; const float* D3; const float* tmax;
-	__device__ __forceinline__ bool load(int i, f3& O, f3& D, float& tm) const
+	__device__ __forceinline__ bool load(int i, f3& O, f3& D, float& tm, HitRef&) const
 	{
 		O = f3(O3[3 * i], O3[3 * i + 1], O3[3 * i + 2]), D = f3(D3[3 * i], D3[3 * i + 1], D3[3 * i + 2]);
 		tm = tmax ? tmax[i] : 1e34f;
@@ -628,7 +644,8 @@ struct NearestQueryPolicy : ArrayRays {
 	{
 		f3 O, D;
 		float tm;
-		load(i, O, D, tm);
+		HitRef unused;
+		load(i, O, D, tm, unused);
 		int objIdx, mat;
 		f3 normal;
 		resolve_hit(S, hit, O, D, objIdx, mat, normal);
@@ -645,12 +662,13 @@ struct OccludedQueryPolicy : ArrayRays {
 // Camera::GetPrimaryRay + Scene::FindNearest for every pixel
 struct PrimaryPolicy {
 	const DScene& S; const DCamera& C; int* objOut; float* tOut;
-	__device__ __forceinline__ bool load(int i, f3& O, f3& D, float& tm) const { primary_ray(C, i % C.width, i / C.width, O, D); tm = 1e34f; return true; }
+	__device__ __forceinline__ bool load(int i, f3& O, f3& D, float& tm, HitRef&) const { primary_ray(C, i % C.width, i / C.width, O, D); tm = 1e34f; return true; }
 	__device__ __forceinline__ void store(int i, const HitRef& hit, const f3&, const f3&) const
 	{
 		f3 O, D;
 		float tm;
-		load(i, O, D, tm);
+		HitRef unused;
+		load(i, O, D, tm, unused);
 		int objIdx, mat;
 		f3 normal;
 		resolve_hit(S, hit, O, D, objIdx, mat, normal);
@@ -668,7 +686,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, con
 	lc.clear();
 	uint rays = 0;
 	NearestQueryPolicy pol(S, O3, D3, tmax, out);
-	trace_persistent<false, COUNT>(S, pol, n, &work[0], t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, COUNT, true>(S, pol, n, &work[0], t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
@@ -681,7 +699,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, co
 	lc.clear();
 	uint rays = 0;
 	OccludedQueryPolicy pol(O3, D3, tmax, out);
-	trace_persistent<true, COUNT>(S, pol, n, &work[0], 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<true, COUNT, false>(S, pol, n, &work[0], 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -693,7 +711,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, 
 	lc.clear();
 	uint rays = 0;
 	PrimaryPolicy pol{ S, C, objOut, tOut };
-	trace_persistent<false, COUNT>(S, pol, C.width * C.height, &work[0], t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, COUNT, true>(S, pol, C.width * C.height, &work[0], t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 

@@ -139,6 +139,37 @@ __device__ __forceinline__ void light_intersect(const DLight& L, int li, const f
 	}
 }
 
+// What Scene::FindNearest tests before it enters the BVH / TLAS (template/scene.h:1257-1261): every
+// light, then in TLAS mode the brute-force spheres and planes, all with the caller's t_min.  The
+// render path runs this where rays are CREATED (shade / finish: dense, all lanes busy) and hands
+// extend the shortened rayT plus the candidate hit; the batch queries run it when a lane picks up a ray.
+template <bool COUNT>
+__device__ __forceinline__ void find_nearest_head(const DScene& S, const f3& O, const f3& D, float t_min, float& rayT, HitRef& hit, LaneCounters& lc)
+{
+	for (int i = 0; i < S.nLights; i++) {
+		light_intersect(S.lights[i], i, O, D, t_min, rayT, hit);
+		if (COUNT) lc.light++;
+	}
+	if (S.useTLAS) {
+		const int nb = S.nBruteSph + S.nBrutePla;
+		for (int i = 0; i < nb; i++) {
+			const float4 r0 = S.brute[4 * i];
+			float t;
+			const bool h = i < S.nBruteSph ? sphere_hit(O, D, rayT, t_min, xyz(r0), r0.w, t) : plane_hit(O, D, rayT, t_min, xyz(r0), r0.w, t);
+			if (COUNT) lc.brute++;
+			if (h) rayT = t, hit.kind = 1, hit.prim = (uint)i, hit.inst = -1;
+		}
+	}
+}
+// the candidate hit of the head tests as one dword (kept in the ray's D.w): 0 none, kind << 28 | prim + 1
+__device__ __forceinline__ uint pack_head(const HitRef& h) { return h.kind < 0 ? 0u : ((uint)h.kind << 28) | (h.prim + 1); }
+__device__ __forceinline__ void unpack_head(uint v, HitRef& h)
+{
+	h.inst = -1;
+	if (v == 0) { h.kind = -1, h.prim = 0; return; }
+	h.kind = (int)(v >> 28), h.prim = (v & 0x0FFFFFFFu) - 1;
+}
+
 // ---- persistent, lane-granular traversal --------------------------------------------------------
 // Rays in one wave need very different numbers of node visits, so a wave that walks 64 rays to
 // completion idles most of its lanes most of the time (measured: 12 % VALU lane utilisation).
@@ -149,14 +180,15 @@ __device__ __forceinline__ void light_intersect(const DLight& L, int li, const f
 // pushed, leaf primitives in primitiveIdx order, t_min 0.0001 inside the BVH.
 //
 // A *policy* supplies the rays and takes the results:
-//   bool load(int work, f3& O, f3& D, float& tmax)   world-space ray of work item 'work'; false = nothing to trace
+//   bool load(int work, f3& O, f3& D, float& tmax, HitRef& head)   world-space ray of work item 'work' (+ the
+//                                                     candidate hit of head tests already made); false = nothing to trace
 //   void store(int work, const HitRef&, O, D)         nearest-hit result      (ANY == false)
 //   void store(int work, bool occluded)               occlusion result        (ANY == true)
 #define RT_TLAS_BIT 0x40000000u
 #define RT_LINK_POP 0xFFFFFFFDu
 #define RT_CHUNK 256 // queue entries a wave reserves per atomic on the work head
 
-template <bool ANY, bool COUNT, class Policy>
+template <bool ANY, bool COUNT, bool HEAD, class Policy>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* head, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
@@ -194,29 +226,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 					const int avail = chunkEnd - chunkNext;
 					float tmax = 0;
 					// a work item may turn out to be nothing to trace (slot not in this state): the lane stays idle
-					if (idle && mine < chunkEnd && pol.load(mine, O, D, tmax)) {
+					hit.kind = idle ? -1 : hit.kind;
+					if (idle && mine < chunkEnd && pol.load(mine, O, D, tmax, hit)) {
 						work = mine;
 						rayT = tmax;
 						st.sp = 0, inst = -1;
-						hit.kind = -1, hit.inst = -1, hit.prim = 0;
-						if (!ANY) {
-							// Scene::FindNearest head (template/scene.h:1257-1261): lights, then in TLAS mode the
-							// brute-force spheres and planes, all with the caller's t_min
-							for (int i = 0; i < S.nLights; i++) {
-								light_intersect(S.lights[i], i, O, D, t_min, rayT, hit);
-								if (COUNT) lc.light++;
-							}
-							if (S.useTLAS) {
-								const int nb = S.nBruteSph + S.nBrutePla;
-								for (int i = 0; i < nb; i++) {
-									const float4 r0 = S.brute[4 * i];
-									float t;
-									const bool h = i < S.nBruteSph ? sphere_hit(O, D, rayT, t_min, xyz(r0), r0.w, t) : plane_hit(O, D, rayT, t_min, xyz(r0), r0.w, t);
-									if (COUNT) lc.brute++;
-									if (h) rayT = t, hit.kind = 1, hit.prim = (uint)i, hit.inst = -1;
-								}
-							}
-						}
+						if (!ANY && HEAD) find_nearest_head<COUNT>(S, O, D, t_min, rayT, hit, lc);
 						rD = rcp3(D);
 						link = S.useTLAS ? RT_TLAS_BIT : S.rootLink;
 						if (link == RT_EMPTY) link = RT_LINK_POP;
@@ -328,7 +343,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 					if (v == RT_SENTINEL) {
 						// back to world space (the backup ray of bvhInstance.cpp:6, :20), then keep popping
 						float tmaxUnused;
-						pol.load(work, O, D, tmaxUnused);
+						HitRef headUnused;
+						pol.load(work, O, D, tmaxUnused, headUnused);
 						rD = rcp3(D);
 						inst = -1;
 						link = RT_LINK_POP;
