@@ -133,6 +133,21 @@ def test_path_frames(name, kw, w, h, frames, scenes, oracle_api, host_api):
     r.close()
 
 
+def test_fisheye_camera(scenes, oracle_api, host_api):
+    """Camera::GetPrimaryRay fisheye branch (camera.h:26-32): primary hits and a Whitted frame."""
+    o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 64, 40)
+    cam = orr.camera()
+    for rr in (orr, r):
+        rr.set_camera(cam[0], cam[1], cam[2], cam[3], fisheye=True, view_angle=0.4, y_angle=0.3)
+    obj_ref, t_ref, _ = orr.primary_hits(1e-6)
+    obj, t = r.primary_hits(1e-6)
+    assert np.array_equal(obj, obj_ref)
+    assert np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    check_frames(orr, r, "whitted", 1, host_api)
+    check_frames(orr, r, "path", 2, host_api)
+    r.close()
+
+
 def test_frames_one_by_one_equal_batch(scenes, oracle_api, host_api):
     """Progressive accumulation: 6 calls of one frame == one call of 6 frames (path regeneration)."""
     o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 64, 40)
