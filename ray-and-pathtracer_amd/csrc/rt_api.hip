@@ -43,7 +43,8 @@ struct rt_ctx {
 	// traversal stack spill + flags
 	uint* spill = nullptr;
 	int gridBlocks = 0;
-	int refillMin = 24; // idle lanes a wave waits for before it refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
+	int refillMin = 24; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
+	int refillAny = 32; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
 	bool counting = false, profiling = false;
@@ -152,7 +153,9 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_REFILL")) c->refillMin = atoi(getenv("RT_REFILL"));
 	if (c->refillMin < 1) c->refillMin = 1;
 	if (c->refillMin > 64) c->refillMin = 64;
-	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 8; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
+	if (getenv("RT_REFILL_ANY")) c->refillAny = atoi(getenv("RT_REFILL_ANY"));
+	if (c->refillAny < 1 || c->refillAny > 64) c->refillAny = 32;
+	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 16; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
 	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->flags, 16 * sizeof(int)) == hipSuccess;
 	ok = ok && hipMemset(c->flags, 0, 16 * sizeof(int)) == hipSuccess;
@@ -295,6 +298,35 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			pack_prim(&prims[(size_t)(primOff + j) * 16], b, p, last[j] != 0);
 		}
 	}
+	// TLAS inner nodes -> pair records appended to the BLAS pairs (children boxes inside the parent's
+	// record; child A = leftRight & 0xFFFF, the one tlas::Intersect tests first)
+	uint tlasRoot = RT_EMPTY;
+	if (d->use_tlas) {
+		for (uint i = 0; i < d->tlas_nodes_used; i++) {
+			const rt_tlas_node& nd = d->tlas_nodes[i];
+			if (nd.left_right == 0) { if (nd.blas >= d->n_instances && i != 0) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u instance %u out of range", i, nd.blas); }
+			else if ((nd.left_right & 0xFFFF) >= d->tlas_nodes_used || (nd.left_right >> 16) >= d->tlas_nodes_used) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u child out of range", i);
+		}
+		const uint nT = d->tlas_nodes_used;
+		std::vector<uint> slotOf(nT, 0);
+		uint next = (uint)(pairs.size() / 16);
+		for (uint i = 0; i < nT; i++) if (d->tlas_nodes[i].left_right != 0) slotOf[i] = next++;
+		auto tlink = [&](uint i) -> uint { const rt_tlas_node& nd = d->tlas_nodes[i]; return nd.left_right == 0 ? (RT_INST_BIT | nd.blas) : slotOf[i]; };
+		pairs.resize((size_t)next * 16, 0.0f);
+		for (uint i = 0; i < nT; i++) {
+			const rt_tlas_node& nd = d->tlas_nodes[i];
+			if (nd.left_right == 0) continue;
+			const uint ch[2] = { nd.left_right & 0xFFFFu, nd.left_right >> 16 };
+			float* rec = &pairs[(size_t)slotOf[i] * 16];
+			for (int s = 0; s < 2; s++) {
+				const rt_tlas_node& cn = d->tlas_nodes[ch[s]];
+				const uint lk = tlink(ch[s]);
+				memcpy(rec + 8 * s, cn.aabb_min, 12), memcpy(rec + 8 * s + 3, &lk, 4);
+				memcpy(rec + 8 * s + 4, cn.aabb_max, 12);
+			}
+		}
+		tlasRoot = tlink(0);
+	}
 	DScene S;
 	memset(&S, 0, sizeof(S));
 	float* dp = nullptr;
@@ -304,18 +336,10 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	HIPCHK(c, dalloc(c->sceneAllocs, &dp, prims.size() + 16));
 	HIPCHK(c, hipMemcpy(dp, prims.data(), prims.size() * 4, hipMemcpyHostToDevice));
 	S.prims = (const float4*)dp;
-	S.rootLink = rootLink[0];
+	S.rootLink = d->use_tlas ? tlasRoot : rootLink[0];
 	S.useTLAS = d->use_tlas ? 1 : 0;
 
 	if (d->use_tlas) {
-		for (uint i = 0; i < d->tlas_nodes_used; i++) {
-			const rt_tlas_node& nd = d->tlas_nodes[i];
-			if (nd.left_right == 0) { if (nd.blas >= d->n_instances && i != 0) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u instance %u out of range", i, nd.blas); }
-			else if ((nd.left_right & 0xFFFF) >= d->tlas_nodes_used || (nd.left_right >> 16) >= d->tlas_nodes_used) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u child out of range", i);
-		}
-		HIPCHK(c, dalloc(c->sceneAllocs, &dp, (size_t)d->tlas_nodes_used * 8));
-		HIPCHK(c, hipMemcpy(dp, d->tlas_nodes, (size_t)d->tlas_nodes_used * 32, hipMemcpyHostToDevice));
-		S.tlas = (const float4*)dp;
 		std::vector<DInstance> inst(d->n_instances);
 		for (uint i = 0; i < d->n_instances; i++) {
 			const rt_instance& in = d->instances[i];
@@ -444,8 +468,8 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 		prof_end(c);
 		hipLaunchKernelGGL(k_compact, dim3(grid), dim3(RT_BLOCK), 0, c->stream, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
 		prof_begin(c, K_CONNECT);
-		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->refillMin, c->spill, c->counters + 1);
-		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, c->refillMin, c->spill, c->counters + 1);
+		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, (c->refillMin & ~0xFF) | c->refillAny, c->spill, c->counters + 1);
+		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, (c->refillMin & ~0xFF) | c->refillAny, c->spill, c->counters + 1);
 		prof_end(c);
 		prof_begin(c, K_SHADE);
 		hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);

@@ -24,6 +24,9 @@
 
 namespace rtd {
 
+#ifndef RT_EXTEND_WAVES
+#define RT_EXTEND_WAVES 7 // waves per SIMD the extend kernel is compiled for (launch bound)
+#endif
 #define RT_PEND_CAP 12 // pending Whitted branches per pixel (glass: <= 3 at depth 4; shiny diffuse: more)
 
 struct DCamera {
@@ -333,7 +336,7 @@ struct ExtendPolicy {
 	}
 };
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
 	LaneCounters lc;

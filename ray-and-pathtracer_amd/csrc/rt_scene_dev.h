@@ -14,7 +14,9 @@
 //              plane  {N.xyz, d}    {-}            {-}          {-, objIdx, mat, kind|last}
 //            'last' marks the final slot of a leaf, so a leaf is named by its first slot alone and
 //            a stack entry is one dword.
-//   tlas[]   the reference's 32-byte TLASNode records (tlas.h:4-11), 2 float4 each.
+//            TLAS inner nodes (tlas.h:4-11) are stored in the same form (children boxes inside the
+//            parent's record, link = pair index or INST_BIT | instance), so one piece of code walks both
+//            levels; tlas::Intersect tests child (leftRight & 0xFFFF) first, which is slot A here.
 //   inst[]   128-byte records: invTransform rows 0-2, matTransform rows 0-2, root link.
 // All of it is read-only and a few MB at most: every XCD's 4 MiB L2 ends up holding its own copy.
 #pragma once
@@ -54,13 +56,12 @@ struct DInstance {
 struct DScene {
 	const float4* pairs;
 	const float4* prims;
-	const float4* tlas;
 	const DInstance* inst;
 	const float4* brute; // TLAS mode: spheres then planes, prim-record format
 	const DLight* lights;
 	const DMaterial* mats;
 	const unsigned char* sky;
-	uint rootLink; // non-TLAS scene BVH
+	uint rootLink; // scene BVH root, or the TLAS root in TLAS mode
 	int useTLAS;
 	int nBruteSph, nBrutePla;
 	int nLights;
@@ -184,8 +185,9 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 //                                                     candidate hit of head tests already made); false = nothing to trace
 //   void store(int work, const HitRef&, O, D)         nearest-hit result      (ANY == false)
 //   void store(int work, bool occluded)               occlusion result        (ANY == true)
-#define RT_TLAS_BIT 0x40000000u
-#define RT_LINK_POP 0xFFFFFFFDu
+#define RT_INST_BIT 0x40000000u // link names an instance (TLAS leaf)
+#define RT_LINK_EXIT 0xFFFFFFFCu // leave the current instance (the sentinel was popped)
+#define RT_LINK_DONE 0xFFFFFFFBu // this ray is finished; its result is written at the next refill
 #define RT_CHUNK 256 // queue entries a wave reserves per atomic on the work head
 
 template <bool ANY, bool COUNT, bool HEAD, class Policy>
@@ -202,160 +204,148 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	bool exhausted = false;  // wave-uniform: the queue has no more entries
 	f3 O(0.0f), D(0.0f), rD(0.0f);
 	float rayT = 0;
-	uint link = RT_LINK_POP;
+	uint link = RT_LINK_DONE;
 	HitRef hit;
 	hit.kind = -1, hit.inst = -1, hit.prim = 0, hit.t = 0;
 	int inst = -1;
 
+	// next node for this lane: pop the stack; an empty stack ends the ray, the sentinel leaves the instance
+	auto pop_next = [&]() {
+		if (st.sp == 0) { link = RT_LINK_DONE; return; }
+		const uint v = st.pop();
+		link = v == RT_SENTINEL ? RT_LINK_EXIT : v;
+	};
+
 	while (true) {
-		// ---- refill idle lanes ----
+		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
 		const bool idle = work < 0;
-		const unsigned long long idleMask = __ballot(idle);
-		if (idleMask != 0 && !exhausted) {
-			const int cnt = __popcll(idleMask);
-			if (cnt >= refillMin || idleMask == ~0ull) {
-				if (chunkNext >= chunkEnd) {
-					int base = 0;
-					if (lane == 0) base = atomicAdd(head, RT_CHUNK);
-					base = __shfl(base, 0);
-					chunkNext = base, chunkEnd = base + RT_CHUNK < n ? base + RT_CHUNK : n;
-					if (base >= n) exhausted = true;
+		const bool doneLane = work >= 0 && link == RT_LINK_DONE;
+		const unsigned long long freeMask = __ballot(idle || doneLane);
+		if (freeMask != 0) {
+			const int cnt = __popcll(freeMask);
+			if (cnt >= refillMin || freeMask == ~0ull) {
+				if (doneLane) {
+					// results are written here, many lanes at a time, not one lane per iteration
+					if constexpr (ANY) pol.store(work, hit.kind == 1);
+					else { hit.t = rayT; pol.store(work, hit, O, D); }
+					work = -1;
 				}
 				if (!exhausted) {
-					const int mine = chunkNext + __popcll(idleMask & below);
-					const int avail = chunkEnd - chunkNext;
-					float tmax = 0;
-					// a work item may turn out to be nothing to trace (slot not in this state): the lane stays idle
-					hit.kind = idle ? -1 : hit.kind;
-					if (idle && mine < chunkEnd && pol.load(mine, O, D, tmax, hit)) {
-						work = mine;
-						rayT = tmax;
-						st.sp = 0, inst = -1;
-						if (!ANY && HEAD) find_nearest_head<COUNT>(S, O, D, t_min, rayT, hit, lc);
-						rD = rcp3(D);
-						link = S.useTLAS ? RT_TLAS_BIT : S.rootLink;
-						if (link == RT_EMPTY) link = RT_LINK_POP;
-						rays++;
+					if (chunkNext >= chunkEnd) {
+						int base = 0;
+						if (lane == 0) base = atomicAdd(head, RT_CHUNK);
+						base = __shfl(base, 0);
+						chunkNext = base, chunkEnd = base + RT_CHUNK < n ? base + RT_CHUNK : n;
+						if (base >= n) exhausted = true;
 					}
-					chunkNext += cnt < avail ? cnt : avail;
+					if (!exhausted) {
+						const int mine = chunkNext + __popcll(freeMask & below);
+						const int avail = chunkEnd - chunkNext;
+						float tmax = 0;
+						const bool take = mine < chunkEnd && ((freeMask >> lane) & 1);
+						if (take) hit.kind = -1, hit.prim = 0, hit.inst = -1;
+						// a work item may turn out to be nothing to trace: the lane stays idle
+						if (take && pol.load(mine, O, D, tmax, hit)) {
+							work = mine;
+							rayT = tmax;
+							st.sp = 0, inst = -1;
+							if (!ANY && HEAD) find_nearest_head<COUNT>(S, O, D, t_min, rayT, hit, lc);
+							rD = rcp3(D);
+							link = S.rootLink;
+							if (link == RT_EMPTY) link = RT_LINK_DONE;
+							rays++;
+						}
+						chunkNext += cnt < avail ? cnt : avail;
+					}
 				}
 			}
 		}
-		if (__ballot(work >= 0) == 0) {
-			if (exhausted) break;
-			continue;
+		const bool stepping = work >= 0 && link != RT_LINK_DONE;
+		if (__ballot(stepping) == 0) {
+			if (exhausted && __ballot(work >= 0) == 0) break;
+			continue; // only finished lanes left (they flush above), or nothing was handed out this time
 		}
 
 		// ---- one step of the state machine ----
-		// The two common step kinds (primitive test, sibling-pair test) are different code; a kind that
-		// only a few lanes want this iteration is postponed until at least stepMin lanes want it (or it
-		// is the majority), so its instructions run with more lanes enabled.
+		// Four kinds of step, four pieces of code.  A kind that only a few lanes want this iteration
+		// is postponed until at least stepMin lanes want it or it is the most wanted kind, so its
+		// instructions run with more lanes enabled; postponed lanes just wait.
 		const uint lk = link;
-		const bool wantLeaf = work >= 0 && lk != RT_LINK_POP && (lk & RT_LEAF_BIT);
-		const bool wantPair = work >= 0 && !(lk & (RT_LEAF_BIT | RT_TLAS_BIT));
-		bool runLeaf = true, runPair = true;
-		if (stepMin > 0) {
-			const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(wantPair));
-			runLeaf = nL >= stepMin || nL >= nP;
-			runPair = nP >= stepMin || nP > nL;
+		const bool wantLeaf = stepping && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
+		const bool wantExit = stepping && lk == RT_LINK_EXIT;
+		const bool wantTlas = stepping && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT);
+		const bool wantPair = stepping && !(lk & (RT_LEAF_BIT | RT_INST_BIT));
+		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(wantPair));
+		const int nT = __popcll(__ballot(wantTlas)), nE = __popcll(__ballot(wantExit));
+		int most = nL > nP ? nL : nP;
+		most = nT > most ? nT : most;
+		most = nE > most ? nE : most;
+		const bool runLeaf = nL > 0 && (nL >= stepMin || nL == most);
+		const bool runPair = nP > 0 && (nP >= stepMin || nP == most);
+		const bool runTlas = nT > 0 && (nT >= stepMin || nT == most);
+		const bool runExit = nE > 0 && (nE >= stepMin || nE == most);
+
+		if (runPair && wantPair) {
+			// one sibling pair: of the BLAS (bvh.cpp:638-654 / :788-804) or, outside an instance in TLAS
+			// mode, of the TLAS (tlas.cpp:77-91 / :106-120) -- same test, same ordering rule
+			if (COUNT) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
+			const float4* p = S.pairs + 4 * (size_t)lk;
+			const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+			float dist1 = intersect_aabb(O, rD, rayT, xyz(a0), xyz(a1));
+			float dist2 = intersect_aabb(O, rD, rayT, xyz(b0), xyz(b1));
+			uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
+			if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
+			if (dist1 == 1e30f) pop_next();
+			else {
+				link = c1;
+				if (dist2 != 1e30f) st.push(c2);
+			}
 		}
-		if (work >= 0 && !(wantLeaf && !runLeaf) && !(wantPair && !runPair)) {
-			bool needPop = false, finished = false, occluded = false;
-			if (lk == RT_LINK_POP) {
-				needPop = true;
-			} else if (lk & RT_LEAF_BIT) {
-				// one primitive of a leaf (bvh.cpp:616-629 / :770-783)
-				const uint slot = lk & ~RT_LEAF_BIT;
-				const float4 r0 = S.prims[4 * (size_t)slot + 0];
-				const float4 r3 = S.prims[4 * (size_t)slot + 3];
-				const int kl = __float_as_int(r3.w);
-				const int kind = kl & 3;
-				if (COUNT) lc.prim++;
-				float t;
-				bool h;
-				if (kind == RT_KIND_TRI) {
-					const float4 r1 = S.prims[4 * (size_t)slot + 1];
-					const float4 r2 = S.prims[4 * (size_t)slot + 2];
-					h = tri_hit(O, D, rayT, bvh_t_min, xyz(r0), xyz(r1), xyz(r2), f3(r0.w, r1.w, r2.w), r3.x, t);
-				} else if (kind == RT_KIND_SPHERE) {
-					if (ANY) h = sphere_occludes(O, D, rayT, bvh_t_min, xyz(r0), r0.w);
-					else h = sphere_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
-				} else {
-					h = plane_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
-				}
-				if (h) {
-					if (ANY) finished = true, occluded = true;
-					else rayT = t, hit.prim = slot, hit.inst = inst, hit.kind = 0;
-				}
-				if (kl & RT_LAST_BIT) needPop = true;
+		if (runLeaf && wantLeaf) {
+			// one primitive of a leaf (bvh.cpp:616-629 / :770-783); all four vectors of the record in
+			// one go (nearly every record is a triangle)
+			const uint slot = lk & ~RT_LEAF_BIT;
+			const float4* rec = S.prims + 4 * (size_t)slot;
+			const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+			const int kl = __float_as_int(r3.w);
+			const int kind = kl & 3;
+			if (COUNT) lc.prim++;
+			float t;
+			bool h;
+			if (kind == RT_KIND_TRI) h = tri_hit(O, D, rayT, bvh_t_min, xyz(r0), xyz(r1), xyz(r2), f3(r0.w, r1.w, r2.w), r3.x, t);
+			else if (kind == RT_KIND_SPHERE) {
+				if (ANY) h = sphere_occludes(O, D, rayT, bvh_t_min, xyz(r0), r0.w);
+				else h = sphere_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
+			} else h = plane_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
+			if (h && ANY) hit.kind = 1, link = RT_LINK_DONE; // first occluder ends the query
+			else {
+				if (h) rayT = t, hit.prim = slot, hit.inst = inst, hit.kind = 0;
+				if (kl & RT_LAST_BIT) pop_next();
 				else link = lk + 1;
-			} else if (lk & RT_TLAS_BIT) {
-				// tlas::Intersect / IsOccluded (tlas.cpp:65-122)
-				const uint node = lk & ~RT_TLAS_BIT;
-				const float4 n0 = S.tlas[2 * node], n1 = S.tlas[2 * node + 1];
-				const uint leftRight = __float_as_uint(n0.w);
-				if (leftRight == 0) {
-					// bvhInstance::BIntersect / IsOccluded (bvhInstance.cpp:3-35): ray to object space with
-					// invTransform (direction not renormalised: t is shared by both spaces); the BLAS is walked
-					// above a sentinel on the same stack
-					inst = (int)__float_as_uint(n1.w);
-					if (COUNT) lc.inst++;
-					const DInstance* I = S.inst + inst;
-					const f3 Oo = xform_pos(I->invT, O);
-					const f3 Do = xform_vec(I->invT, D);
-					O = Oo, D = Do, rD = rcp3(Do);
-					st.push(RT_SENTINEL);
-					link = I->rootLink;
-					if (link == RT_EMPTY) link = RT_LINK_POP;
-				} else {
-					if (COUNT) lc.tlasInner++;
-					uint c1 = leftRight & 0xFFFFu, c2 = leftRight >> 16;
-					const float4 a0 = S.tlas[2 * c1], a1 = S.tlas[2 * c1 + 1];
-					const float4 b0 = S.tlas[2 * c2], b1 = S.tlas[2 * c2 + 1];
-					float dist1 = intersect_aabb(O, rD, rayT, xyz(a0), xyz(a1));
-					float dist2 = intersect_aabb(O, rD, rayT, xyz(b0), xyz(b1));
-					if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
-					if (dist1 == 1e30f) needPop = true;
-					else {
-						link = RT_TLAS_BIT | c1;
-						if (dist2 != 1e30f) st.push(RT_TLAS_BIT | c2);
-					}
-				}
-			} else {
-				// one sibling pair of the BLAS (bvh.cpp:638-654 / :788-804)
-				if (COUNT) lc.inner++;
-				const float4* p = S.pairs + 4 * (size_t)lk;
-				const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-				float dist1 = intersect_aabb(O, rD, rayT, xyz(a0), xyz(a1));
-				float dist2 = intersect_aabb(O, rD, rayT, xyz(b0), xyz(b1));
-				uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
-				if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
-				if (dist1 == 1e30f) needPop = true;
-				else {
-					link = c1;
-					if (dist2 != 1e30f) st.push(c2);
-				}
 			}
-			if (needPop && !finished) {
-				if (st.sp == 0) finished = true;
-				else {
-					const uint v = st.pop();
-					if (v == RT_SENTINEL) {
-						// back to world space (the backup ray of bvhInstance.cpp:6, :20), then keep popping
-						float tmaxUnused;
-						HitRef headUnused;
-						pol.load(work, O, D, tmaxUnused, headUnused);
-						rD = rcp3(D);
-						inst = -1;
-						link = RT_LINK_POP;
-					} else link = v;
-				}
-			}
-			if (finished) {
-				if constexpr (ANY) pol.store(work, occluded);
-				else { hit.t = rayT; pol.store(work, hit, O, D); }
-				work = -1;
-			}
+		}
+		if (runTlas && wantTlas) {
+			// TLAS leaf: bvhInstance::BIntersect / IsOccluded (bvhInstance.cpp:3-35): ray to object space
+			// with invTransform (direction not renormalised: t is shared by both spaces); the BLAS is
+			// walked above a sentinel on the same stack
+			inst = (int)(lk & ~RT_INST_BIT);
+			if (COUNT) lc.inst++;
+			const DInstance* I = S.inst + inst;
+			const f3 Oo = xform_pos(I->invT, O);
+			const f3 Do = xform_vec(I->invT, D);
+			O = Oo, D = Do, rD = rcp3(Do);
+			link = I->rootLink;
+			if (link == RT_EMPTY) link = RT_LINK_EXIT;
+			else st.push(RT_SENTINEL);
+		}
+		if (runExit && wantExit) {
+			// back to world space (the backup ray of bvhInstance.cpp:6, :20), then the next TLAS entry
+			float tmaxUnused;
+			HitRef headUnused;
+			pol.load(work, O, D, tmaxUnused, headUnused);
+			rD = rcp3(D);
+			inst = -1;
+			pop_next();
 		}
 	}
 }
