@@ -64,7 +64,11 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ha, scenes, dpar = pkg("host_api"), pkg("scenes"), pkg("distributed")
-    ha.build()
+    # one rank (re)builds stale libraries; the others wait, they would race in the same directory
+    if rank == 0:
+        ha.build()
+    if world > 1:
+        dist.barrier()
 
     # ---- workload ----
     probe = ha.HostScene()
