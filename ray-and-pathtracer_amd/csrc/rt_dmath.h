@@ -119,21 +119,29 @@ __device__ __forceinline__ float intersect_aabb_exact(const f3& O, const f3& rD,
 }
 // Same function on the hardware min/max.  v_min_f32 / v_max_f32 select one of their operands and
 // differ from the ternaries only when an operand is NaN (and in the sign of a zero result, which no
-// comparison below can see), so: if none of the six slab products is NaN the selection network
-// returns the same tmin / tmax; otherwise the literal form runs.  NaN products need 0 * inf
-// (a ray running exactly along a box face) and are rare.  The sum of the six is NaN whenever one of
-// them is (it may also be NaN for inf - inf: that only sends a clean case to the literal form).
-__device__ __forceinline__ float intersect_aabb(const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
+// comparison below can see).  A slab product (b - O) * rD is NaN only through 0 * inf, inf * 0 or a
+// NaN input.  ray_is_clean() rules all of those out once per ray: |O| < 1e30 and D finite make
+// b - O finite (boxes are bounded by +-1e30, bvh.cpp:96-109) and rD non-zero, and rD finite leaves
+// only finite * finite.  Clean rays take this path, every other ray the literal one.
+__device__ __forceinline__ bool ray_is_clean(const f3& O, const f3& D, const f3& rD)
+{
+	const float inf = __builtin_inff();
+	return fabsf(O.x) < 1e30f && fabsf(O.y) < 1e30f && fabsf(O.z) < 1e30f && fabsf(D.x) < inf && fabsf(D.y) < inf && fabsf(D.z) < inf &&
+	       fabsf(rD.x) < inf && fabsf(rD.y) < inf && fabsf(rD.z) < inf;
+}
+__device__ __forceinline__ float intersect_aabb_clean(const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
 {
 	const float tx1 = (bmin.x - O.x) * rD.x, tx2 = (bmax.x - O.x) * rD.x;
 	const float ty1 = (bmin.y - O.y) * rD.y, ty2 = (bmax.y - O.y) * rD.y;
 	const float tz1 = (bmin.z - O.z) * rD.z, tz2 = (bmax.z - O.z) * rD.z;
-	const float probe = ((tx1 + tx2) + (ty1 + ty2)) + (tz1 + tz2);
-	if (probe != probe) return intersect_aabb_exact(O, rD, rayT, bmin, bmax);
 	const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
 	const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
 	if (tmax >= tmin && tmin < rayT && tmax > 0) return tmin;
 	return 1e30f;
+}
+__device__ __forceinline__ float intersect_aabb(bool clean, const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
+{
+	return clean ? intersect_aabb_clean(O, rD, rayT, bmin, bmax) : intersect_aabb_exact(O, rD, rayT, bmin, bmax);
 }
 
 // Triangle::Intersect / IsOccluding (template/scene.h:190-237): true when the hit lies in

@@ -208,6 +208,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	HitRef hit;
 	hit.kind = -1, hit.inst = -1, hit.prim = 0, hit.t = 0;
 	int inst = -1;
+	bool clean = false; // the current (world or object space) ray cannot produce a NaN slab product
 
 	// next node for this lane: pop the stack; an empty stack ends the ray, the sentinel leaves the instance
 	auto pop_next = [&]() {
@@ -251,6 +252,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 							st.sp = 0, inst = -1;
 							if (!ANY && HEAD) find_nearest_head<COUNT>(S, O, D, t_min, rayT, hit, lc);
 							rD = rcp3(D);
+							clean = ray_is_clean(O, D, rD);
 							link = S.rootLink;
 							if (link == RT_EMPTY) link = RT_LINK_DONE;
 							rays++;
@@ -291,8 +293,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			if (COUNT) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
 			const float4* p = S.pairs + 4 * (size_t)lk;
 			const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-			float dist1 = intersect_aabb(O, rD, rayT, xyz(a0), xyz(a1));
-			float dist2 = intersect_aabb(O, rD, rayT, xyz(b0), xyz(b1));
+			float dist1, dist2;
+			if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
+			else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
 			uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
 			if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
 			if (dist1 == 1e30f) pop_next();
@@ -334,6 +337,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			const f3 Oo = xform_pos(I->invT, O);
 			const f3 Do = xform_vec(I->invT, D);
 			O = Oo, D = Do, rD = rcp3(Do);
+			clean = ray_is_clean(O, D, rD);
 			link = I->rootLink;
 			if (link == RT_EMPTY) link = RT_LINK_EXIT;
 			else st.push(RT_SENTINEL);
@@ -344,6 +348,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			HitRef headUnused;
 			pol.load(work, O, D, tmaxUnused, headUnused);
 			rD = rcp3(D);
+			clean = ray_is_clean(O, D, rD);
 			inst = -1;
 			pop_next();
 		}
