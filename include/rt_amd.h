@@ -146,7 +146,8 @@ int rt_set_camera(rt_ctx* ctx, const rt_camera* cam);
  * Renderer::Trace (mode RT_MODE_WHITTED, renderer.cpp:21-126; nframes must be 1) or
  * Renderer::Sample (RT_MODE_PATH, renderer.cpp:128-236), accumulated into the accumulator exactly
  * as :270 / :279-282 do.  The random stream of pixel p in frame f starts at
- * InitSeed(seed_base + p + f*width*height) (template/template.cpp:680-683).
+ * InitSeed(seed_base + p + f*width*height) (template/template.cpp:680-683; the single index whose
+ * hash is 0 starts at 0x9E3779B9 instead, because xorshift32 cannot leave state 0).
  * max_depth is the depth argument of Trace (4 at renderer.cpp:269); Sample always starts at 4.
  * RT_E_UNSUPPORTED in RT_MODE_PATH when a diffuse material has shinieness != 0 or
  * raytracer == 0 (their draws interleave with shadow queries). */

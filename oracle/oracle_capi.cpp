@@ -331,12 +331,12 @@ void orc_primary_rays(void* h, float* O, float* D)
 // ---- unit-level entry points (per-function parity vectors) -----------------------------------
 void orc_rng_stream(unsigned seedBase, int n, unsigned* outU, float* outF)
 {
-	uint s = InitSeed(seedBase);
+	uint s = StreamSeed(seedBase);
 	for (int i = 0; i < n; i++) { uint before = s; (void)before; float f = RandomFloat(s); outU[i] = s; outF[i] = f; }
 }
 void orc_hemisphere(unsigned seedBase, int n, const float* normals, float* out)
 {
-	uint s = InitSeed(seedBase);
+	uint s = StreamSeed(seedBase);
 	for (int i = 0; i < n; i++) { float3 v = RandomInHemisphere(s, f3(normals + 3 * i)); out[3 * i] = v.x, out[3 * i + 1] = v.y, out[3 * i + 2] = v.z; }
 }
 float orc_intersect_aabb(const float* O, const float* D, float t, const float* bmin, const float* bmax)

@@ -186,6 +186,11 @@ static const float TWOPI = 6.28318530717958647692528f;
 // deviation (SURVEY.md section 7 "RNG semantics").
 static inline uint WangHash(uint s) { s = (s ^ 61) ^ (s >> 16); s *= 9; s = s ^ (s >> 4); s *= 0x27d4eb2d; s = s ^ (s >> 15); return s; }
 static inline uint InitSeed(uint seedBase) { return WangHash((seedBase + 1) * 17); }
+// Start of the stream of one (pixel, frame).  WangHash is a bijection, so exactly one index maps to
+// state 0, where xorshift32 is stuck (every draw 0) and RandomVectorInUnitSphere never terminates.  A
+// single global stream can never reach 0; per-sample streams can (at 4K, frame 176 of seed base
+// 0x12345678 contains that index), so the zero state is replaced by a fixed non-zero one.
+static inline uint StreamSeed(uint index) { uint s = InitSeed(index); return s ? s : 0x9E3779B9u; }
 static inline uint RandomUInt(uint& seed) { seed ^= seed << 13; seed ^= seed >> 17; seed ^= seed << 5; return seed; }
 static inline float RandomFloat(uint& seed) { return RandomUInt(seed) * 2.3283064365387e-10f; }
 // template.cpp:709-715.  The three draws are constructor arguments in the reference, so their

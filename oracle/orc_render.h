@@ -274,7 +274,7 @@ struct Renderer {
 	{
 		const int W = camera.width, H = camera.height;
 		const size_t idx = (size_t)x + (size_t)y * W;
-		uint seed = InitSeed(seedBase + (uint)idx + frame * (uint)(W * H));
+		uint seed = StreamSeed(seedBase + (uint)idx + frame * (uint)(W * H));
 		float4& acc = accumulator[idx];
 		if (scene->raytracer) {
 			Ray pr = camera.GetPrimaryRay(x, y);

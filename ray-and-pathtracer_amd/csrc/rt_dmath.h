@@ -71,6 +71,9 @@ __device__ __forceinline__ float x_powf(float a, float b) { return (float)pow((d
 // RNG (template/template.cpp:672-724), one stream per (pixel, frame)
 __device__ __forceinline__ uint WangHash(uint s) { s = (s ^ 61) ^ (s >> 16); s *= 9; s = s ^ (s >> 4); s *= 0x27d4eb2d; s = s ^ (s >> 15); return s; }
 __device__ __forceinline__ uint InitSeed(uint seedBase) { return WangHash((seedBase + 1) * 17); }
+// start of the stream of one (pixel, frame): the one index whose hash is 0 would park xorshift32 at 0
+// (every draw 0, RandomVectorInUnitSphere never returns); it gets a fixed non-zero state instead
+__device__ __forceinline__ uint StreamSeed(uint index) { uint s = InitSeed(index); return s ? s : 0x9E3779B9u; }
 __device__ __forceinline__ uint RandomUInt(uint& seed) { seed ^= seed << 13; seed ^= seed >> 17; seed ^= seed << 5; return seed; }
 __device__ __forceinline__ float RandomFloat(uint& seed) { return RandomUInt(seed) * 2.3283064365387e-10f; }
 __device__ __forceinline__ f3 RandomVectorInUnitSphere(uint& seed)

@@ -257,13 +257,13 @@ __device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, 
 	if (R.customO) {
 		O = f3(R.customO[3 * sid], R.customO[3 * sid + 1], R.customO[3 * sid + 2]);
 		D = f3(R.customD[3 * sid], R.customD[3 * sid + 1], R.customD[3 * sid + 2]);
-		seed = InitSeed(R.seedBase + sid);
+		seed = StreamSeed(R.seedBase + sid);
 		depth = R.customDepth;
 	} else {
 		const uint lp = sid % R.tilePixels, frame = R.frame0 + sid / R.tilePixels;
 		const int x = (int)(lp % (uint)C.width), y = R.rowFirst + (int)(lp / (uint)C.width) * R.rowStride;
 		const int pixel = y * C.width + x;
-		seed = InitSeed(R.seedBase + (uint)pixel + frame * (uint)(C.width * C.height));
+		seed = StreamSeed(R.seedBase + (uint)pixel + frame * (uint)(C.width * C.height));
 		if (R.mode == 0) {
 			primary_ray(C, x, y, O, D);
 			depth = R.maxDepth;

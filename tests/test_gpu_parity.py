@@ -285,3 +285,69 @@ def test_full_size_properties(scenes, oracle_api, host_api):
     err, cls_ok = rel_err(a[rows][..., :3], ref[rows][..., :3])
     assert cls_ok and err.max() <= RADIANCE_TOL
     r.close()
+
+
+def test_limits_are_reported(scenes, oracle_api, host_api):
+    """Device-path limits surface as errors, never as silent fallbacks: > 8 lights, and rendering
+    rows outside the image."""
+    r = host_api.HostRenderer(16, 8)
+    s = r.scene
+    m = s.diffuse(0.8, (1, 1, 1))
+    s.plane(0, m, (0, 1, 0), 0)
+    for i in range(9):
+        s.area_light(11 + i, (i, 5, 0), 10.0, (1, 1, 1), 1.0, (0, -1, 0))
+    s.build(0)
+    with pytest.raises(RuntimeError, match="lights"):
+        r.commit()
+    r.close()
+    r = host_api.HostRenderer(16, 8)
+    scenes.mixed_small(r.scene)
+    r.commit()
+    with pytest.raises(RuntimeError, match="rows"):
+        r.render(host_api.RT_MODE_PATH, 0, 1, y0=4, y1=12)
+    with pytest.raises(RuntimeError):
+        r.render(host_api.RT_MODE_WHITTED, 0, 2)  # Whitted frames overwrite: one at a time
+    r.close()
+
+
+def test_deep_tree_uses_the_spill_stack(oracle_api, host_api):
+    """A degenerate LONGESTAXIS tree over geometrically spaced triangles is deeper than the 16 stack
+    entries kept in LDS: the global spill part of the traversal stack must give the same hits."""
+    n = 40
+    tris = []
+    for i in range(n):
+        x = 2.0 ** i * 1e-6
+        tris.append([x, 0, 1, x, 1, 1, x * 1.1, 0, 1])
+    tris = np.array(tris, dtype=np.float32)
+    def fill(s):
+        m = s.diffuse(0.8, (1, 1, 1))
+        s.mesh_raw(1, m, tris)
+        s.build(2)  # LONGESTAXIS: halves the extent, peeling off one triangle per level
+    o = oracle_api.OracleScene(); fill(o)
+    r = host_api.HostRenderer(8, 8); fill(r.scene); r.commit()
+    assert o.bvh_dump(-1)["max_depth"] > 20
+    rng = np.random.default_rng(0)
+    O = np.stack([rng.uniform(0, 600, 4000), rng.uniform(0, 1, 4000), np.zeros(4000)], 1).astype(np.float32)
+    O[:, 0] = np.exp(rng.uniform(np.log(1e-6), np.log(600.0), 4000)).astype(np.float32)
+    D = np.tile(np.array([[0, 0, 1]], np.float32), (4000, 1))
+    D[:, 0] = rng.uniform(-0.05, 0.05, 4000).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True).astype(np.float32)
+    ref = o.find_nearest(O, D)
+    got = r.find_nearest(O, D)
+    assert (ref["obj"] != -1).sum() > 20
+    assert np.array_equal(got["obj"], ref["obj"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert np.array_equal(r.is_occluded(O, D), o.is_occluded(O, D)["occluded"])
+    r.close()
+
+
+def test_zero_hash_stream(scenes, oracle_api, host_api):
+    """The stream index whose Wang hash is 0 (xorshift32's fixed point): same replacement state on
+    both sides, no endless rejection loop in the hemisphere sampler."""
+    o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 16, 8)
+    base = 1768515948 - 40
+    orr.scene.set_raytracer(False)
+    orr.render(0, 2, seed_base=base, nthreads=0)
+    r.render(host_api.RT_MODE_PATH, 0, 2, seed_base=base)
+    err, cls_ok = rel_err(r.accumulator()[..., :3], orr.accumulator()[..., :3])
+    assert cls_ok and err.max() <= RADIANCE_TOL
+    r.close()

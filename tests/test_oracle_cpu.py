@@ -37,7 +37,7 @@ def test_rng_against_published_algorithms(oracle_api):
         u = np.zeros(64, np.uint32)
         f = np.zeros(64, np.float32)
         L.orc_rng_stream(C.c_uint(seed), 64, u.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p))
-        s = wang(((seed + 1) * 17) & 0xFFFFFFFF)  # InitSeed (template/template.cpp:680-683)
+        s = wang(((seed + 1) * 17) & 0xFFFFFFFF) or 0x9E3779B9  # InitSeed (template/template.cpp:680-683), zero state replaced
         for i in range(64):
             s = xorshift32(s)
             assert u[i] == s
@@ -145,4 +145,17 @@ def test_whitted_image_statistics(scenes, oracle_api):
     assert np.isposinf(a).any()
     fin = a[np.isfinite(a).all(-1)]
     assert fin.min() >= 0 and 0.05 < fin.mean() < 5
+    r.close(); s.close()
+
+
+def test_zero_hash_stream_does_not_hang(scenes, oracle_api):
+    """WangHash(61) == 0, so the stream with index 1768515948 would start xorshift32 in its fixed
+    point 0 and RandomVectorInUnitSphere would spin forever; per-sample streams replace that state."""
+    assert wang(61) == 0 and ((1768515948 + 1) * 17) & 0xFFFFFFFF == 61
+    s = oracle_api.OracleScene()
+    scenes.mixed_small(s)
+    s.set_raytracer(False)
+    r = oracle_api.OracleRenderer(s, 16, 8)
+    r.render(0, 1, seed_base=1768515948 - 40)  # pixel 40 of frame 0 gets the zero-hash index
+    assert np.isfinite(r.accumulator()[..., 3]).all()
     r.close(); s.close()
