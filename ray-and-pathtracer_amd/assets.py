@@ -105,3 +105,63 @@ def lattice_tower(levels=40, sides=12, seed=3):
             strut(a[s], b[s2], 0.015)
             strut(a[s2], b[s], 0.015)
     return np.array(tris, dtype=np.float32)
+
+
+def write_hdr(path, rgb, rle=True):
+    """Write a Radiance RGBE (.hdr) file from float RGB [H, W, 3] -- the published format: header,
+    '-Y h +X w', then flat RGBE pixels or new-style run-length-encoded scanlines (per channel)."""
+    rgb = np.asarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    m = rgb.max(axis=2)
+    e = np.zeros_like(m, dtype=np.int32)
+    nz = m > 1e-32
+    mant, ex = np.frexp(m[nz])
+    scale = np.zeros_like(m)
+    scale[nz] = mant * 256.0 / m[nz]
+    e[nz] = ex + 128
+    rgbe = np.zeros((h, w, 4), dtype=np.uint8)
+    rgbe[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.clip(e, 0, 255).astype(np.uint8)
+    rgbe[~nz] = 0
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        if not rle or w < 8 or w >= 32768:
+            f.write(rgbe.tobytes())
+            return rgbe
+        for j in range(h):
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for k in range(4):
+                row = rgbe[j, :, k]
+                i = 0
+                while i < w:
+                    run = 1
+                    while i + run < w and run < 127 and row[i + run] == row[i]:
+                        run += 1
+                    if run >= 4:
+                        f.write(bytes([128 + run, int(row[i])]))
+                        i += run
+                    else:
+                        lit = i
+                        while lit < w and lit - i < 128:
+                            r2 = 1
+                            while lit + r2 < w and r2 < 4 and row[lit + r2] == row[lit]:
+                                r2 += 1
+                            if r2 >= 4:
+                                break
+                            lit += 1
+                        n = max(1, lit - i)
+                        f.write(bytes([n]) + row[i:i + n].tobytes())
+                        i += n
+    return rgbe
+
+
+def synthetic_sky_hdr(width=256, height=128, seed=7):
+    """Float lat-long sky (linear radiance, sun well above 1.0) for .hdr round trips."""
+    base = synthetic_sky(width, height, seed).astype(np.float32) / 255.0
+    lin = base ** 2.2
+    y = np.linspace(0.0, 1.0, height, dtype=np.float32)[:, None]
+    x = np.linspace(0.0, 1.0, width, dtype=np.float32)[None, :]
+    sun = np.exp(-(((x - 0.7) * 20) ** 2 + ((y - 0.25) * 24) ** 2))
+    lin += sun[..., None] * 40.0
+    lin[height - 4:, :8] = 0.0  # exact zeros (e = 0 texels)
+    return lin

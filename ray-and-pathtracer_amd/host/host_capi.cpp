@@ -106,6 +106,20 @@ int rth_set_sky(void* h, int w, int hgt, int n, const unsigned char* px)
 	sc.skydome.assign(px, px + (size_t)w * hgt * n);
 	return 0;
 }
+int rth_load_sky_hdr(void* h, const char* path)
+{
+	RthScene* s = (RthScene*)h;
+	std::string why;
+	if (!s->sc->LoadSkyHDR(path, &why)) { s->err = std::string(path) + ": " + why; return -1; }
+	return 0;
+}
+// dims[0..2] = width, height, channels; returns the 8-bit texels
+const unsigned char* rth_get_sky(void* h, int* dims)
+{
+	const Scene& sc = *((RthScene*)h)->sc;
+	dims[0] = sc.skydomeX, dims[1] = sc.skydomeY, dims[2] = sc.skydomeN;
+	return sc.skydome.data();
+}
 void rth_set_raytracer(void* h, int rt)
 {
 	Scene& sc = *((RthScene*)h)->sc;

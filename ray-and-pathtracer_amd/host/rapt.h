@@ -272,6 +272,8 @@ public:
 	void BuildBVH(int splitMethod = BINNEDSAH);
 	// instances reference meshes by index; one bvh per distinct mesh (TLASSceneTest2 shares one)
 	void BuildTLAS(const std::vector<int>& meshOfInstance, const std::vector<mat4>& transforms, int splitMethod = BINNEDSAH);
+	// skydome = stbi_load(path, &x, &y, &n, 3) for a Radiance .hdr file (template/scene.h:792)
+	bool LoadSkyHDR(const char* path, std::string* why = nullptr);
 	// flatten + upload to the device context (must be called before queries / rendering)
 	void Commit(rt_ctx* ctx);
 

@@ -4,6 +4,7 @@
 #include "rapt.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <fstream>
 #include <map>
 #include <stdexcept>
@@ -98,6 +99,90 @@ Mesh::Mesh(int idGroup, material* m, const float* v9, int n) : mat(m), groupIdx(
 		faces.push_back(f);
 		tri.push_back(Triangle(1000 * idGroup + i, m, a, b, c));
 	}
+}
+
+// ---- sky texture -------------------------------------------------------------------------------
+// The reference loads its skydome with stbi_load("...hdr", &x, &y, &n, 3) (template/scene.h:792 ...):
+// a Radiance RGBE picture decoded to float and squeezed to 8 bits per channel.  Own reader for the
+// published format (header lines, "-Y h +X w", flat or new-style run-length scanlines) followed by the
+// same float pipeline: c * 2^(e-136), then (float)pow(v, 1/2.2f) * 255 + 0.5f, clamped, truncated.
+// Pinned against the reference's vendored stb_image by tests/test_sky_hdr.py.
+static bool hdr_token(const std::string& d, size_t& pos, std::string& out)
+{
+	out.clear();
+	while (pos < d.size()) {
+		char c = d[pos++];
+		if (c == '\n') return true;
+		out.push_back(c);
+	}
+	return !out.empty();
+}
+bool Scene::LoadSkyHDR(const char* path, std::string* why)
+{
+	auto fail = [&](const char* msg) { if (why) *why = msg; return false; };
+	std::string d;
+	if (!read_file(path, d)) return fail("cannot open file");
+	size_t pos = 0;
+	std::string tok;
+	hdr_token(d, pos, tok);
+	if (tok != "#?RADIANCE" && tok != "#?RGBE") return fail("not a Radiance HDR file");
+	bool valid = false;
+	for (;;) {
+		if (!hdr_token(d, pos, tok)) return fail("truncated header");
+		if (tok.empty()) break;
+		if (tok == "FORMAT=32-bit_rle_rgbe") valid = true;
+	}
+	if (!valid) return fail("unsupported HDR format");
+	hdr_token(d, pos, tok);
+	int hgt = 0, wid = 0;
+	if (sscanf(tok.c_str(), "-Y %d +X %d", &hgt, &wid) != 2 || hgt <= 0 || wid <= 0) return fail("unsupported data layout");
+	std::vector<unsigned char> rgbe((size_t)wid * hgt * 4);
+	auto need = [&](size_t n) { return pos + n <= d.size(); };
+	const unsigned char* u = reinterpret_cast<const unsigned char*>(d.data());
+	bool flat = wid < 8 || wid >= 32768;
+	if (!flat && need(4) && !(u[pos] == 2 && u[pos + 1] == 2 && !(u[pos + 2] & 0x80))) flat = true; // old-style file: plain pixels
+	if (flat) {
+		if (!need(rgbe.size())) return fail("truncated pixel data");
+		memcpy(rgbe.data(), u + pos, rgbe.size());
+	} else {
+		for (int j = 0; j < hgt; j++) {
+			if (!need(4)) return fail("truncated scanline");
+			if (u[pos] != 2 || u[pos + 1] != 2 || (u[pos + 2] & 0x80)) return fail("mixed scanline encodings");
+			if (((u[pos + 2] << 8) | u[pos + 3]) != wid) return fail("invalid decoded scanline length");
+			pos += 4;
+			for (int k = 0; k < 4; k++) {
+				int i = 0;
+				while (i < wid) {
+					if (!need(1)) return fail("truncated run");
+					int count = u[pos++];
+					if (count > 128) {
+						count -= 128;
+						if (count > wid - i || !need(1)) return fail("bad RLE data in HDR");
+						unsigned char v = u[pos++];
+						for (int z = 0; z < count; z++) rgbe[((size_t)j * wid + i++) * 4 + k] = v;
+					} else {
+						if (count > wid - i || !need((size_t)count)) return fail("bad RLE data in HDR");
+						for (int z = 0; z < count; z++) rgbe[((size_t)j * wid + i++) * 4 + k] = u[pos++];
+					}
+				}
+			}
+		}
+	}
+	skydome.resize((size_t)wid * hgt * 3);
+	const float gamma_i = 1.0f / 2.2f, scale_i = 1.0f;
+	for (size_t px = 0; px < (size_t)wid * hgt; px++) {
+		const unsigned char* q = &rgbe[px * 4];
+		float f1 = q[3] ? (float)ldexp(1.0f, (int)q[3] - (128 + 8)) : 0.0f;
+		for (int k = 0; k < 3; k++) {
+			float lin = q[3] ? q[k] * f1 : 0.0f;
+			float z = (float)pow(lin * scale_i, gamma_i) * 255 + 0.5f;
+			if (z < 0) z = 0;
+			if (z > 255) z = 255;
+			skydome[px * 3 + k] = (unsigned char)(int)z;
+		}
+	}
+	skydomeX = wid, skydomeY = hgt, skydomeN = 3;
+	return true;
 }
 
 // ---- Scene -------------------------------------------------------------------------------------

@@ -98,7 +98,7 @@ def host_lib():
             raise RuntimeError("librapt_host.so is not built (run __graft_entry__.build())")
         L = C.CDLL(HOST_SO)
         for name in ["rth_scene_new", "rth_renderer_new", "rth_renderer_scene", "rth_renderer_ctx", "rth_describe",
-                     "rth_renderer_accumulator", "rth_renderer_pixels"]:
+                     "rth_renderer_accumulator", "rth_renderer_pixels", "rth_get_sky"]:
             getattr(L, name).restype = C.c_void_p
         L.rth_last_error.restype = C.c_char_p
         L.rth_renderer_error.restype = C.c_char_p
@@ -171,6 +171,14 @@ class HostScene:
         px = np.ascontiguousarray(pixels, dtype=np.uint8)
         hgt, w, n = px.shape
         self.L.rth_set_sky(self.h, w, hgt, n, _p(px))
+
+    def sky_hdr(self, path):
+        """Scene's stbi_load(path, ..., 3) of a Radiance .hdr file; returns the 8-bit texels [H, W, 3]."""
+        self._chk(self.L.rth_load_sky_hdr(self.h, path.encode()))
+        dims = (C.c_int * 3)()
+        p = self.L.rth_get_sky(self.h, dims)
+        buf = C.cast(p, C.POINTER(C.c_ubyte))
+        return np.ctypeslib.as_array(buf, shape=(dims[1], dims[0], dims[2])).copy()
 
     def trs(self, t, s, rx, ry, rz):
         out = np.zeros(16, dtype=np.float32)
