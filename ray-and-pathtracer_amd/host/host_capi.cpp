@@ -106,6 +106,12 @@ int rth_set_sky(void* h, int w, int hgt, int n, const unsigned char* px)
 	sc.skydome.assign(px, px + (size_t)w * hgt * n);
 	return 0;
 }
+int rth_scene_load_file(void* h, const char* path)
+{
+	RthScene* s = (RthScene*)h;
+	GUARD(s, s->sc->LoadFile(path));
+	return 0;
+}
 int rth_load_sky_hdr(void* h, const char* path)
 {
 	RthScene* s = (RthScene*)h;

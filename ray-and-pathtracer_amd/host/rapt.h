@@ -272,6 +272,9 @@ public:
 	void BuildBVH(int splitMethod = BINNEDSAH);
 	// instances reference meshes by index; one bvh per distinct mesh (TLASSceneTest2 shares one)
 	void BuildTLAS(const std::vector<int>& meshOfInstance, const std::vector<mat4>& transforms, int splitMethod = BINNEDSAH);
+	// Scene description file (host/scene_file.cpp): the data a reference scene factory hard-codes
+	// (template/scene.h:791-1209) as a text file; builds the BVH / TLAS it names.  Throws on errors.
+	void LoadFile(const std::string& path);
 	// skydome = stbi_load(path, &x, &y, &n, 3) for a Radiance .hdr file (template/scene.h:792)
 	bool LoadSkyHDR(const char* path, std::string* why = nullptr);
 	// flatten + upload to the device context (must be called before queries / rendering)

@@ -172,6 +172,10 @@ class HostScene:
         hgt, w, n = px.shape
         self.L.rth_set_sky(self.h, w, hgt, n, _p(px))
 
+    def load_file(self, path):
+        """Scene::LoadFile: build the scene a 'rapt-scene 1' description file names."""
+        self._chk(self.L.rth_scene_load_file(self.h, path.encode()))
+
     def sky_hdr(self, path):
         """Scene's stbi_load(path, ..., 3) of a Radiance .hdr file; returns the 8-bit texels [H, W, 3]."""
         self._chk(self.L.rth_load_sky_hdr(self.h, path.encode()))

@@ -118,3 +118,44 @@ def test_mat4_products_and_inverse(oracle_api, host_api):
         assert np.array_equal(ia.view(np.uint32), ib.view(np.uint32))
         assert np.allclose(A.reshape(4, 4).astype(np.float64) @ ia.reshape(4, 4).astype(np.float64), np.eye(4), atol=1e-4)
     o.close(); h.close()
+
+
+@pytest.mark.parametrize("name,kw", [("background", {}), ("mixed_small", {"split": 3}), ("scene3", {"force_diffuse": False}),
+                                     ("tlas_test2", {}), ("pretty_tlas", {"n_instances": 4}), ("tower", {})])
+def test_scene_file_round_trip(name, kw, tmp_path, scenes, host_api):
+    """A scene recorded as a 'rapt-scene 1' file and loaded with Scene::LoadFile builds the same
+    acceleration structures and flattens to the same primitives as the scene built through the API."""
+    from conftest import pkg
+    sf = pkg("scene_file")
+    path = str(tmp_path / (name + ".rapt"))
+    w = sf.SceneWriter(path)
+    d = scenes.REGISTRY[name](w, **kw)
+    a, b = host_api.HostScene(), host_api.HostScene()
+    scenes.REGISTRY[name](a, **kw)
+    b.load_file(path)
+    for blas in (range(a.blas_count()) if d["tlas"] else [-1]):
+        A, B = a.bvh_dump(blas), b.bvh_dump(blas)
+        assert np.array_equal(A["prim_idx"], B["prim_idx"])
+        assert np.array_equal(np.delete(A["nodes"], 1, axis=0), np.delete(B["nodes"], 1, axis=0))
+    if d["tlas"]:
+        assert np.array_equal(a.tlas_dump(), b.tlas_dump())
+    for m in range(2 if name in ("background", "pretty_tlas") else 1):
+        (ta, ia), (tb, ib) = a.mesh_tris(m), b.mesh_tris(m)
+        assert np.array_equal(ia, ib) and np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert b.describe()
+    a.close(); b.close()
+
+
+def test_scene_file_errors(tmp_path, host_api):
+    s = host_api.HostScene()
+    bad = tmp_path / "bad.rapt"
+    bad.write_text("rapt-scene 1\nmaterial diffuse 0.8 0.8 0.8 1 1 1 0.2 0.8 2 0 0 1\nsphere 1 3 0 0 0 1\nbuild bvh 0\n")
+    with pytest.raises(RuntimeError, match="bad.rapt:3: material index"):
+        s.load_file(str(bad))
+    bad.write_text("not a scene\n")
+    with pytest.raises(RuntimeError, match="rapt-scene 1"):
+        host_api.HostScene().load_file(str(bad))
+    bad.write_text("rapt-scene 1\nplane 0 0 0 1 0 0\n")
+    with pytest.raises(RuntimeError):
+        host_api.HostScene().load_file(str(bad))
+    s.close()
