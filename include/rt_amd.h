@@ -139,6 +139,12 @@ const char* rt_last_error(const rt_ctx* ctx);
  * RT_E_UNSUPPORTED: more than 8 lights, or a TLAS with more than 256 instances. */
 int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* desc);
 int rt_set_camera(rt_ctx* ctx, const rt_camera* cam);
+/* Scene::SetTime(t) with animation on (template/scene.h:1228-1244): every triangle of the scene BVH
+ * is deformed from its ORIGINAL (uploaded) vertices -- rotation about z by a*y*0.2, a = sin(fmod(t,
+ * 2*pi))/2 -- its normal re-derived (Triangle::update, template/scene.h:238-246) and the BVH refitted
+ * bottom-up (bvh::Refit, bvh.cpp:556-594), all on the GPU.  Non-TLAS scenes only (the reference's
+ * animOn is false under useTLAS, template/scene.h:1389).  t = 0 restores the uploaded geometry. */
+int rt_set_time(rt_ctx* ctx, float t);
 
 /* ---- the pixel loop ---------------------------------------------------------------------------- */
 /* Replaces the pixel loop of Renderer::Tick (renderer.cpp:259-285) for frames

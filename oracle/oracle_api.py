@@ -121,6 +121,9 @@ class OracleScene:
     def set_raytracer(self, rt):
         self.L.orc_set_raytracer(self.h, int(rt))
 
+    def set_time(self, t):
+        self.L.orc_set_time(self.h, C.c_float(t))
+
     # ---- dumps ----
     def mesh_tris(self, mesh):
         n = self.L.orc_mesh_count(self.h, mesh)

@@ -140,6 +140,8 @@ void orc_set_raytracer(void* h, int rt)
 	if (sc.raytracer != (rt != 0)) sc.toogleRaytracer();
 }
 
+void orc_set_time(void* h, float t) { ((OrcScene*)h)->sc.SetTime(t); }
+
 // non-TLAS scene: new bvh(this); Build(false) -- template/scene.h:700-702
 int orc_build(void* h, int splitMethod)
 {

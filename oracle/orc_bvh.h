@@ -575,6 +575,32 @@ struct tlas {
 	}
 };
 
+// Scene::SetTime (template/scene.h:1228-1244): every mesh vertex is rotated about z by an angle
+// proportional to its own height, triangles are re-derived (Mesh::update, Triangle::update) and the
+// BVH is refitted.  The deformation is a pure function of the ORIGINAL vertex, so applying it per
+// triangle corner gives the values the reference computes per shared vertex.  sinf/cosf as f64-
+// rounded-once (orc_math.h).
+inline void Scene::SetTime(float t)
+{
+	float r = fmodf(t, 2 * PI);
+	float a = x_sinf(r) * 0.5f;
+	for (auto& m : meshes) {
+		if (m.orig.size() != m.tri.size()) m.orig = m.tri;
+		for (size_t i = 0; i < m.tri.size(); i++) {
+			const Triangle& o = m.orig[i];
+			float3 v[3] = { o.v0, o.v1, o.v2 };
+			for (int k = 0; k < 3; k++) {
+				float sft = a * v[k].y * 0.2f;
+				float x = v[k].x * x_cosf(sft) - v[k].y * x_sinf(sft);
+				float y = v[k].x * x_sinf(sft) + v[k].y * x_cosf(sft);
+				v[k] = float3(x, y, v[k].z);
+			}
+			m.tri[i] = Triangle(o.objIdx, o.mat, v[0], v[1], v[2]);
+		}
+	}
+	if (b) b->Refit();
+}
+
 // Scene::FindNearest (template/scene.h:1248-1267)
 inline void Scene::FindNearest(Ray& ray, float t_min, Counters& cnt) const
 {

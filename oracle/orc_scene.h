@@ -297,6 +297,7 @@ struct Plane {
 // template/scene.h:258-340
 struct Mesh {
 	std::vector<Triangle> tri;
+	std::vector<Triangle> orig; // originalVerts of the reference (template/scene.h:337), kept per triangle
 	int groupIdx = -1;
 	int mat = -1;
 	Mesh() = default;
@@ -389,6 +390,7 @@ struct Scene {
 	// :1352-1357: flips the scene flag and the lights' flags; materials keep theirs
 	void toogleRaytracer() { raytracer = !raytracer; for (auto& l : lights) l.raytracer = raytracer; }
 
+	void SetTime(float t); // :1210-1246 (mesh wobble + bvh::Refit; the reference gates it with animOn)
 	void FindNearest(Ray& ray, float t_min, Counters& cnt) const; // :1248-1267
 	bool IsOccluded(Ray& ray, Counters& cnt) const;               // :1286-1291
 

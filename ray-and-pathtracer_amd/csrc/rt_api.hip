@@ -28,6 +28,11 @@ struct rt_ctx {
 	std::vector<void*> sceneAllocs;
 	bool pathUnsupported = false; // shiny or rt==0 diffuse present
 	std::string pathUnsupportedWhy;
+	// animation (rt_set_time): original leaf records of the scene BVH and its pair records by level
+	float4* primsOrig = nullptr;
+	float4* pairsMut = nullptr; float4* primsMut = nullptr;
+	uint* refitOrder = nullptr; int* refitLevelStart = nullptr;
+	int refitLevels = 0, animSlots = 0;
 	// camera
 	DCamera C;
 	bool cameraSet = false;
@@ -337,6 +342,34 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	HIPCHK(c, hipMemcpy(dp, prims.data(), prims.size() * 4, hipMemcpyHostToDevice));
 	S.prims = (const float4*)dp;
 	S.rootLink = d->use_tlas ? tlasRoot : rootLink[0];
+	c->pairsMut = (float4*)S.pairs, c->primsMut = (float4*)S.prims;
+	c->primsOrig = nullptr, c->refitLevels = 0, c->animSlots = 0;
+	if (!d->use_tlas && d->blas[0].n_prims > 0) {
+		// rt_set_time support: a copy of the uploaded leaf records, and the pair records of the scene
+		// BVH grouped by depth (children are deeper than their parents) for the bottom-up refit
+		const rt_blas& b = d->blas[0];
+		std::vector<uint> order;
+		std::vector<int> levelStart(1, 0);
+		std::vector<uint> level;
+		if (b.nodes[0].prim_count == 0) level.push_back(b.nodes[0].left_first / 2);
+		while (!level.empty()) {
+			std::vector<uint> next;
+			for (uint pr : level) {
+				order.push_back(pr);
+				for (int sI = 0; sI < 2; sI++) { const rt_bvh_node& nd = b.nodes[2 * pr + sI]; if (nd.prim_count == 0) next.push_back(nd.left_first / 2); }
+			}
+			levelStart.push_back((int)order.size());
+			level.swap(next);
+		}
+		c->refitLevels = (int)levelStart.size() - 1;
+		c->animSlots = (int)b.n_prims;
+		HIPCHK(c, dalloc(c->sceneAllocs, &c->primsOrig, (size_t)b.n_prims * 4));
+		HIPCHK(c, hipMemcpy(c->primsOrig, prims.data(), (size_t)b.n_prims * 64, hipMemcpyHostToDevice));
+		HIPCHK(c, dalloc(c->sceneAllocs, &c->refitOrder, order.size() + 1));
+		HIPCHK(c, hipMemcpy(c->refitOrder, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+		HIPCHK(c, dalloc(c->sceneAllocs, &c->refitLevelStart, levelStart.size()));
+		HIPCHK(c, hipMemcpy(c->refitLevelStart, levelStart.data(), levelStart.size() * 4, hipMemcpyHostToDevice));
+	}
 	S.useTLAS = d->use_tlas ? 1 : 0;
 
 	if (d->use_tlas) {
@@ -395,6 +428,22 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	}
 	c->S = S;
 	c->sceneLoaded = true;
+	return RT_OK;
+}
+
+int rt_set_time(rt_ctx* c, float t)
+{
+	if (!c) return RT_E_ARG;
+	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_set_time: no scene uploaded");
+	if (c->S.useTLAS) return fail(c, RT_E_UNSUPPORTED, "rt_set_time: the reference animates only without the TLAS (animOn, template/scene.h:1389)");
+	if (!c->primsOrig) return RT_OK; // nothing to animate
+	HIPCHK(c, hipSetDevice(c->device));
+	// float r = fmodf(t, 2 * PI); float a = sinf(r) * 0.5f;  (template/scene.h:1229-1230; sinf in f64, rounded once)
+	const float r = fmodf(t, 2 * RT_PI);
+	const float a = (float)sin((double)r) * 0.5f;
+	hipLaunchKernelGGL(k_animate, dim3((c->animSlots + 255) / 256), dim3(256), 0, c->stream, c->primsOrig, c->primsMut, c->animSlots, a);
+	if (c->refitLevels > 0) hipLaunchKernelGGL(k_refit, dim3(1), dim3(1024), 0, c->stream, c->pairsMut, c->primsMut, c->refitOrder, c->refitLevelStart, c->refitLevels);
+	HIPCHK(c, hipGetLastError());
 	return RT_OK;
 }
 

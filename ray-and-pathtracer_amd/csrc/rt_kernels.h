@@ -718,6 +718,81 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, 
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
+// ---- animation: Scene::SetTime + bvh::Refit on the device ------------------------------------------
+// k_animate: one thread per leaf slot of the scene BVH; triangles are rebuilt from their ORIGINAL
+// vertices (template/scene.h:1233-1241) and re-derived like Triangle::update (:238-246).
+__global__ void k_animate(const float4* __restrict__ orig, float4* prims, int nSlots, float a)
+{
+	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= nSlots) return;
+	const float4 r0 = orig[4 * slot], r1 = orig[4 * slot + 1], r2 = orig[4 * slot + 2], r3 = orig[4 * slot + 3];
+	if ((__float_as_int(r3.w) & 3) != RT_KIND_TRI) return;
+	f3 v[3] = { xyz(r0), xyz(r1), xyz(r2) };
+	for (int k = 0; k < 3; k++) {
+		const float sft = a * v[k].y * 0.2f;
+		const float x = v[k].x * x_cosf(sft) - v[k].y * x_sinf(sft);
+		const float y = v[k].x * x_sinf(sft) + v[k].y * x_cosf(sft);
+		v[k] = f3(x, y, v[k].z);
+	}
+	const f3 N = normalize(cross(v[1] - v[0], v[2] - v[0]));
+	const float d = -dot(N, v[0]);
+	prims[4 * slot] = mk4(v[0], N.x), prims[4 * slot + 1] = mk4(v[1], N.y), prims[4 * slot + 2] = mk4(v[2], N.z);
+	prims[4 * slot + 3] = make_float4(d, r3.y, r3.z, r3.w);
+}
+
+// bounds of one leaf: bvh::UpdateNodeBounds (bvh.cpp:67-114) over its slots, in slot order
+__device__ __forceinline__ void leaf_bounds(const float4* prims, uint first, f3& lo, f3& hi)
+{
+	lo = f3(1e30f), hi = f3(-1e30f);
+	auto fmin3 = [](const f3& a, const f3& b) { return f3(t_fminf(a.x, b.x), t_fminf(a.y, b.y), t_fminf(a.z, b.z)); };
+	auto fmax3 = [](const f3& a, const f3& b) { return f3(t_fmaxf(a.x, b.x), t_fmaxf(a.y, b.y), t_fmaxf(a.z, b.z)); };
+	for (uint slot = first;; slot++) {
+		const float4 r0 = prims[4 * slot], r1 = prims[4 * slot + 1], r2 = prims[4 * slot + 2], r3 = prims[4 * slot + 3];
+		const int kl = __float_as_int(r3.w);
+		const int kind = kl & 3;
+		if (kind == RT_KIND_TRI) {
+			lo = fmin3(lo, xyz(r0)), lo = fmin3(lo, xyz(r1)), lo = fmin3(lo, xyz(r2));
+			hi = fmax3(hi, xyz(r0)), hi = fmax3(hi, xyz(r1)), hi = fmax3(hi, xyz(r2));
+		} else if (kind == RT_KIND_SPHERE) {
+			lo = fmin3(lo, xyz(r0) - f3(r1.y)), hi = fmax3(hi, xyz(r0) + f3(r1.y));
+		} else {
+			const f3 n = normalize(xyz(r0));
+			if (n.x + n.y + n.z == 1 && (n.x == 1 || n.y == 1 || n.z == 1)) {
+				f3 slabLo(-1e30f), slabHi(1e30f);
+				if (n.x == 1) slabLo.x = 0, slabHi.x = 0; else if (n.y == 1) slabLo.y = 0, slabHi.y = 0; else slabLo.z = 0, slabHi.z = 0;
+				lo = fmin3(lo, slabLo), hi = fmax3(hi, slabHi);
+			} else { lo = f3(-1e30f), hi = f3(1e30f); return; }
+		}
+		if (kl & RT_LAST_BIT) return;
+	}
+}
+
+// k_refit: bvh::Refit (bvh.cpp:556-594).  A pair record holds the boxes of its two children, so the
+// records are processed deepest level first; 'order' lists them by level, levelStart[l] .. [l+1].
+// One workgroup walks all levels (a tree of 10^4..10^5 nodes has a few dozen), barrier between levels.
+__global__ void __launch_bounds__(1024) k_refit(float4* pairs, const float4* prims, const uint* order, const int* levelStart, int nLevels)
+{
+	for (int l = nLevels - 1; l >= 0; l--) {
+		for (int i = levelStart[l] + (int)threadIdx.x; i < levelStart[l + 1]; i += (int)blockDim.x) {
+			float4* rec = pairs + 4 * (size_t)order[i];
+			for (int s = 0; s < 2; s++) {
+				const uint lk = __float_as_uint(rec[2 * s].w);
+				f3 lo, hi;
+				if (lk & RT_LEAF_BIT) leaf_bounds(prims, lk & ~RT_LEAF_BIT, lo, hi);
+				else {
+					const float4* ch = pairs + 4 * (size_t)lk; // child pair: already refitted (deeper level)
+					lo = f3(t_fminf(ch[0].x, ch[2].x), t_fminf(ch[0].y, ch[2].y), t_fminf(ch[0].z, ch[2].z));
+					hi = f3(t_fmaxf(ch[1].x, ch[3].x), t_fmaxf(ch[1].y, ch[3].y), t_fmaxf(ch[1].z, ch[3].z));
+				}
+				rec[2 * s] = mk4(lo, rec[2 * s].w);
+				rec[2 * s + 1] = mk4(hi, 0.0f);
+			}
+		}
+		__threadfence_block();
+		__syncthreads();
+	}
+}
+
 // RGBF32_to_RGB8(accumulator / it) (renderer.cpp:287-290, template/precomp.h:445-448)
 __global__ void k_resolve(const float4* accum, int first, int n, int it, uint* out)
 {

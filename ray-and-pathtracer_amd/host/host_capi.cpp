@@ -248,6 +248,12 @@ int rth_renderer_trace(void* h, int path, const float* O, const float* D, int de
 	rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
 	return 0;
 }
+int rth_scene_set_time(void* h, float t)
+{
+	RthScene* s = (RthScene*)h;
+	GUARD(s, s->sc->SetTime(t));
+	return 0;
+}
 int rth_scene_find_nearest(void* h, const float* O, const float* D, float tmax, float t_min, float* t, int* obj, float* normal)
 {
 	RthScene* s = (RthScene*)h;

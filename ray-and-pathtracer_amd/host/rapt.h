@@ -280,6 +280,9 @@ public:
 	// flatten + upload to the device context (must be called before queries / rendering)
 	void Commit(rt_ctx* ctx);
 
+	// template/scene.h:1210: mesh wobble + bvh::Refit, executed on the device (rt_set_time); the
+	// reference runs it only when animOn (raytracer && defaultAnim && !useTLAS)
+	void SetTime(float t);
 	void FindNearest(Ray& ray, float t_min) const;   // template/scene.h:1248
 	bool IsOccluded(Ray& ray) const;                 // template/scene.h:1286
 	float3 GetSkyColor(Ray& ray) const;              // template/scene.h:1312 (host evaluation of a miss is not needed by the path; throws)

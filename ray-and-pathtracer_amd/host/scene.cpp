@@ -378,6 +378,12 @@ void Scene::Commit(rt_ctx* c)
 	check(ctx, rt_upload_scene(ctx, &Describe()));
 }
 
+void Scene::SetTime(float t)
+{
+	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");
+	check(ctx, rt_set_time(ctx, t));
+}
+
 void Scene::FindNearestBatch(int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out) const
 {
 	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");

@@ -19,7 +19,7 @@ COUNTER_NAMES = ["inner_visits", "prim_tests", "tlas_inner", "instance_visits",
                  "rays_nearest", "rays_occluded", "brute_tests", "light_tests"]
 
 # every symbol include/rt_amd.h declares
-RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera",
+RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_time",
               "rt_render", "rt_render_rows", "rt_clear", "rt_download_accumulator", "rt_resolve", "rt_accumulator_device_ptr",
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize"]
@@ -70,8 +70,9 @@ def rt_lib():
         L.rt_last_error.argtypes = [C.c_void_p]
         L.rt_accumulator_device_ptr.restype = C.c_void_p
         L.rt_accumulator_device_ptr.argtypes = [C.c_void_p]
-        for name in ["rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_clear", "rt_synchronize"]:
+        for name in ["rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_set_time", "rt_clear", "rt_synchronize"]:
             getattr(L, name).argtypes = [C.c_void_p] + ([C.c_void_p] if name in ("rt_upload_scene", "rt_set_camera") else [])
+        L.rt_set_time.argtypes = [C.c_void_p, C.c_float]
         L.rt_render.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.rt_render_rows.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]
         L.rt_get_counters_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -203,6 +204,10 @@ class HostScene:
     def raytracer(self):
         return bool(self.L.rth_get_raytracer(self.h))
 
+    def set_time(self, t):
+        """Scene::SetTime (animation + refit on the device); needs a committed scene."""
+        self._chk(self.L.rth_scene_set_time(self.h, C.c_float(t)))
+
     # ---- dumps ----
     def mesh_tris(self, mesh):
         n = self.L.rth_mesh_count(self.h, mesh)
@@ -319,6 +324,10 @@ class HostRenderer:
 
     def render_rows(self, mode, frame0, nframes, row_first, row_stride, row_count, seed_base=0x12345678, max_depth=4):
         self._rt(self.rt.rt_render_rows(self.ctx, mode, frame0, nframes, seed_base, row_first, row_stride, row_count, max_depth))
+
+    def set_time(self, t):
+        """Scene::SetTime with animation on: deform + refit on the GPU."""
+        self._rt(self.rt.rt_set_time(self.ctx, t))
 
     def clear(self):
         self._rt(self.rt.rt_clear(self.ctx))

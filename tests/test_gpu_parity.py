@@ -382,3 +382,46 @@ def test_cpp_host_example(tmp_path, scenes, oracle_api, host_api):
         assert np.abs(px.astype(np.int32) - ref_rgb).max() <= 1
         assert (px.astype(np.int32) == ref_rgb).mean() > 0.99
         orr.close()
+
+
+@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("mixed_small", {"split": 3}), ("scene3", {"force_diffuse": False}), ("tower", {})])
+def test_animation_and_refit(name, kw, scenes, oracle_api, host_api):
+    """Scene::SetTime with animation on (template/scene.h:1228-1244) + bvh::Refit (bvh.cpp:556-594),
+    both on the GPU (rt_set_time): hits, distances, normals and traversal counters still equal the
+    oracle's for the deformed, refitted scene; t = 0 restores the uploaded geometry."""
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 48, 32, **kw)
+    O, D = random_rays(4000, 11)
+    pO, pD = orr.primary_rays()
+    O, D = np.concatenate([O, pO]), np.concatenate([D, pD])
+    base = o.find_nearest(O, D)
+    for t in (0.6, 2.9, 7.5, 0.0):
+        o.set_time(t)
+        r.scene.set_time(t)
+        ref = o.find_nearest(O, D)
+        r.set_counting(True); r.counters()
+        got = r.find_nearest(O, D)
+        cnt = r.counters(); r.set_counting(False)
+        assert np.array_equal(got["obj"], ref["obj"])
+        assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+        hit = ref["obj"] != -1
+        assert np.array_equal(got["normal"][hit].view(np.uint32), ref["normal"][hit].view(np.uint32))
+        for k in ("inner_visits", "prim_tests"):
+            assert cnt[k] == ref["counters"][k], k
+        if t != 0.0:
+            assert not np.array_equal(ref["t"], base["t"])  # the geometry really moved
+        else:
+            assert np.array_equal(ref["t"].view(np.uint32), base["t"].view(np.uint32))
+        tmax = np.full(len(O), 6.0, np.float32)
+        assert np.array_equal(r.is_occluded(O, D, tmax), o.is_occluded(O, D, tmax)["occluded"])
+    o.set_time(1.3); r.scene.set_time(1.3)
+    check_frames(orr, r, "whitted", 1, host_api)
+    r.close()
+
+
+def test_set_time_refuses_tlas(scenes, oracle_api, host_api):
+    r = host_api.HostRenderer(16, 8)
+    scenes.tlas_test2(r.scene)
+    r.commit()
+    with pytest.raises(RuntimeError, match="TLAS"):
+        r.scene.set_time(1.0)
+    r.close()
