@@ -58,10 +58,18 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; this benchmark has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # RAPT_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share
+    # devices (local_rank % device_count) and the gather goes through host memory.  The driver's
+    # multi-GPU runs use the default: one GPU per rank, "nccl" (= RCCL over xGMI).
+    backend = os.environ.get("RAPT_DIST_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     ha, scenes, dpar = pkg("host_api"), pkg("scenes"), pkg("distributed")
     # one rank (re)builds stale libraries; the others wait, they would race in the same directory
@@ -77,7 +85,7 @@ def main():
     W = args.width or cfg["width"]
     H = args.height or cfg["height"]
     spp = args.spp or cfg["frames"]
-    r = ha.HostRenderer(W, H, local_rank)
+    r = ha.HostRenderer(W, H, device_index)
     scenes.REGISTRY[args.workload](r.scene)
     r.commit()
     if "camera" in cfg:
@@ -93,7 +101,13 @@ def main():
         torch.cuda.synchronize()
         r.render_rows(mode, 0, spp, row_first, row_stride, row_count)
         r.synchronize()
-        dpar.gather_rows(acc, rank, world, 0)
+        if backend == "nccl" or world == 1:
+            dpar.gather_rows(acc, rank, world, 0)
+        else:
+            host = acc.cpu()
+            dpar.gather_rows(host, rank, world, 0)
+            if rank == 0:
+                acc.copy_(host)
 
     def fence():
         if world > 1:
@@ -122,8 +136,9 @@ def main():
     prof = r.profile()
     r.set_profiling(False)
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([near["rays_nearest"], occl["rays_occluded"]], dtype=torch.float64, device="cuda")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    cnt = torch.tensor([near["rays_nearest"], occl["rays_occluded"]], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -164,6 +179,7 @@ def main():
                          "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches_per_step,
                          "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}},
         }
+        out["frame_checksum"] = "%016x" % int(torch.sum(acc.view(torch.int32).to(torch.int64)).item() & 0xFFFFFFFFFFFFFFFF)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg, W, H)
         print(json.dumps(out), flush=True)
