@@ -275,16 +275,16 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		const uint lk = link;
 		const bool wantLeaf = stepping && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
 		const bool wantExit = stepping && lk == RT_LINK_EXIT;
-		const bool wantTlas = stepping && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT);
+		const bool wantEnter = stepping && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT);
 		const bool wantPair = stepping && !(lk & (RT_LEAF_BIT | RT_INST_BIT));
 		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(wantPair));
-		const int nT = __popcll(__ballot(wantTlas)), nE = __popcll(__ballot(wantExit));
+		const int nN = __popcll(__ballot(wantEnter)), nE = __popcll(__ballot(wantExit));
 		int most = nL > nP ? nL : nP;
-		most = nT > most ? nT : most;
+		most = nN > most ? nN : most;
 		most = nE > most ? nE : most;
 		const bool runLeaf = nL > 0 && (nL >= stepMin || nL == most);
 		const bool runPair = nP > 0 && (nP >= stepMin || nP == most);
-		const bool runTlas = nT > 0 && (nT >= stepMin || nT == most);
+		const bool runEnter = nN > 0 && (nN >= stepMin || nN == most);
 		const bool runExit = nE > 0 && (nE >= stepMin || nE == most);
 
 		if (runPair && wantPair) {
@@ -327,7 +327,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				else link = lk + 1;
 			}
 		}
-		if (runTlas && wantTlas) {
+		if (runEnter && wantEnter) {
 			// TLAS leaf: bvhInstance::BIntersect / IsOccluded (bvhInstance.cpp:3-35): ray to object space
 			// with invTransform (direction not renormalised: t is shared by both spaces); the BLAS is
 			// walked above a sentinel on the same stack
