@@ -132,13 +132,20 @@ __device__ __forceinline__ bool ray_is_clean(const f3& O, const f3& D, const f3&
 	return fabsf(O.x) < 1e30f && fabsf(O.y) < 1e30f && fabsf(O.z) < 1e30f && fabsf(D.x) < inf && fabsf(D.y) < inf && fabsf(D.z) < inf &&
 	       fabsf(rD.x) < inf && fabsf(rD.y) < inf && fabsf(rD.z) < inf;
 }
+// v_min_f32 / v_max_f32 / v_min3 / v_max3 issued directly: through fminf/fmaxf hipcc puts a
+// canonicalising v_max x,x in front of every operand (12 extra VALU per box).  Operands here are
+// never NaN (clean rays), so the selection is exact.
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float intersect_aabb_clean(const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
 {
 	const float tx1 = (bmin.x - O.x) * rD.x, tx2 = (bmax.x - O.x) * rD.x;
 	const float ty1 = (bmin.y - O.y) * rD.y, ty2 = (bmax.y - O.y) * rD.y;
 	const float tz1 = (bmin.z - O.z) * rD.z, tz2 = (bmax.z - O.z) * rD.z;
-	const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
-	const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
+	const float tmin = hw_max3(hw_min(tx1, tx2), hw_min(ty1, ty2), hw_min(tz1, tz2));
+	const float tmax = hw_min3(hw_max(tx1, tx2), hw_max(ty1, ty2), hw_max(tz1, tz2));
 	if (tmax >= tmin && tmin < rayT && tmax > 0) return tmin;
 	return 1e30f;
 }
