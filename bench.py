@@ -206,7 +206,7 @@ def cpu_baseline(args, cfg, W, H):
     t0 = time.perf_counter()
     orr.render(0, 1, nthreads=cores)
     t1 = time.perf_counter() - t0
-    frames = int(max(1, min(16, args.cpu_seconds / max(t1, 1e-3))))
+    frames = int(max(1, min(64, args.cpu_seconds / max(t1, 1e-3))))
     t0 = time.perf_counter()
     orr.render(1, frames, nthreads=cores)
     dt = time.perf_counter() - t0
