@@ -188,7 +188,10 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #define RT_INST_BIT 0x40000000u // link names an instance (TLAS leaf)
 #define RT_LINK_EXIT 0xFFFFFFFCu // leave the current instance (the sentinel was popped)
 #define RT_LINK_DONE 0xFFFFFFFBu // this ray is finished; its result is written at the next refill
-#define RT_CHUNK 256 // queue entries a wave reserves per atomic on the work head
+#define RT_CHUNK 256 // queue entries a wave reserves per atomic on the work head (upper bound)
+#ifndef RT_CHUNK_DIV
+#define RT_CHUNK_DIV 8 // aim for this many reservations per wave and launch
+#endif
 
 template <bool ANY, bool COUNT, bool HEAD, class Policy>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* head, float t_min, int tuning,
@@ -196,6 +199,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 {
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
 	const int refillMin = tuning & 0xFF, stepMin = (tuning >> 8) & 0xFF;
+	// queue entries a wave reserves per atomic on the work head: RT_CHUNK for long queues (one atomic per
+	// 256 rays), down to 64 for short ones so that the last reservations are small and waves finish together
+	int chunk = n / (int)((gridDim.x * blockDim.x >> 6) * RT_CHUNK_DIV);
+	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= 64 ? 64 : (chunk & ~63));
 	const uint lane = threadIdx.x & 63;
 	const unsigned long long below = (1ull << lane) - 1;
 	Stack st = make_stack(ldsStack, spill, overflow);
@@ -234,9 +241,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				if (!exhausted) {
 					if (chunkNext >= chunkEnd) {
 						int base = 0;
-						if (lane == 0) base = atomicAdd(head, RT_CHUNK);
+						if (lane == 0) base = atomicAdd(head, chunk);
 						base = __shfl(base, 0);
-						chunkNext = base, chunkEnd = base + RT_CHUNK < n ? base + RT_CHUNK : n;
+						chunkNext = base, chunkEnd = base + chunk < n ? base + chunk : n;
 						if (base >= n) exhausted = true;
 					}
 					if (!exhausted) {

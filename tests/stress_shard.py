@@ -13,4 +13,8 @@ for n in (1, 2, 4, 8):
         r.clear(); r.synchronize()
         t = time.perf_counter(); r.render_rows(ha.RT_MODE_PATH, 0, spp, 0, n, cnt); r.synchronize(); dt = time.perf_counter() - t
     base = base or dt
+    r.set_profiling(True); r.profile()
+    r.clear(); r.render_rows(ha.RT_MODE_PATH, 0, spp, 0, n, cnt); r.synchronize()
+    pr = r.profile(); r.set_profiling(False)
+    print("   kernels:", {k: (v["launches"], round(v["ms"], 2)) for k, v in pr.items() if v["launches"]}, flush=True)
     print("N=%d rank0 share: %.2f ms  -> speedup %.2fx (ideal %d)" % (n, dt * 1e3, base / dt, n), flush=True)
