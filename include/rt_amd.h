@@ -155,8 +155,9 @@ int rt_set_time(rt_ctx* ctx, float t);
  * InitSeed(seed_base + p + f*width*height) (template/template.cpp:680-683; the single index whose
  * hash is 0 starts at 0x9E3779B9 instead, because xorshift32 cannot leave state 0).
  * max_depth is the depth argument of Trace (4 at renderer.cpp:269); Sample always starts at 4.
- * RT_E_UNSUPPORTED in RT_MODE_PATH when a diffuse material has shinieness != 0 or
- * raytracer == 0 (their draws interleave with shadow queries). */
+ * In RT_MODE_PATH a scene with a diffuse material that has shinieness != 0 or raytracer == 0 (random
+ * draws then interleave with shadow queries in depth-first order) is rendered by a slower
+ * one-lane-per-sample kernel instead of the wavefront kernels; results follow the same definition. */
 int rt_render(rt_ctx* ctx, int mode, uint32_t frame0, int nframes, uint32_t seed_base, int y0, int y1, int max_depth);
 /* Same for the rows row_first + k*row_stride, k < row_count: the row-interleaved pixel shard used
  * when the frame is split over several GPUs (rank r of n renders row_first = r, row_stride = n). */

@@ -26,7 +26,7 @@ struct rt_ctx {
 	DScene S;
 	bool sceneLoaded = false;
 	std::vector<void*> sceneAllocs;
-	bool pathUnsupported = false; // shiny or rt==0 diffuse present
+	bool pathUnsupported = false; // shiny or rt==0 diffuse present: path mode runs k_sample_general instead of the wavefront
 	std::string pathUnsupportedWhy;
 	// animation (rt_set_time): original leaf records of the scene BVH and its pair records by level
 	float4* primsOrig = nullptr;
@@ -447,6 +447,8 @@ int rt_set_time(rt_ctx* c, float t)
 	return RT_OK;
 }
 
+static int check_overflow(rt_ctx* c);
+
 // ---- path state -------------------------------------------------------------------------------
 static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 {
@@ -564,7 +566,6 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 	if (row_first < 0 || row_stride < 1 || row_count < 1 || row_first + (row_count - 1) * row_stride >= c->height)
 		return fail(c, RT_E_ARG, "rt_render: rows %d + k*%d (k < %d) outside 0..%d", row_first, row_stride, row_count, c->height);
 	if (nframes < 1 || (mode == RT_MODE_WHITTED && nframes != 1)) return fail(c, RT_E_ARG, "rt_render: nframes %d (Whitted frames overwrite the accumulator: 1 only)", nframes);
-	if (mode == RT_MODE_PATH && c->pathUnsupported) return fail(c, RT_E_UNSUPPORTED, "rt_render: path mode unsupported for this scene: %s", c->pathUnsupportedWhy.c_str());
 	HIPCHK(c, hipSetDevice(c->device));
 	const int nSlots = c->width * row_count;
 	if (mode == RT_MODE_WHITTED && max_depth <= 0) { // Trace(depth <= 0) returns black without tracing
@@ -583,12 +584,20 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		const int bf = nframes - f < batchFrames ? nframes - f : batchFrames;
 		const size_t total = tilePixels * bf;
 		const int slots = (int)(total < (size_t)slot_budget() ? total : (size_t)slot_budget());
-		rc = ensure_state(c, slots, mode == RT_MODE_WHITTED);
-		if (rc != RT_OK) return rc;
 		RenderParams R;
 		memset(&R, 0, sizeof(R));
 		R.mode = mode, R.frame0 = frame0 + (uint)f, R.nSamples = (uint)total, R.tilePixels = (uint)tilePixels, R.samples = c->samples;
 		R.seedBase = seed_base, R.rowFirst = row_first, R.rowStride = row_stride, R.maxDepth = max_depth, R.accum = c->accum;
+		if (mode == RT_MODE_PATH && c->pathUnsupported) {
+			// random draws interleave with occlusion queries (shiny / raytracer == 0 diffuse): one lane per sample
+			hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
+			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
+			rc = check_overflow(c);
+			if (rc != RT_OK) return rc;
+			continue;
+		}
+		rc = ensure_state(c, slots, mode == RT_MODE_WHITTED);
+		if (rc != RT_OK) return rc;
 		const int seg = segments_per_sample(mode, mode == RT_MODE_PATH ? 4 : max_depth, c->S.nLights);
 		const int maxRounds = (int)((total + slots - 1) / slots) * seg + seg + 4;
 		rc = run_rounds(c, R, maxRounds);
@@ -610,7 +619,6 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 {
 	if (!c || !O || !D || !rgb_out || n < 0) return fail(c, RT_E_ARG, "rt_trace_batch: bad argument");
 	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_trace_batch: no scene uploaded");
-	if (mode == RT_MODE_PATH && c->pathUnsupported) return fail(c, RT_E_UNSUPPORTED, "rt_trace_batch: path mode unsupported for this scene: %s", c->pathUnsupportedWhy.c_str());
 	if (n == 0) return RT_OK;
 	HIPCHK(c, hipSetDevice(c->device));
 	if ((mode == RT_MODE_WHITTED && depth <= 0) || (mode == RT_MODE_PATH && depth < 0)) {
@@ -633,8 +641,13 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 	memset(&R, 0, sizeof(R));
 	R.mode = mode, R.nSamples = (uint)n, R.tilePixels = (uint)n, R.seedBase = seed_base, R.maxDepth = depth, R.accum = c->accum;
 	R.customO = dO, R.customD = dD, R.customOut = dOut, R.customDepth = depth;
-	const int seg = segments_per_sample(mode, depth, c->S.nLights);
-	rc = run_rounds(c, R, ((n + slots - 1) / slots) * seg + seg + 4);
+	if (mode == RT_MODE_PATH && c->pathUnsupported) {
+		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
+		rc = check_overflow(c);
+	} else {
+		const int seg = segments_per_sample(mode, depth, c->S.nLights);
+		rc = run_rounds(c, R, ((n + slots - 1) / slots) * seg + seg + 4);
+	}
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);
 		hipError_t e = hipMemcpy(out4.data(), dOut, (size_t)16 * n, hipMemcpyDeviceToHost);

@@ -611,6 +611,131 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, Render
 	}
 }
 
+// ---- general path-mode kernel -------------------------------------------------------------------
+// Renderer::Sample (renderer.cpp:128-236) for scenes the wavefront cannot replay: a diffuse material with
+// shinieness != 0 (a recursive Sample INSIDE the light loop, :172-173) or built with raytracer == false
+// (diffuse::scatter then draws a hemisphere sample after every visible light, template/scene.h:612-614).
+// In both cases random draws interleave with occlusion queries in depth-first order, so one lane runs
+// one whole sample: recursion becomes a stack of suspended light loops, radiance is carried forward as
+// weights exactly as in the wavefront kernels.  Slow path by design (divergent, scratch-heavy).
+struct Suspended { // a DIFFUSE hit whose light loop is waiting for a shiny branch to return
+	f3 P, N, rayD, W, E;
+	int mat, nextLight, depth;
+};
+__global__ void __launch_bounds__(RT_BLOCK) k_sample_general(DScene S, DCamera C, RenderParams R, uint* spill, int* overflow)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	Stack st = make_stack(ldsStack, spill, overflow);
+	for (uint sid = blockIdx.x * blockDim.x + threadIdx.x; sid < R.nSamples; sid += gridDim.x * blockDim.x) {
+		f3 O, D;
+		uint seed;
+		int depth;
+		if (R.customO) {
+			O = f3(R.customO[3 * sid], R.customO[3 * sid + 1], R.customO[3 * sid + 2]);
+			D = f3(R.customD[3 * sid], R.customD[3 * sid + 1], R.customD[3 * sid + 2]);
+			seed = StreamSeed(R.seedBase + sid), depth = R.customDepth;
+		} else {
+			const uint lp = sid % R.tilePixels, frame = R.frame0 + sid / R.tilePixels;
+			const int x = (int)(lp % (uint)C.width), y = R.rowFirst + (int)(lp / (uint)C.width) * R.rowStride;
+			seed = StreamSeed(R.seedBase + (uint)(y * C.width + x) + frame * (uint)(C.width * C.height));
+			float newX = x + (RandomFloat(seed) * 2 - 1);
+			float newY = y + (RandomFloat(seed) * 2 - 1);
+			primary_ray(C, (int)newX, (int)newY, O, D);
+			depth = 4;
+		}
+		f3 W(1.0f), E(1.0f), Lsum(0.0f);
+		Suspended stack[6];
+		int sp = 0;
+		bool resume = false;
+		Suspended cur;
+		while (true) {
+			if (!resume) {
+				// ---- Sample(ray, depth, energy) from its first line ----
+				if (depth < 0) { Lsum = Lsum + W * f3(0.05f); }
+				else {
+					HitRef hit;
+					find_nearest_one(S, O, D, 1e34f, 0.001f, hit, st);
+					int objIdx, matId;
+					f3 normal;
+					resolve_hit(S, hit, O, D, objIdx, matId, normal);
+					const f3 I = O + hit.t * D;
+					if (objIdx == -1) Lsum = Lsum + W * sky_color(S, D);
+					else if (objIdx >= 11 && objIdx < 11 + S.nLights) Lsum = Lsum + W * light_intensity(S.lights[objIdx - 11], I, normal, I);
+					else {
+						const DMaterial m = S.mats[matId];
+						const f3 col(m.col[0], m.col[1], m.col[2]);
+						if (m.type == 2) {
+							O = I + normal * 0.001f, D = reflect(D, normal), W = W * col, depth--;
+							continue;
+						}
+						if (m.type == 3) {
+							const float kr = glass_fresnel(normalize(D), normalize(normal), m.ir);
+							const bool outside = dot(D, normal) < 0;
+							const f3 bias = 0.0001f * normal, norm = outside ? normal : -normal;
+							const float r = !outside ? m.ir : (1 / m.ir);
+							if (outside) {
+								E.x *= x_expf(m.absorption[0] * -hit.t);
+								E.y *= x_expf(m.absorption[1] * -hit.t);
+								E.z *= x_expf(m.absorption[2] * -hit.t);
+							}
+							if (kr < RandomFloat(seed)) {
+								const f3 nd = normalize(glass_refract(D, norm, r));
+								O = outside ? I - bias : I + bias, D = nd, W = W * ((col * E) * (1 - kr));
+							} else {
+								const f3 nd = normalize(reflect(D, norm));
+								O = outside ? I + bias : I - bias, D = nd, W = W * (col * kr);
+							}
+							depth--;
+							continue;
+						}
+						cur.P = I, cur.N = normal, cur.rayD = D, cur.W = W, cur.E = E, cur.mat = matId, cur.nextLight = 0, cur.depth = depth;
+						resume = true;
+						continue;
+					}
+				}
+				// this Sample returned: resume the innermost suspended light loop, or finish
+				if (sp == 0) break;
+				cur = stack[--sp];
+				resume = true;
+				continue;
+			}
+			// ---- the light loop of a DIFFUSE hit (renderer.cpp:158-176), possibly resumed ----
+			resume = false;
+			const DMaterial m = S.mats[cur.mat];
+			const f3 col(m.col[0], m.col[1], m.col[2]), albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
+			bool branched = false;
+			for (int i = cur.nextLight; i < S.nLights; i++) {
+				const f3 pickedPos = light_position(S.lights[i], false, seed);
+				f3 L = pickedPos - cur.P;
+				const float len2 = dot(L, L);
+				L = normalize(L);
+				if (is_occluded_one(S, cur.P + L * 1e-4f, L, sqrtf(len2), st)) continue;
+				const f3 att = diffuse_scatter(m, cur.rayD, L, light_intensity(S.lights[i], cur.P, cur.N, pickedPos), cur.N, cur.E);
+				if (!m.raytracer) (void)RandomInHemisphere(seed, cur.N); // diffuse::scatter's own draw (template/scene.h:612-614)
+				Lsum = Lsum + cur.W * ((((1 - m.shinieness) * col * att * cur.E) * RT_INVPI) * albedo);
+				if (m.shinieness != 0) {
+					// directLightning += shinieness * col * Sample(mirror ray, depth - 1, energy): run it now
+					// (its draws come before the next light's), keep the rest of this loop for later
+					cur.nextLight = i + 1;
+					if (sp < 6) stack[sp++] = cur; else *overflow = 2;
+					O = cur.P, D = reflect(cur.rayD, cur.N), E = cur.E, depth = cur.depth - 1;
+					W = cur.W * (((m.shinieness * col) * RT_INVPI) * albedo);
+					branched = true;
+					break;
+				}
+			}
+			if (branched) continue;
+			// indirect term: one hemisphere sample (renderer.cpp:181-186)
+			const f3 rayToHemi = RandomInHemisphere(seed, cur.N);
+			const f3 cos_i(dot(rayToHemi, cur.N));
+			O = cur.P, D = rayToHemi, E = cur.E, depth = cur.depth - 1;
+			W = cur.W * ((2 * (col * cos_i)) * albedo);
+		}
+		if (R.customOut) R.customOut[sid] = mk4(Lsum, 0.0f);
+		else R.samples[sid] = make_float4(x_powf(Lsum.x * 1, RT_GAMMA), x_powf(Lsum.y * 1, RT_GAMMA), x_powf(Lsum.z * 1, RT_GAMMA), 0.0f);
+	}
+}
+
 // accumulate: add the finished samples of a batch to the accumulator in frame order
 // (renderer.cpp:270: overwrite in Whitted mode; :282: += in path mode)
 __global__ void k_accumulate(DCamera C, RenderParams R, int batchFrames)

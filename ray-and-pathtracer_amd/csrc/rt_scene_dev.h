@@ -362,6 +362,85 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	}
 }
 
+// ---- one ray at a time (the general path-mode kernel) ----------------------------------------------
+// The same walk as trace_persistent for a single ray held by one lane: used by k_sample_general, where
+// a lane runs a whole sample and queries are interleaved with random draws.
+template <bool ANY>
+__device__ __forceinline__ bool trace_one(const DScene& S, const f3& Ow, const f3& Dw, float& rayT, HitRef& hit, Stack& st)
+{
+	const float bvh_t_min = 0.0001f;
+	f3 O = Ow, D = Dw, rD = rcp3(Dw);
+	int inst = -1;
+	uint link = S.rootLink;
+	st.sp = 0;
+	if (link == RT_EMPTY) return false;
+	while (true) {
+		bool needPop = false;
+		if (link == RT_LINK_EXIT) {
+			O = Ow, D = Dw, rD = rcp3(Dw), inst = -1;
+			needPop = true;
+		} else if (link & RT_LEAF_BIT) {
+			const uint slot = link & ~RT_LEAF_BIT;
+			const float4* rec = S.prims + 4 * (size_t)slot;
+			const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+			const int kl = __float_as_int(r3.w);
+			const int kind = kl & 3;
+			float t;
+			bool h;
+			if (kind == RT_KIND_TRI) h = tri_hit(O, D, rayT, bvh_t_min, xyz(r0), xyz(r1), xyz(r2), f3(r0.w, r1.w, r2.w), r3.x, t);
+			else if (kind == RT_KIND_SPHERE) {
+				if (ANY) h = sphere_occludes(O, D, rayT, bvh_t_min, xyz(r0), r0.w);
+				else h = sphere_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
+			} else h = plane_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
+			if (h) {
+				if (ANY) return true;
+				rayT = t, hit.prim = slot, hit.inst = inst, hit.kind = 0;
+			}
+			if (kl & RT_LAST_BIT) needPop = true;
+			else link++;
+		} else if (link & RT_INST_BIT) {
+			inst = (int)(link & ~RT_INST_BIT);
+			const DInstance* I = S.inst + inst;
+			const f3 Oo = xform_pos(I->invT, O), Do = xform_vec(I->invT, D);
+			O = Oo, D = Do, rD = rcp3(Do);
+			link = I->rootLink;
+			if (link == RT_EMPTY) link = RT_LINK_EXIT;
+			else st.push(RT_SENTINEL);
+		} else {
+			const float4* p = S.pairs + 4 * (size_t)link;
+			const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+			float dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1));
+			float dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
+			uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
+			if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
+			if (dist1 == 1e30f) needPop = true;
+			else {
+				link = c1;
+				if (dist2 != 1e30f) st.push(c2);
+			}
+		}
+		if (needPop) {
+			if (st.sp == 0) return false;
+			const uint v = st.pop();
+			link = v == RT_SENTINEL ? RT_LINK_EXIT : v;
+		}
+	}
+}
+// Scene::FindNearest / Scene::IsOccluded for one ray
+__device__ __forceinline__ void find_nearest_one(const DScene& S, const f3& O, const f3& D, float rayT, float t_min, HitRef& hit, Stack& st)
+{
+	LaneCounters unused;
+	hit.kind = -1, hit.inst = -1, hit.prim = 0;
+	find_nearest_head<false>(S, O, D, t_min, rayT, hit, unused);
+	trace_one<false>(S, O, D, rayT, hit, st);
+	hit.t = rayT;
+}
+__device__ __forceinline__ bool is_occluded_one(const DScene& S, const f3& O, const f3& D, float rayT, Stack& st)
+{
+	HitRef unused;
+	return trace_one<true>(S, O, D, rayT, unused, st);
+}
+
 // Fill the fields FindNearest leaves in the Ray: objIdx, material, hitNormal (for the sphere the
 // normal is (P - pos) * invr at the accepted t, template/scene.h:361; for an instanced triangle
 // normalize(TransformVector(N, matTransform)), bvhInstance.cpp:19).

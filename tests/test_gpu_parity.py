@@ -241,7 +241,8 @@ def test_edge_cases(scenes, oracle_api, host_api):
     # empty batches are accepted
     assert len(r.find_nearest(np.zeros((0, 3)), np.zeros((0, 3)))["t"]) == 0
     assert len(r.is_occluded(np.zeros((0, 3)), np.zeros((0, 3)))) == 0
-    # path mode refuses a shiny diffuse material (documented limit) and says why
+    # a shiny diffuse material: Whitted takes a mirror branch per visible light (pending-branch stack);
+    # path mode switches to the one-lane-per-sample kernel (see test_general_path_kernel)
     r2 = host_api.HostRenderer(16, 8)
     s2 = r2.scene
     m2 = s2.diffuse(0.8, (1, 1, 1), 0.6, 0.4, 4, shininess=0.5)
@@ -249,8 +250,6 @@ def test_edge_cases(scenes, oracle_api, host_api):
     s2.area_light(11, (0, 5, 0), 10.0, (1, 1, 1), 1.0, (0, -1, 0))
     s2.build(0)
     r2.commit()
-    with pytest.raises(RuntimeError, match="shinieness"):
-        r2.render(host_api.RT_MODE_PATH)
     r2.render(host_api.RT_MODE_WHITTED)  # Whitted handles it (mirror branch per visible light)
     o2 = oracle_api.OracleScene()
     mo2 = o2.diffuse(0.8, (1, 1, 1), 0.6, 0.4, 4, shininess=0.5)
@@ -424,4 +423,40 @@ def test_set_time_refuses_tlas(scenes, oracle_api, host_api):
     r.commit()
     with pytest.raises(RuntimeError, match="TLAS"):
         r.scene.set_time(1.0)
+    r.close()
+
+
+def _shiny_scene(b, shininess, rt):
+    """mixed_small with a shiny floor / materials built with raytracer == false: the cases where
+    Renderer::Sample's random draws interleave with occlusion queries."""
+    from conftest import pkg
+    assets = pkg("assets")
+    b.sky(assets.synthetic_sky(64, 32, seed=4))
+    b.area_light(11, (1.0, 4.0, 1.0), 10.0, (1, 1, 1), 1.0, (0, -1, 0))
+    b.area_light(12, (-1.0, 3.0, 0.5), 5.0, (1, 1, 1), 0.5, (0, -1, 0))
+    gl = b.glass(1.5, (0.6, 0.6, 1.0), (0.1, 0.2, 0.05), rt=rt)
+    me = b.metal(0.7, (0.85, 0.65, 0.12), rt=rt)
+    df = b.diffuse(0.8, (0, 1, 0), 0.6, 0.4, 10, rt=rt)
+    fl = b.diffuse(0.8, (1, 1, 1), 0.3, 0.7, 4, shininess=shininess, rt=rt)
+    b.mesh_obj(1, assets.obj_path("ico"), gl, (-0.9, 0.6, 0.6), 0.5)
+    b.mesh_obj(2, assets.obj_path("stellatedDode"), me, (0.9, 0.7, 0.8), 0.5)
+    b.mesh_obj(3, assets.obj_path("three"), df, (0.0, 0.5, 1.8), 1.2)
+    b.sphere(1, gl, (0.2, 0.35, 0.2), 0.35)
+    b.plane(0, fl, (0, 1, 0), 0)
+    b.build(0)
+    return dict(name="shiny", tlas=False)
+
+
+@pytest.mark.parametrize("shininess,rt", [(0.4, True), (0.0, False), (0.25, False)])
+def test_general_path_kernel(shininess, rt, scenes, oracle_api, host_api):
+    """Path mode with a shiny diffuse floor and/or materials built with raytracer == false: the
+    one-lane-per-sample kernel (k_sample_general) must reproduce Renderer::Sample's depth-first draw order."""
+    fn = lambda b: _shiny_scene(b, shininess, rt)
+    o, orr, r, d = make_pair(fn, oracle_api, host_api, 72, 48)
+    check_frames(orr, r, "path", 3, host_api)
+    check_frames(orr, r, "whitted", 1, host_api)
+    # Renderer::Sample on caller rays through the same kernel
+    O, D = orr.primary_rays()
+    got = r.trace_batch(host_api.RT_MODE_PATH, O[:512], D[:512], depth=4, seed_base=77)
+    assert np.isfinite(got).mean() > 0.8
     r.close()
