@@ -306,6 +306,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	// TLAS inner nodes -> pair records appended to the BLAS pairs (children boxes inside the parent's
 	// record; child A = leftRight & 0xFFFF, the one tlas::Intersect tests first)
 	uint tlasRoot = RT_EMPTY;
+	std::vector<uint> tlasSlots; // TLAS node index of every TLAS pair record, in record order
+	uint tlasSlotBase = 0;
 	if (d->use_tlas) {
 		for (uint i = 0; i < d->tlas_nodes_used; i++) {
 			const rt_tlas_node& nd = d->tlas_nodes[i];
@@ -315,7 +317,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		const uint nT = d->tlas_nodes_used;
 		std::vector<uint> slotOf(nT, 0);
 		uint next = (uint)(pairs.size() / 16);
-		for (uint i = 0; i < nT; i++) if (d->tlas_nodes[i].left_right != 0) slotOf[i] = next++;
+		tlasSlotBase = next;
+		for (uint i = 0; i < nT; i++) if (d->tlas_nodes[i].left_right != 0) slotOf[i] = next++, tlasSlots.push_back(i);
 		auto tlink = [&](uint i) -> uint { const rt_tlas_node& nd = d->tlas_nodes[i]; return nd.left_right == 0 ? (RT_INST_BIT | nd.blas) : slotOf[i]; };
 		pairs.resize((size_t)next * 16, 0.0f);
 		for (uint i = 0; i < nT; i++) {
@@ -396,6 +399,118 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		HIPCHK(c, hipMemcpy(dp, brute.data(), brute.size() * 4, hipMemcpyHostToDevice));
 		S.brute = (const float4*)dp;
 		S.nBruteSph = (int)fake.n_sph, S.nBrutePla = (int)fake.n_pla;
+
+		// reach[]: per TLAS pair, the world boxes its children's geometry can occupy (rt_scene_dev.h)
+		struct Reach { double lo[3], hi[3], a, b; };
+		const double big = 1e30, rel = 1.0 / 32768.0;
+		auto unbounded = [&]() { Reach r; for (int k = 0; k < 3; k++) r.lo[k] = -big, r.hi[k] = big; r.a = 0, r.b = 0; return r; };
+		std::vector<Reach> instReach(d->n_instances);
+		for (uint i = 0; i < d->n_instances; i++) {
+			const rt_instance& in = d->instances[i];
+			const rt_blas& b = d->blas[in.blas];
+			Reach r = unbounded();
+			instReach[i] = r;
+			// object-space box of everything a ray can hit in this BLAS: triangles and spheres; a plane is
+			// unbounded.  Triangle::Intersect rejects a triangle with N == 0 for every ray with finite D
+			// (|dot(N, D)| < t_min), and one with a NaN in N for every ray (t is NaN and fails the final
+			// range test) -- the two sentinel triangles a .tri mesh ends with (v0 = v1 = v2 = 999) are such.
+			if (b.n_prims == 0 || b.n_pla > 0) continue;
+			double lo[3] = { big, big, big }, hi[3] = { -big, -big, -big };
+			bool finite = true;
+			for (uint j = 0; j < b.n_tri; j++) {
+				const rt_triangle& t = b.tris[j];
+				if ((t.N[0] == 0 && t.N[1] == 0 && t.N[2] == 0) || t.N[0] != t.N[0] || t.N[1] != t.N[1] || t.N[2] != t.N[2]) continue;
+				for (int k = 0; k < 3; k++) {
+					lo[k] = std::min(lo[k], (double)std::min(t.v0[k], std::min(t.v1[k], t.v2[k])));
+					hi[k] = std::max(hi[k], (double)std::max(t.v0[k], std::max(t.v1[k], t.v2[k])));
+					if (!(std::fabs(t.v0[k]) < 1e29f && std::fabs(t.v1[k]) < 1e29f && std::fabs(t.v2[k]) < 1e29f)) finite = false;
+				}
+			}
+			for (uint j = 0; j < b.n_sph; j++) {
+				const rt_sphere& q = b.spheres[j];
+				const double rr = std::max(std::fabs((double)q.r), std::sqrt(std::fabs((double)q.r2))); // r and r2 are separate inputs
+				for (int k = 0; k < 3; k++) {
+					lo[k] = std::min(lo[k], (double)q.pos[k] - rr), hi[k] = std::max(hi[k], (double)q.pos[k] + rr);
+					if (!(std::fabs(q.pos[k]) < 1e29f && rr < 1e29)) finite = false;
+				}
+			}
+			if (lo[0] > hi[0]) { for (int k = 0; k < 3; k++) lo[k] = hi[k] = 0; } // nothing hittable: an empty box at the origin
+			if (!finite) continue;
+			// exact inverse of the float matrix the device applies (rows 0-2 of invTransform), in double
+			const float* m = in.inv_transform;
+			const double A[3][3] = { { m[0], m[1], m[2] }, { m[4], m[5], m[6] }, { m[8], m[9], m[10] } }, tv[3] = { m[3], m[7], m[11] };
+			const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+			                   A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+			if (!(std::fabs(det) > 1e-30) || !std::isfinite(det)) continue;
+			double Ai[3][3];
+			for (int rI = 0; rI < 3; rI++)
+				for (int cI = 0; cI < 3; cI++) {
+					const int r1 = (cI + 1) % 3, r2 = (cI + 2) % 3, c1 = (rI + 1) % 3, c2 = (rI + 2) % 3;
+					Ai[rI][cI] = (A[r1][c1] * A[r2][c2] - A[r1][c2] * A[r2][c1]) / det;
+				}
+			double nA = 0, nAi = 0, lmax = 0, wmax = 0;
+			for (int rI = 0; rI < 3; rI++) {
+				nA = std::max(nA, std::fabs(A[rI][0]) + std::fabs(A[rI][1]) + std::fabs(A[rI][2]));
+				nAi = std::max(nAi, std::fabs(Ai[rI][0]) + std::fabs(Ai[rI][1]) + std::fabs(Ai[rI][2]));
+			}
+			for (int k = 0; k < 3; k++) r.lo[k] = big, r.hi[k] = -big, lmax = std::max(lmax, std::max(std::fabs(lo[k]), std::fabs(hi[k])) + std::fabs(tv[k]));
+			for (int corner = 0; corner < 8; corner++) {
+				const double l[3] = { (corner & 1 ? hi[0] : lo[0]) - tv[0], (corner & 2 ? hi[1] : lo[1]) - tv[1], (corner & 4 ? hi[2] : lo[2]) - tv[2] };
+				for (int k = 0; k < 3; k++) {
+					const double w = Ai[k][0] * l[0] + Ai[k][1] * l[1] + Ai[k][2] * l[2];
+					r.lo[k] = std::min(r.lo[k], w), r.hi[k] = std::max(r.hi[k], w);
+				}
+			}
+			for (int k = 0; k < 3; k++) wmax = std::max(wmax, std::max(std::fabs(r.lo[k]), std::fabs(r.hi[k])));
+			const double cond = std::max(1.0, nA * nAi);
+			r.a = rel * (cond * wmax + nAi * lmax) + 1e-20, r.b = rel * cond;
+			if (!(wmax < 1e29) || !std::isfinite(r.a) || !std::isfinite(r.b) || r.a > 1e29 || r.b > 1e10) continue;
+			instReach[i] = r;
+		}
+		const uint nT = d->tlas_nodes_used;
+		std::vector<Reach> nodeReach(nT);
+		std::vector<char> state(nT, 0); // 0 unseen, 1 open, 2 done
+		std::vector<uint> walk;
+		if (nT > 0 && d->tlas_nodes[0].left_right != 0) walk.push_back(0);
+		while (!walk.empty()) {
+			const uint i = walk.back();
+			const rt_tlas_node& nd = d->tlas_nodes[i];
+			if (nd.left_right == 0) { nodeReach[i] = nd.blas < d->n_instances ? instReach[nd.blas] : unbounded(); state[i] = 2; walk.pop_back(); continue; }
+			const uint ch[2] = { nd.left_right & 0xFFFFu, nd.left_right >> 16 };
+			if (state[i] == 0) {
+				state[i] = 1;
+				for (int sI = 0; sI < 2; sI++) {
+					if (state[ch[sI]] == 1) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u is its own ancestor", ch[sI]);
+					if (state[ch[sI]] == 0) walk.push_back(ch[sI]);
+				}
+				continue;
+			}
+			Reach r = nodeReach[ch[0]];
+			const Reach& o = nodeReach[ch[1]];
+			for (int k = 0; k < 3; k++) r.lo[k] = std::min(r.lo[k], o.lo[k]), r.hi[k] = std::max(r.hi[k], o.hi[k]);
+			r.a = std::max(r.a, o.a), r.b = std::max(r.b, o.b);
+			nodeReach[i] = r, state[i] = 2;
+			walk.pop_back();
+		}
+		const uint tlasBase = (uint)tlasSlots.size() ? tlasSlotBase : 0;
+		std::vector<float> reach((size_t)tlasSlots.size() * 16 + 16, 0.0f);
+		for (size_t sI = 0; sI < tlasSlots.size(); sI++) {
+			const rt_tlas_node& nd = d->tlas_nodes[tlasSlots[sI]];
+			const uint ch[2] = { nd.left_right & 0xFFFFu, nd.left_right >> 16 };
+			for (int h = 0; h < 2; h++) {
+				const Reach& r = state[ch[h]] == 2 ? nodeReach[ch[h]] : unbounded();
+				float* rec = &reach[sI * 16 + 8 * h];
+				// round outwards: the float box must contain the double one
+				for (int k = 0; k < 3; k++) {
+					rec[k] = std::nextafterf((float)r.lo[k], -INFINITY), rec[4 + k] = std::nextafterf((float)r.hi[k], INFINITY);
+				}
+				rec[3] = std::nextafterf((float)r.a, INFINITY), rec[7] = std::nextafterf((float)r.b, INFINITY);
+			}
+		}
+		HIPCHK(c, dalloc(c->sceneAllocs, &dp, reach.size()));
+		HIPCHK(c, hipMemcpy(dp, reach.data(), reach.size() * 4, hipMemcpyHostToDevice));
+		S.reach = (const float4*)dp;
+		S.tlasBase = tlasBase;
 	}
 	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);
 	for (uint i = 0; i < d->n_lights; i++) {
