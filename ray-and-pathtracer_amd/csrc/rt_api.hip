@@ -588,9 +588,10 @@ static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 	}
 	Queues Q;
 	memset(&Q, 0, sizeof(Q));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.status, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &P.status, n + 16));
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.active, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.shadow, n));
+	HIPCHK(c, dalloc(c->stateAllocs, &Q.ended, n));
 	HIPCHK(c, dalloc(c->stateAllocs, &Q.counts, 16));
 	HIPCHK(c, hipMemset(Q.counts, 0, 16 * sizeof(int)));
 	P.nSlots = nSlots;
@@ -639,6 +640,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 		prof_end(c);
 		prof_begin(c, K_SHADE);
 		hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
+		hipLaunchKernelGGL(k_compact, dim3(grid), dim3(RT_BLOCK), 0, c->stream, P, (int)ST_ENDED, Q.ended, &Q.counts[1]);
 		hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity);
 		prof_end(c);
 		parity = 1 - parity;

@@ -73,7 +73,8 @@ struct RenderParams {
 struct Queues {
 	uint* active; // compacted ACTIVE slots (built per round by k_compact)
 	uint* shadow; // compacted SHADOW slots
-	int* counts;  // [0] active count, [2] shadow count, [3] overflow flag, [4] extend head, [6] connect head, [7] next sample in the pool
+	uint* ended;  // compacted ENDED slots (built after light)
+	int* counts;  // [0] active count, [1] ended count, [2] shadow count, [3] overflow flag, [4] extend head, [6] connect head, [7] next sample in the pool
 };
 
 // ---- camera (camera.h:24-41) ---------------------------------------------------------------
@@ -197,28 +198,66 @@ __device__ __forceinline__ void wave_range(int nSlots, int& first, int& last)
 	if (first > nSlots) first = nSlots;
 }
 
-// compact: queue <- slots of this wave's range whose status has any bit of 'mask', in slot order
-__global__ void __launch_bounds__(RT_BLOCK) k_compact(PathState P, int mask, uint* queue, int* count)
+// compact: queue <- slots whose status has the (single) bit 'bit', in slot order.  A lane reads 16
+// status bytes at a time (one dwordx4), a wave 1024 slots per iteration; wave w owns a contiguous
+// range (a multiple of 1024 slots), counts it, reserves its queue positions with one atomic, then writes.
+__device__ __forceinline__ uint4 status16(const PathState& P, int slot0, int last, uint bits)
+{
+	if (slot0 >= last) return make_uint4(0, 0, 0, 0);
+	uint4 v = *(const uint4*)(P.status + slot0);
+	v.x &= bits, v.y &= bits, v.z &= bits, v.w &= bits;
+	const int valid = last - slot0; // bytes of this vector that are slots
+	if (valid < 16) {
+		uint w[4] = { v.x, v.y, v.z, v.w };
+		for (int k = 0; k < 4; k++) {
+			const int vb = valid - 4 * k;
+			if (vb <= 0) w[k] = 0;
+			else if (vb < 4) w[k] &= (1u << (8 * vb)) - 1;
+		}
+		v = make_uint4(w[0], w[1], w[2], w[3]);
+	}
+	return v;
+}
+__global__ void __launch_bounds__(RT_BLOCK) k_compact(PathState P, int bit, uint* queue, int* count)
 {
 	const uint lane = threadIdx.x & 63;
-	int first, last;
-	wave_range(P.nSlots, first, last);
-	int total = 0;
-	for (int s0 = first; s0 < last; s0 += 64) {
-		const int slot = s0 + (int)lane;
-		const bool want = slot < last && (P.status[slot] & mask);
-		total += __popcll(__ballot(want));
+	const uint bits = (uint)bit * 0x01010101u;
+	const int waves = (gridDim.x * blockDim.x) >> 6;
+	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	int per = (P.nSlots + waves - 1) / waves;
+	per = (per + 1023) & ~1023;
+	const long long firstL = (long long)wave * per;
+	if (firstL >= P.nSlots) return;
+	const int first = (int)firstL;
+	const int last = first + per < P.nSlots ? first + per : P.nSlots;
+	int mine = 0;
+	for (int s0 = first; s0 < last; s0 += 1024) {
+		const uint4 v = status16(P, s0 + (int)lane * 16, last, bits);
+		mine += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
 	}
+	int total = mine;
+	for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
 	if (total == 0) return;
 	int base = 0;
 	if (lane == 0) base = atomicAdd(count, total);
 	base = __shfl(base, 0);
-	for (int s0 = first; s0 < last; s0 += 64) {
-		const int slot = s0 + (int)lane;
-		const bool want = slot < last && (P.status[slot] & mask);
-		const unsigned long long m = __ballot(want);
-		if (want) queue[base + __popcll(m & ((1ull << lane) - 1))] = (uint)slot;
-		base += __popcll(m);
+	for (int s0 = first; s0 < last; s0 += 1024) {
+		const int slot0 = s0 + (int)lane * 16;
+		const uint4 v = status16(P, slot0, last, bits);
+		const int c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+		int incl = c; // inclusive prefix sum over the wave
+		for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
+		uint* q = queue + base + incl - c;
+		const uint w[4] = { v.x, v.y, v.z, v.w };
+		for (int k = 0; k < 4; k++) {
+			uint x = w[k];
+			while (x) {
+				const int b = __ffs(x) - 1;
+				*q++ = (uint)(slot0 + 4 * k + (b >> 3));
+				x &= x - 1;
+			}
+		}
+		base += __shfl(incl, 63);
 	}
 }
 
@@ -304,7 +343,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DScene S, DCamera C, Rend
 // round bookkeeping between kernels: reset the work heads and the queue counts
 __global__ void k_round_begin(Queues Q)
 {
-	Q.counts[0] = 0, Q.counts[2] = 0;
+	Q.counts[0] = 0, Q.counts[1] = 0, Q.counts[2] = 0;
 	Q.counts[4] = 0, Q.counts[6] = 0;
 }
 
@@ -357,8 +396,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, 
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity)
 {
 	const int pout = 1 - parity;
-	for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < P.nSlots; slot += gridDim.x * blockDim.x) {
-		if (!(P.status[slot] & ST_ACTIVE)) continue;
+	const int nActive = Q.counts[0];
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nActive; e += gridDim.x * blockDim.x) {
+		const int slot = (int)Q.active[e]; // the slots extend just traced, in slot order
 		bool keep = false, wantShadow = false, ended = false;
 		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
@@ -508,9 +548,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Que
 // occlusion test.  Path (renderer.cpp:158-176): occlusion test first, scatter only when visible.
 __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, PathState P, Queues Q, int parity)
 {
-	for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < P.nSlots; slot += gridDim.x * blockDim.x) {
+	const int nShadow = Q.counts[2];
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nShadow; e += gridDim.x * blockDim.x) {
+		const int slot = (int)Q.shadow[e]; // the slots connect just tested, in slot order
 		const unsigned char stBits = P.status[slot];
-		if (!(stBits & ST_SHADOW)) continue;
 		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
 			const int2 id = P.hitId[slot];
@@ -557,15 +598,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, Render
 {
 	const uint lane = threadIdx.x & 63;
 	const int pout = 1 - parity;
+	const uint* queue = Q.ended; // slots with ST_ENDED, in slot order
 	int first, last;
-	wave_range(P.nSlots, first, last);
-	// pass 1: how many slots of this wave's range complete a sample (ENDED, no pending branch)
+	wave_range(Q.counts[1], first, last);
+	if (first >= last) return;
+	// pass 1: how many entries of this wave's range complete a sample (no pending branch to resume)
 	int total = 0;
-	for (int s0 = first; s0 < last; s0 += 64) {
-		const int slot = s0 + (int)lane;
-		const bool completes = slot < last && (P.status[slot] & ST_ENDED) && !(P.pendCount && P.pendCount[slot] > 0);
-		total += __popcll(__ballot(completes));
-	}
+	if (!P.pendCount) total = last - first;
+	else
+		for (int e0 = first; e0 < last; e0 += 64) {
+			const int e = e0 + (int)lane;
+			const bool completes = e < last && !(P.pendCount[queue[e]] > 0);
+			total += __popcll(__ballot(completes));
+		}
 	// one atomic per wave: the next 'total' samples of the pool
 	int base = 0;
 	if (total > 0) {
@@ -573,17 +618,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, Render
 		base = __shfl(base, 0);
 	}
 	// pass 2
-	for (int s0 = first; s0 < last; s0 += 64) {
-		const int slot = s0 + (int)lane;
-		unsigned char stBits = slot < last ? P.status[slot] : 0;
+	for (int e0 = first; e0 < last; e0 += 64) {
+		const int e = e0 + (int)lane;
+		const int slot = e < last ? (int)queue[e] : -1;
+		unsigned char stBits = slot >= 0 ? P.status[slot] : 0;
 		bool completes = false;
-		if (stBits & ST_ENDED) {
+		if (slot >= 0) {
 			stBits &= ~ST_ENDED;
 			int np = P.pendCount ? P.pendCount[slot] : 0;
 			if (np > 0) {
 				np--;
-				const float4* e = P.pend + ((size_t)slot * RT_PEND_CAP + np) * 4;
-				const float4 o = e[0], d = e[1], w = e[2], en = e[3];
+				const float4* pe = P.pend + ((size_t)slot * RT_PEND_CAP + np) * 4;
+				const float4 o = pe[0], d = pe[1], w = pe[2], en = pe[3];
 				emit_ray(S, P, pout, slot, xyz(o), xyz(d), mode_t_min(R.mode));
 				P.W[slot] = make_float4(w.x, w.y, w.z, o.w);
 				P.E[slot] = make_float4(en.x, en.y, en.z, P.E[slot].w);
@@ -607,7 +653,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, Render
 			}
 		}
 		base += __popcll(m);
-		if (slot < last) P.status[slot] = stBits;
+		if (slot >= 0) P.status[slot] = stBits;
 	}
 }
 

@@ -460,3 +460,71 @@ def test_general_path_kernel(shininess, rt, scenes, oracle_api, host_api):
     got = r.trace_batch(host_api.RT_MODE_PATH, O[:512], D[:512], depth=4, seed_base=77)
     assert np.isfinite(got).mean() > 0.8
     r.close()
+
+
+def _silhouette_rays(o, n_inst, rng, per_inst=400):
+    """Rays aimed at the vertices that DEFINE each instance's world box (and at random vertices), from
+    near and far origins, with unit and non-unit directions: the cases where a conservative box test
+    could wrongly drop an instance."""
+    Os, Ds = [], []
+    for i in range(n_inst):
+        I = o.instance_dump(i)
+        T = I["T"].reshape(4, 4).astype(np.float64)
+        tris, _ = o.mesh_tris(I["blas"])
+        ok = np.isfinite(tris[:, 9:12]).all(1)
+        v = tris[ok, :9].reshape(-1, 3).astype(np.float64)
+        w = v @ T[:3, :3].T + T[:3, 3]
+        pick = np.concatenate([w.argmin(0), w.argmax(0), rng.integers(0, len(w), per_inst - 6)])
+        tgt = w[pick]
+        dist = rng.choice([0.5, 3.0, 30.0, 1e3, 1e5], len(tgt))
+        dirs = rng.normal(size=(len(tgt), 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        org = (tgt - dirs * dist[:, None]).astype(np.float32)
+        d = tgt - org.astype(np.float64)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d *= rng.choice([1.0, 1.0, 1e-3, 37.0], len(tgt))[:, None]
+        # nudge a third of the directions by a few ulps so that they graze the vertex on either side
+        d = d.astype(np.float32)
+        nud = rng.integers(-3, 4, d.shape).astype(np.int32)
+        nud[::3] = 0
+        d = (d.view(np.int32) + nud).view(np.float32)
+        Os.append(org), Ds.append(d)
+    return np.concatenate(Os), np.concatenate(Ds)
+
+
+@pytest.mark.parametrize("name,kw", [("tlas_test2", {}), ("pretty_tlas", {"n_instances": 8}), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"})])
+def test_tlas_reach_culling_keeps_results(name, kw, scenes, oracle_api, host_api):
+    """The timed kernels (counting off) drop TLAS children whose hittable geometry the ray cannot reach
+    (csrc/rt_scene_dev.h, reach[]); hits, t, normals and occlusion must stay bit-identical to the
+    reference walk, which enters every instance whose (much larger) bounds the ray touches."""
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 64, 48, **kw)
+    rng = np.random.default_rng(77)
+    n_inst = o.n_instances
+    sO, sD = _silhouette_rays(o, n_inst, rng)
+    rO, rD = random_rays(20000, 5, center=(0.0, 1.0, 5.0), spread=8.0)
+    pO, pD = orr.primary_rays()
+    O, D = np.concatenate([sO, rO, pO]), np.concatenate([sD, rD, pD])
+    r.set_counting(False)
+    for t_min in (1e-6, 0.001):
+        ref = o.find_nearest(O, D, t_min=t_min)
+        got = r.find_nearest(O, D, t_min=t_min)
+        assert np.array_equal(got["obj"], ref["obj"])
+        assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+        hit = ref["obj"] != -1
+        assert np.array_equal(got["mat"][hit & (ref["mat"] >= 0)], ref["mat"][hit & (ref["mat"] >= 0)])
+        assert np.array_equal(got["normal"][hit].view(np.uint32), ref["normal"][hit].view(np.uint32))
+    # the silhouette rays must really hit instanced geometry often, or the test proves nothing
+    ref_s = o.find_nearest(sO, sD)
+    assert (ref_s["obj"] != -1).mean() > 0.5
+    for tmax in (None, np.full(len(O), 4.0, dtype=np.float32), rng.uniform(0.5, 2e5, len(O)).astype(np.float32)):
+        assert np.array_equal(r.is_occluded(O, D, tmax), o.is_occluded(O, D, tmax)["occluded"])
+    # counting on walks without culling: same answers, and the reference's tallies
+    r.set_counting(True)
+    r.counters()
+    got = r.find_nearest(O, D)
+    cnt = r.counters()
+    r.set_counting(False)
+    ref = o.find_nearest(O, D)
+    assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits"):
+        assert cnt[k] == ref["counters"][k], k
