@@ -624,8 +624,8 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 	prof_end(c);
 	int parity = 0;
 	for (int round = 0; round < maxRounds; round++) {
-		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, c->stream, Q);
-		hipLaunchKernelGGL(k_compact, dim3(grid), dim3(RT_BLOCK), 0, c->stream, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
+		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, c->stream, Q, P.pendCount ? 0 : 1);
+		hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, c->stream, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
 		prof_begin(c, K_EXTEND);
 		if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
 		else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
@@ -633,14 +633,14 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 		prof_begin(c, K_SHADE);
 		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
 		prof_end(c);
-		hipLaunchKernelGGL(k_compact, dim3(grid), dim3(RT_BLOCK), 0, c->stream, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
+		hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, c->stream, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
 		prof_begin(c, K_CONNECT);
 		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, (c->refillMin & ~0xFF) | c->refillAny, c->spill, c->counters + 1);
 		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, (c->refillMin & ~0xFF) | c->refillAny, c->spill, c->counters + 1);
 		prof_end(c);
 		prof_begin(c, K_SHADE);
 		hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
-		hipLaunchKernelGGL(k_compact, dim3(grid), dim3(RT_BLOCK), 0, c->stream, P, (int)ST_ENDED, Q.ended, &Q.counts[1]);
+		hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, c->stream, P, (int)ST_ENDED, Q.ended, &Q.counts[1]);
 		hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity);
 		prof_end(c);
 		parity = 1 - parity;

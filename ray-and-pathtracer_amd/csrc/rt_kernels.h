@@ -218,8 +218,11 @@ __device__ __forceinline__ uint4 status16(const PathState& P, int slot0, int las
 	}
 	return v;
 }
-__global__ void __launch_bounds__(RT_BLOCK) k_compact(PathState P, int bit, uint* queue, int* count)
+#define RT_COMPACT_BLOCK 1024
+__global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int bit, uint* queue, int* count)
 {
+	__shared__ int waveTotal[RT_COMPACT_BLOCK / 64];
+	__shared__ int blockBase;
 	const uint lane = threadIdx.x & 63;
 	const uint bits = (uint)bit * 0x01010101u;
 	const int waves = (gridDim.x * blockDim.x) >> 6;
@@ -227,9 +230,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_compact(PathState P, int bit, uint
 	int per = (P.nSlots + waves - 1) / waves;
 	per = (per + 1023) & ~1023;
 	const long long firstL = (long long)wave * per;
-	if (firstL >= P.nSlots) return;
-	const int first = (int)firstL;
-	const int last = first + per < P.nSlots ? first + per : P.nSlots;
+	const int first = firstL < P.nSlots ? (int)firstL : P.nSlots;
+	const int last = firstL + per < P.nSlots ? (int)(firstL + per) : P.nSlots;
 	int mine = 0;
 	for (int s0 = first; s0 < last; s0 += 1024) {
 		const uint4 v = status16(P, s0 + (int)lane * 16, last, bits);
@@ -237,10 +239,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_compact(PathState P, int bit, uint
 	}
 	int total = mine;
 	for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+	// one atomic per BLOCK (same-address atomics retire at ~88 per microsecond: one per wave of a
+	// 7000-wave grid was most of this kernel's time)
+	const int wib = threadIdx.x >> 6;
+	if (lane == 0) waveTotal[wib] = total;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int sum = 0;
+		for (int w = 0; w < RT_COMPACT_BLOCK / 64; w++) sum += waveTotal[w];
+		blockBase = sum > 0 ? atomicAdd(count, sum) : 0;
+	}
+	__syncthreads();
+	int base = blockBase;
+	for (int w = 0; w < wib; w++) base += waveTotal[w];
 	if (total == 0) return;
-	int base = 0;
-	if (lane == 0) base = atomicAdd(count, total);
-	base = __shfl(base, 0);
 	for (int s0 = first; s0 < last; s0 += 1024) {
 		const int slot0 = s0 + (int)lane * 16;
 		const uint4 v = status16(P, slot0, last, bits);
@@ -337,12 +349,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DScene S, DCamera C, Rend
 	if (slot >= P.nSlots) return;
 	start_sample(S, C, R, P, slot, (uint)slot, 0); // slots take the first nSlots samples of the pool
 	P.status[slot] = ST_ACTIVE;
-	if (slot == 0) Q.counts[7] = P.nSlots;
+	if (slot == 0) Q.counts[7] = P.nSlots, Q.counts[1] = 0;
 }
 
 // round bookkeeping between kernels: reset the work heads and the queue counts
-__global__ void k_round_begin(Queues Q)
+__global__ void k_round_begin(Queues Q, int poolFollowsEnded)
 {
+	if (poolFollowsEnded) Q.counts[7] += Q.counts[1]; // k_finish handed out one pool sample per ended slot
 	Q.counts[0] = 0, Q.counts[1] = 0, Q.counts[2] = 0;
 	Q.counts[4] = 0, Q.counts[6] = 0;
 }
@@ -602,20 +615,24 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, Render
 	int first, last;
 	wave_range(Q.counts[1], first, last);
 	if (first >= last) return;
-	// pass 1: how many entries of this wave's range complete a sample (no pending branch to resume)
-	int total = 0;
-	if (!P.pendCount) total = last - first;
-	else
+	int base = 0;
+	if (!P.pendCount) {
+		// every entry completes a sample: entry e takes pool sample counts[7] + e; k_round_begin advances
+		// counts[7] by the queue length afterwards (no atomics)
+		base = Q.counts[7] + first;
+	} else {
+		// pass 1: how many entries of this wave's range complete a sample (no pending branch to resume)
+		int total = 0;
 		for (int e0 = first; e0 < last; e0 += 64) {
 			const int e = e0 + (int)lane;
 			const bool completes = e < last && !(P.pendCount[queue[e]] > 0);
 			total += __popcll(__ballot(completes));
 		}
-	// one atomic per wave: the next 'total' samples of the pool
-	int base = 0;
-	if (total > 0) {
-		if (lane == 0) base = atomicAdd(&Q.counts[7], total);
-		base = __shfl(base, 0);
+		// one atomic per wave: the next 'total' samples of the pool
+		if (total > 0) {
+			if (lane == 0) base = atomicAdd(&Q.counts[7], total);
+			base = __shfl(base, 0);
+		}
 	}
 	// pass 2
 	for (int e0 = first; e0 < last; e0 += 64) {
