@@ -48,7 +48,7 @@ struct rt_ctx {
 	// traversal stack spill + flags
 	uint* spill = nullptr;
 	int gridBlocks = 0;
-	int refillMin = 24; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
+	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
 	int refillAny = 32; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
@@ -160,7 +160,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (c->refillMin > 64) c->refillMin = 64;
 	if (getenv("RT_REFILL_ANY")) c->refillAny = atoi(getenv("RT_REFILL_ANY"));
 	if (c->refillAny < 1 || c->refillAny > 64) c->refillAny = 32;
-	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 16; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
+	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 12; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
 	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->flags, 16 * sizeof(int)) == hipSuccess;
 	ok = ok && hipMemset(c->flags, 0, 16 * sizeof(int)) == hipSuccess;
@@ -660,12 +660,15 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
 
 static int slot_budget()
 {
-	// slots in flight.  Every round pays a fixed tail (waves drain unevenly once the work head runs dry)
-	// and six launches, so fewer, larger rounds win until state memory matters: 2M -> 16M slots took the
-	// 1080p x 64 spp frame from 392 to 264 ms; ~190 B of state per slot.  RT_SLOTS overrides.
+	// slots in flight.  Every round pays a fixed tail: once the work head runs dry the waves of a traversal
+	// launch drain unevenly, and the longest rays finish alone at memory latency per step (measured
+	// ~0.7 ms per traversal launch, ~1.5 ms per round, on the bench scene).  Fewer, larger rounds win until
+	// every sample of the batch has its own slot: 16M -> 64M -> 128M slots took the 1080p x 64 spp frame
+	// from 97.8 to 79.0 to 76.4 ms.  ~200 B of state per slot: 128M slots = 26 GB of the 288 GB.
+	// RT_SLOTS overrides.
 	const char* e = getenv("RT_SLOTS");
 	long v = e ? atol(e) : 0;
-	return v > 0 ? (int)v : (1 << 24);
+	return v > 0 ? (int)v : (1 << 27);
 }
 static int segments_per_sample(int mode, int depth, int nLights)
 {
