@@ -18,6 +18,7 @@ struct Timer {
 	hipEvent_t a = nullptr, b = nullptr;
 };
 
+#define RT_MAX_POOLS 4
 struct rt_ctx {
 	int device = 0, width = 0, height = 0;
 	hipStream_t stream = nullptr;
@@ -39,15 +40,25 @@ struct rt_ctx {
 	// accumulator
 	float4* accum = nullptr;
 	bool accumOwned = true;
-	// path state for the current tile size
-	PathState P;
-	Queues Q;
-	int stateSlots = 0, stateLights = -1;
-	bool statePend = false;
-	std::vector<void*> stateAllocs;
-	// traversal stack spill + flags
+	// path state: up to RT_MAX_POOLS independent sample pools, each with its own slots, queues, stream
+	// and stack spill area, so that one pool's kernels fill the machine while another's drain
+	struct Pool {
+		PathState P;
+		Queues Q;
+		int stateSlots = 0, stateLights = -1;
+		bool statePend = false;
+		std::vector<void*> allocs;
+		hipStream_t stream = nullptr; // pool 0 runs on the context's stream
+		uint* spill = nullptr;
+		hipEvent_t done = nullptr;
+	};
+	Pool pools[RT_MAX_POOLS];
+	int nPoolsWanted = 2;
+	hipEvent_t fork = nullptr;
+	// traversal stack spill of pool 0 and of the batch queries + flags
 	uint* spill = nullptr;
 	int gridBlocks = 0;
+	int gridExtend = 0, gridConnect = 0, gridQuery = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
 	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
 	int refillAny = 32; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int* flags = nullptr; // [0] overflow for batch queries
@@ -89,25 +100,26 @@ static void free_pool(std::vector<void*>& pool)
 
 // ---- profiling helpers ---------------------------------------------------------------------
 enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_CONNECT, K_QUERY };
-static void prof_begin(rt_ctx* c, int kind)
+static void prof_begin(rt_ctx* c, int kind, hipStream_t stream = nullptr)
 {
 	if (!c->profiling) return;
 	Timer t;
 	(void)hipEventCreate(&t.a);
 	(void)hipEventCreate(&t.b);
-	(void)hipEventRecord(t.a, c->stream);
+	(void)hipEventRecord(t.a, stream ? stream : c->stream);
 	c->timers.push_back(t);
 	c->timerKind.push_back(kind);
 }
-static void prof_end(rt_ctx* c)
+static void prof_end(rt_ctx* c, hipStream_t stream = nullptr)
 {
 	if (!c->profiling) return;
-	(void)hipEventRecord(c->timers.back().b, c->stream);
+	(void)hipEventRecord(c->timers.back().b, stream ? stream : c->stream);
 }
 static void prof_collect(rt_ctx* c)
 {
 	if (c->timers.empty()) return;
 	(void)hipStreamSynchronize(c->stream);
+	for (int k = 1; k < RT_MAX_POOLS; k++) if (c->pools[k].stream) (void)hipStreamSynchronize(c->pools[k].stream);
 	rt_kernel_time* slot[5] = { &c->prof.generate, &c->prof.extend, &c->prof.shade, &c->prof.connect, &c->prof.query };
 	for (size_t i = 0; i < c->timers.size(); i++) {
 		float ms = 0;
@@ -145,8 +157,10 @@ rt_ctx* rt_create(int device, int width, int height)
 	rt_ctx* c = new rt_ctx();
 	c->device = device, c->width = width, c->height = height;
 	memset(&c->S, 0, sizeof(c->S));
-	memset(&c->P, 0, sizeof(c->P));
-	memset(&c->Q, 0, sizeof(c->Q));
+	for (int k = 0; k < RT_MAX_POOLS; k++) memset(&c->pools[k].P, 0, sizeof(PathState)), memset(&c->pools[k].Q, 0, sizeof(Queues));
+	if (getenv("RT_POOLS")) c->nPoolsWanted = atoi(getenv("RT_POOLS"));
+	if (c->nPoolsWanted < 1) c->nPoolsWanted = 1;
+	if (c->nPoolsWanted > RT_MAX_POOLS) c->nPoolsWanted = RT_MAX_POOLS;
 	memset(&c->prof, 0, sizeof(c->prof));
 	memset(&c->C, 0, sizeof(c->C));
 	bool ok = hipStreamCreate(&c->stream) == hipSuccess;
@@ -155,6 +169,19 @@ rt_ctx* rt_create(int device, int width, int height)
 	// launch geometry: enough 256-lane blocks to fill 256 CUs at 8 blocks per CU; queues are drained
 	// through shared work heads, so the same grid serves every queue length
 	c->gridBlocks = prop.multiProcessorCount * 8;
+	{
+		// the traversal kernels give every wave a fixed first chunk of the queue, so their grids must be
+		// fully resident: blocks per CU from the occupancy calculator, per kernel
+		auto resident = [&](const void* fn) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, RT_BLOCK, 0) != hipSuccess || b < 1) b = 1; if (b > 8) b = 8; return b * prop.multiProcessorCount; };
+		const int e0 = resident((const void*)k_extend<false>), e1 = resident((const void*)k_extend<true>);
+		const int c0 = resident((const void*)k_connect<false>), c1 = resident((const void*)k_connect<true>);
+		c->gridExtend = e0 < e1 ? e0 : e1, c->gridConnect = c0 < c1 ? c0 : c1;
+		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
+		const void* qk[6] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true> };
+		for (int i = 0; i < 6; i++) { const int r = resident(qk[i]); if (r < q) q = r; }
+		c->gridQuery = q;
+		if (getenv("RT_DEBUG")) fprintf(stderr, "rt_create: resident blocks extend %d connect %d query %d (CUs %d)\n", c->gridExtend, c->gridConnect, c->gridQuery, prop.multiProcessorCount);
+	}
 	if (getenv("RT_REFILL")) c->refillMin = atoi(getenv("RT_REFILL"));
 	if (c->refillMin < 1) c->refillMin = 1;
 	if (c->refillMin > 64) c->refillMin = 64;
@@ -162,11 +189,13 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (c->refillAny < 1 || c->refillAny > 64) c->refillAny = 32;
 	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 12; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
 	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
-	ok = ok && hipMalloc((void**)&c->flags, 16 * sizeof(int)) == hipSuccess;
-	ok = ok && hipMemset(c->flags, 0, 16 * sizeof(int)) == hipSuccess;
+	ok = ok && hipMalloc((void**)&c->flags, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
+	ok = ok && hipMemset(c->flags, 0, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->counters, 2 * sizeof(DCounters)) == hipSuccess;
 	ok = ok && hipMemset(c->counters, 0, 2 * sizeof(DCounters)) == hipSuccess;
-	ok = ok && hipHostMalloc((void**)&c->hostCounts, 16 * sizeof(int)) == hipSuccess;
+	ok = ok && hipHostMalloc((void**)&c->hostCounts, 16 * RT_MAX_POOLS * sizeof(int)) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess;
+	c->pools[0].stream = c->stream, c->pools[0].spill = c->spill;
 	if (!ok) { fail(nullptr, RT_E_HIP, "rt_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); rt_destroy(c); return nullptr; }
 	// default camera = Camera::Camera (camera.h:10-22) for this aspect
 	const float aspect = (float)width / (float)height;
@@ -186,7 +215,14 @@ void rt_destroy(rt_ctx* c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	prof_collect(c);
 	free_pool(c->sceneAllocs);
-	free_pool(c->stateAllocs);
+	for (int k = 0; k < RT_MAX_POOLS; k++) {
+		rt_ctx::Pool& pl = c->pools[k];
+		if (k > 0 && pl.stream) { (void)hipStreamSynchronize(pl.stream); (void)hipStreamDestroy(pl.stream); }
+		if (k > 0 && pl.spill) (void)hipFree(pl.spill);
+		if (pl.done) (void)hipEventDestroy(pl.done);
+		free_pool(pl.allocs);
+	}
+	if (c->fork) (void)hipEventDestroy(c->fork);
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
 	if (c->samples) (void)hipFree(c->samples);
@@ -565,38 +601,44 @@ int rt_set_time(rt_ctx* c, float t)
 static int check_overflow(rt_ctx* c);
 
 // ---- path state -------------------------------------------------------------------------------
-static int ensure_state(rt_ctx* c, int nSlots, bool pend)
+static int ensure_state(rt_ctx* c, int k, int nSlots, bool pend)
 {
-	if (c->stateSlots >= nSlots && c->stateLights == c->S.nLights && (c->statePend || !pend)) { c->P.nSlots = nSlots; return RT_OK; }
+	rt_ctx::Pool& pl = c->pools[k];
+	if (!pl.stream) HIPCHK(c, hipStreamCreate(&pl.stream));
+	if (!pl.done) HIPCHK(c, hipEventCreateWithFlags(&pl.done, hipEventDisableTiming));
+	if (!pl.spill) HIPCHK(c, hipMalloc((void**)&pl.spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
+	if (pl.stateSlots >= nSlots && pl.stateLights == c->S.nLights && (pl.statePend || !pend)) { pl.P.nSlots = nSlots; return RT_OK; }
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	free_pool(c->stateAllocs);
-	c->stateSlots = 0;
+	HIPCHK(c, hipStreamSynchronize(pl.stream));
+	free_pool(pl.allocs);
+	pl.stateSlots = 0;
 	PathState P;
 	memset(&P, 0, sizeof(P));
 	const size_t n = (size_t)nSlots;
-	for (int b = 0; b < 2; b++) { HIPCHK(c, dalloc(c->stateAllocs, &P.O[b], n)); HIPCHK(c, dalloc(c->stateAllocs, &P.D[b], n)); }
-	HIPCHK(c, dalloc(c->stateAllocs, &P.hitN, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.hitId, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.W, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.E, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.L, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.sh, n * (size_t)(c->S.nLights + 1)));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.vis, n * (size_t)(c->S.nLights + 1)));
+	for (int b = 0; b < 2; b++) { HIPCHK(c, dalloc(pl.allocs, &P.O[b], n)); HIPCHK(c, dalloc(pl.allocs, &P.D[b], n)); }
+	HIPCHK(c, dalloc(pl.allocs, &P.hitN, n));
+	HIPCHK(c, dalloc(pl.allocs, &P.hitId, n));
+	HIPCHK(c, dalloc(pl.allocs, &P.W, n));
+	HIPCHK(c, dalloc(pl.allocs, &P.E, n));
+	HIPCHK(c, dalloc(pl.allocs, &P.L, n));
+	HIPCHK(c, dalloc(pl.allocs, &P.sh, n * (size_t)(c->S.nLights + 1)));
+	HIPCHK(c, dalloc(pl.allocs, &P.vis, n * (size_t)(c->S.nLights + 1)));
 	if (pend) {
-		HIPCHK(c, dalloc(c->stateAllocs, &P.pend, n * RT_PEND_CAP * 4));
-		HIPCHK(c, dalloc(c->stateAllocs, &P.pendCount, n));
+		HIPCHK(c, dalloc(pl.allocs, &P.pend, n * RT_PEND_CAP * 4));
+		HIPCHK(c, dalloc(pl.allocs, &P.pendCount, n));
 	}
 	Queues Q;
 	memset(&Q, 0, sizeof(Q));
-	HIPCHK(c, dalloc(c->stateAllocs, &P.status, n + 16));
-	HIPCHK(c, dalloc(c->stateAllocs, &Q.active, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &Q.shadow, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &Q.ended, n));
-	HIPCHK(c, dalloc(c->stateAllocs, &Q.counts, 16));
+	HIPCHK(c, dalloc(pl.allocs, &P.status, n + 16));
+	HIPCHK(c, dalloc(pl.allocs, &Q.active, n));
+	HIPCHK(c, dalloc(pl.allocs, &Q.shadow, n));
+	HIPCHK(c, dalloc(pl.allocs, &Q.ended, n));
+	HIPCHK(c, dalloc(pl.allocs, &Q.counts, 16));
+	HIPCHK(c, dalloc(pl.allocs, &Q.heads, (size_t)2 * RT_HEADS * RT_HEAD_STRIDE));
 	HIPCHK(c, hipMemset(Q.counts, 0, 16 * sizeof(int)));
 	P.nSlots = nSlots;
-	c->P = P, c->Q = Q;
-	c->stateSlots = nSlots, c->stateLights = c->S.nLights, c->statePend = pend;
+	pl.P = P, pl.Q = Q;
+	pl.stateSlots = nSlots, pl.stateLights = c->S.nLights, pl.statePend = pend;
 	return RT_OK;
 }
 static int ensure_samples(rt_ctx* c, size_t count)
@@ -610,51 +652,109 @@ static int ensure_samples(rt_ctx* c, size_t count)
 	return RT_OK;
 }
 
-// The round loop shared by rt_render_rows and rt_trace_batch: one pool of R.nSamples samples.
-static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds)
+static int slot_budget();
+// The round loop shared by rt_render_rows and rt_trace_batch.  The batch's samples are split over
+// nPools pools (R[k].sampleFirst / nSamples); every pool runs the same sequence of kernels on its own
+// stream, so while one pool's traversal launch drains (its longest rays finish alone, at memory latency
+// per step) or its small kernels start up, the other pools' kernels fill the machine.  The context's
+// stream waits for all pools at the end.
+static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRounds)
 {
-	PathState P = c->P;
-	if (R.mode != RT_MODE_WHITTED) P.pend = nullptr, P.pendCount = nullptr;
-	const Queues Q = c->Q;
-	const int n = P.nSlots;
-	const float t_min = R.mode == RT_MODE_WHITTED ? (float)1e-6 : 0.001f; // renderer.cpp:24, :131
+	const int mode = Rs[0].mode;
+	const float t_min = mode == RT_MODE_WHITTED ? (float)1e-6 : 0.001f; // renderer.cpp:24, :131
 	const int grid = c->gridBlocks;
-	prof_begin(c, K_GENERATE);
-	hipLaunchKernelGGL(k_generate, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q);
-	prof_end(c);
-	int parity = 0;
-	for (int round = 0; round < maxRounds; round++) {
-		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, c->stream, Q, P.pendCount ? 0 : 1);
-		hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, c->stream, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
-		prof_begin(c, K_EXTEND);
-		if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
-		else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, t_min, c->refillMin, c->spill, c->counters);
-		prof_end(c);
-		prof_begin(c, K_SHADE);
-		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
-		prof_end(c);
-		hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, c->stream, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
-		prof_begin(c, K_CONNECT);
-		if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, (c->refillMin & ~0xFF) | c->refillAny, c->spill, c->counters + 1);
-		else hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, P, Q, parity, (c->refillMin & ~0xFF) | c->refillAny, c->spill, c->counters + 1);
-		prof_end(c);
-		prof_begin(c, K_SHADE);
-		hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, R, P, Q, parity);
-		hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, c->stream, P, (int)ST_ENDED, Q.ended, &Q.counts[1]);
-		hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, P, Q, parity);
-		prof_end(c);
+	PathState P[RT_MAX_POOLS];
+	bool live[RT_MAX_POOLS];
+	// pools start after everything already queued on the context's stream
+	HIPCHK(c, hipEventRecord(c->fork, c->stream));
+	for (int k = 0; k < nPools; k++) {
+		rt_ctx::Pool& pl = c->pools[k];
+		P[k] = pl.P;
+		if (mode != RT_MODE_WHITTED) P[k].pend = nullptr, P[k].pendCount = nullptr;
+		live[k] = true;
+		if (k > 0) HIPCHK(c, hipStreamWaitEvent(pl.stream, c->fork, 0));
+		prof_begin(c, K_GENERATE, pl.stream);
+		hipLaunchKernelGGL(k_generate, dim3((P[k].nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, pl.stream, c->S, c->C, Rs[k], P[k], pl.Q);
+		prof_end(c, pl.stream);
+	}
+	int parity = 0, rc = RT_OK;
+	for (int round = 0; round < maxRounds && rc == RT_OK; round++) {
+		for (int k = 0; k < nPools; k++) {
+			if (!live[k]) continue;
+			rt_ctx::Pool& pl = c->pools[k];
+			const Queues Q = pl.Q;
+			hipStream_t st = pl.stream;
+			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, P[k].pendCount ? 0 : 1);
+			hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ACTIVE, Q.active, &Q.counts[0]);
+			prof_begin(c, K_EXTEND, st);
+			if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, c->refillMin, pl.spill, c->counters);
+			else hipLaunchKernelGGL(k_extend<false>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, c->refillMin, pl.spill, c->counters);
+			prof_end(c, st);
+			prof_begin(c, K_SHADE, st);
+			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
+			prof_end(c, st);
+			hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
+			prof_begin(c, K_CONNECT, st);
+			if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, (c->refillMin & ~0xFF) | c->refillAny, pl.spill, c->counters + 1);
+			else hipLaunchKernelGGL(k_connect<false>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, (c->refillMin & ~0xFF) | c->refillAny, pl.spill, c->counters + 1);
+			prof_end(c, st);
+			prof_begin(c, K_SHADE, st);
+			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
+			hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ENDED, Q.ended, &Q.counts[1]);
+			hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, Rs[k], P[k], Q, parity);
+			prof_end(c, st);
+		}
 		parity = 1 - parity;
-		// look at the queue length every few rounds (one small D2H copy + sync); stop when it is empty
+		// look at the queue lengths every few rounds (one small D2H copy + sync per pool); a pool stops when its queue is empty
 		if ((round & 3) == 3 || round + 1 == maxRounds) {
-			HIPCHK(c, hipMemcpyAsync(c->hostCounts, Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			if (c->hostCounts[3] == 1) return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
-			if (c->hostCounts[3] == 2) return fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
-			if (c->hostCounts[0] == 0) break;
-			if (round + 1 == maxRounds) return fail(c, RT_E_STATE, "paths still active after %d rounds", maxRounds);
+			for (int k = 0; k < nPools; k++)
+				if (live[k]) HIPCHK(c, hipMemcpyAsync(c->hostCounts + 16 * k, c->pools[k].Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->pools[k].stream));
+			bool any = false;
+			for (int k = 0; k < nPools; k++) {
+				if (!live[k]) continue;
+				HIPCHK(c, hipStreamSynchronize(c->pools[k].stream));
+				const int* hc = c->hostCounts + 16 * k;
+				if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+				else if (hc[3] == 2) rc = fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
+				if (hc[3] != 0) (void)hipMemsetAsync(c->pools[k].Q.counts + 3, 0, sizeof(int), c->pools[k].stream);
+				if (hc[0] == 0) live[k] = false;
+				any = any || live[k];
+			}
+			if (rc != RT_OK || !any) break;
+			if (round + 1 == maxRounds) rc = fail(c, RT_E_STATE, "paths still active after %d rounds", maxRounds);
 		}
 	}
+	// join: the context's stream continues after every pool
+	for (int k = 1; k < nPools; k++) {
+		(void)hipEventRecord(c->pools[k].done, c->pools[k].stream);
+		(void)hipStreamWaitEvent(c->stream, c->pools[k].done, 0);
+	}
+	if (rc != RT_OK) {
+		for (int k = 1; k < nPools; k++) (void)hipStreamSynchronize(c->pools[k].stream);
+		return rc;
+	}
 	HIPCHK(c, hipGetLastError());
+	return RT_OK;
+}
+
+// Split 'total' samples over the pools and size their slots.
+static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& base, RenderParams* Rs, int& nPools, int& maxSlots)
+{
+	nPools = total >= ((size_t)1 << 20) ? c->nPoolsWanted : 1; // small batches: one pool
+	const size_t per = (total + nPools - 1) / nPools;
+	maxSlots = 0;
+	size_t first = 0;
+	for (int k = 0; k < nPools; k++) {
+		const size_t cnt = first + per <= total ? per : total - first;
+		const size_t budget = (size_t)slot_budget() / nPools;
+		const int slots = (int)(cnt < budget ? cnt : budget);
+		int rc = ensure_state(c, k, slots > 0 ? slots : 1, pend);
+		if (rc != RT_OK) return rc;
+		Rs[k] = base;
+		Rs[k].sampleFirst = (uint)first, Rs[k].nSamples = (uint)cnt;
+		if (slots > maxSlots) maxSlots = slots;
+		first += cnt;
+	}
 	return RT_OK;
 }
 
@@ -703,7 +803,6 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 	for (int f = 0; f < nframes; f += batchFrames) {
 		const int bf = nframes - f < batchFrames ? nframes - f : batchFrames;
 		const size_t total = tilePixels * bf;
-		const int slots = (int)(total < (size_t)slot_budget() ? total : (size_t)slot_budget());
 		RenderParams R;
 		memset(&R, 0, sizeof(R));
 		R.mode = mode, R.frame0 = frame0 + (uint)f, R.nSamples = (uint)total, R.tilePixels = (uint)tilePixels, R.samples = c->samples;
@@ -716,11 +815,13 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 			if (rc != RT_OK) return rc;
 			continue;
 		}
-		rc = ensure_state(c, slots, mode == RT_MODE_WHITTED);
+		RenderParams Rs[RT_MAX_POOLS];
+		int nPools = 1, slots = 1;
+		rc = setup_pools(c, total, mode == RT_MODE_WHITTED, R, Rs, nPools, slots);
 		if (rc != RT_OK) return rc;
 		const int seg = segments_per_sample(mode, mode == RT_MODE_PATH ? 4 : max_depth, c->S.nLights);
-		const int maxRounds = (int)((total + slots - 1) / slots) * seg + seg + 4;
-		rc = run_rounds(c, R, maxRounds);
+		const int maxRounds = (int)((total / nPools + slots) / slots) * seg + seg + 4;
+		rc = run_rounds(c, Rs, nPools, maxRounds);
 		if (rc != RT_OK) return rc;
 		hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 	}
@@ -746,9 +847,7 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 		for (int i = 0; i < 3 * n; i++) rgb_out[i] = v;
 		return RT_OK;
 	}
-	const int slots = n < slot_budget() ? n : slot_budget();
-	int rc = ensure_state(c, slots, mode == RT_MODE_WHITTED);
-	if (rc != RT_OK) return rc;
+	int rc = RT_OK;
 	float *dO = nullptr, *dD = nullptr;
 	float4* dOut = nullptr;
 	std::vector<void*> tmp;
@@ -765,8 +864,11 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
 		rc = check_overflow(c);
 	} else {
+		RenderParams Rs[RT_MAX_POOLS];
+		int nPools = 1, slots = 1;
+		rc = setup_pools(c, (size_t)n, mode == RT_MODE_WHITTED, R, Rs, nPools, slots);
 		const int seg = segments_per_sample(mode, depth, c->S.nLights);
-		rc = run_rounds(c, R, ((n + slots - 1) / slots) * seg + seg + 4);
+		if (rc == RT_OK) rc = run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4);
 	}
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);
@@ -830,7 +932,7 @@ static int check_overflow(rt_ctx* c)
 	if (f) { (void)hipMemset(c->flags, 0, 2 * sizeof(int)); return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX); }
 	return RT_OK;
 }
-static int query_grid(rt_ctx* c, int n) { int g = (n + RT_CHUNK - 1) / RT_CHUNK / 4 + 1; return g > c->gridBlocks ? c->gridBlocks : g; }
+static int query_grid(rt_ctx* c, int n) { int g = (n + RT_CHUNK - 1) / RT_CHUNK / 4 + 1; return g > c->gridQuery ? c->gridQuery : g; }
 
 int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out)
 {
@@ -850,7 +952,7 @@ int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const f
 	if (e == hipSuccess) e = hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
-		(void)hipMemsetAsync(c->flags, 0, sizeof(int), c->stream); // queue head
+		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
 		if (c->counting) hipLaunchKernelGGL(k_query_nearest<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, c->refillMin, dH, c->spill, c->flags, c->counters);
 		else hipLaunchKernelGGL(k_query_nearest<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, c->refillMin, dH, c->spill, c->flags, c->counters);
@@ -883,7 +985,7 @@ int rt_occluded_batch(rt_ctx* c, int n, const float* O, const float* D, const fl
 	if (e == hipSuccess) e = hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
-		(void)hipMemsetAsync(c->flags, 0, sizeof(int), c->stream); // queue head
+		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
 		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, c->refillMin, dR, c->spill, c->flags, c->counters + 1);
 		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, c->refillMin, dR, c->spill, c->flags, c->counters + 1);
@@ -910,7 +1012,7 @@ int rt_primary_hits(rt_ctx* c, float t_min, int32_t* obj_out, float* t_out)
 	hipError_t e = dalloc(tmp, &dO, (size_t)n);
 	if (e == hipSuccess) e = dalloc(tmp, &dT, (size_t)n);
 	if (e == hipSuccess) {
-		(void)hipMemsetAsync(c->flags, 0, sizeof(int), c->stream); // queue head
+		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
 		if (c->counting) hipLaunchKernelGGL(k_primary_hits<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, c->refillMin, dO, dT, c->spill, c->flags, c->counters);
 		else hipLaunchKernelGGL(k_primary_hits<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, c->refillMin, dO, dT, c->spill, c->flags, c->counters);

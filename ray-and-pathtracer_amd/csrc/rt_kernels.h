@@ -54,7 +54,8 @@ struct PathState {
 struct RenderParams {
 	int mode;          // RT_MODE_WHITTED / RT_MODE_PATH
 	uint frame0;       // first frame of this batch
-	uint nSamples;     // pool size = batch frames * tile pixels
+	uint nSamples;     // samples of this pool
+	uint sampleFirst;  // id of the pool's first sample within the batch (batch = frames * tile pixels, frame-major)
 	uint tilePixels;   // pixels in the tile (rows of this shard * width)
 	float4* samples;   // [batch frame][tile pixel] finished samples (gamma applied in path mode)
 	uint seedBase;
@@ -74,6 +75,7 @@ struct Queues {
 	uint* active; // compacted ACTIVE slots (built per round by k_compact)
 	uint* shadow; // compacted SHADOW slots
 	uint* ended;  // compacted ENDED slots (built after light)
+	int* heads;   // work heads of extend ([0, RT_HEADS)) and connect ([RT_HEADS, 2 RT_HEADS)), RT_HEAD_STRIDE ints apart
 	int* counts;  // [0] active count, [1] ended count, [2] shadow count, [3] overflow flag, [4] extend head, [6] connect head, [7] next sample in the pool
 };
 
@@ -347,7 +349,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DScene S, DCamera C, Rend
 {
 	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= P.nSlots) return;
-	start_sample(S, C, R, P, slot, (uint)slot, 0); // slots take the first nSlots samples of the pool
+	start_sample(S, C, R, P, slot, R.sampleFirst + (uint)slot, 0); // slots take the first nSlots samples of the pool
 	P.status[slot] = ST_ACTIVE;
 	if (slot == 0) Q.counts[7] = P.nSlots, Q.counts[1] = 0;
 }
@@ -357,7 +359,7 @@ __global__ void k_round_begin(Queues Q, int poolFollowsEnded)
 {
 	if (poolFollowsEnded) Q.counts[7] += Q.counts[1]; // k_finish handed out one pool sample per ended slot
 	Q.counts[0] = 0, Q.counts[1] = 0, Q.counts[2] = 0;
-	Q.counts[4] = 0, Q.counts[6] = 0;
+	for (int h = 0; h < 2 * RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
 }
 
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, 
 	lc.clear();
 	uint rays = 0;
 	ExtendPolicy pol{ S, P, Q.active, parity };
-	trace_persistent<false, COUNT, false>(S, pol, Q.counts[0], &Q.counts[4], t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	trace_persistent<false, COUNT, false>(S, pol, Q.counts[0], Q.heads, t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) {
 		// the head tests ran where the rays were created: per ray, every light and every brute-force primitive
 		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Que
 	lc.clear();
 	uint rays = 0;
 	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights };
-	trace_persistent<true, COUNT, false>(S, pol, Q.counts[2] * S.nLights, &Q.counts[6], 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	trace_persistent<true, COUNT, false>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -665,7 +667,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, Render
 		if (completes) {
 			const uint sidNext = (uint)(base + __popcll(m & ((1ull << lane) - 1)));
 			if (sidNext < R.nSamples) {
-				start_sample(S, C, R, P, slot, sidNext, pout);
+				start_sample(S, C, R, P, slot, R.sampleFirst + sidNext, pout);
 				stBits |= ST_ACTIVE;
 			}
 		}
@@ -877,7 +879,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, con
 	lc.clear();
 	uint rays = 0;
 	NearestQueryPolicy pol(S, O3, D3, tmax, out);
-	trace_persistent<false, COUNT, true>(S, pol, n, &work[0], t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, COUNT, true>(S, pol, n, work + 16, t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
@@ -890,7 +892,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, co
 	lc.clear();
 	uint rays = 0;
 	OccludedQueryPolicy pol(O3, D3, tmax, out);
-	trace_persistent<true, COUNT, false>(S, pol, n, &work[0], 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<true, COUNT, false>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -902,7 +904,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, 
 	lc.clear();
 	uint rays = 0;
 	PrimaryPolicy pol{ S, C, objOut, tOut };
-	trace_persistent<false, COUNT, true>(S, pol, C.width * C.height, &work[0], t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, COUNT, true>(S, pol, C.width * C.height, work + 16, t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 

@@ -202,27 +202,37 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #define RT_INST_BIT 0x40000000u // link names an instance (TLAS leaf)
 #define RT_LINK_EXIT 0xFFFFFFFCu // leave the current instance (the sentinel was popped)
 #define RT_LINK_DONE 0xFFFFFFFBu // this ray is finished; its result is written at the next refill
-#define RT_CHUNK 256 // queue entries a wave reserves per atomic on the work head (upper bound)
-#ifndef RT_CHUNK_DIV
-#define RT_CHUNK_DIV 8 // aim for this many reservations per wave and launch
-#endif
-
+#define RT_CHUNK 256 // queue entries a wave reserves per atomic on a work head (upper bound)
+// Work distribution.  Same-address atomics retire at ~88 per microsecond on this part, so ONE work head
+// shared by 7000 waves is a real cost: a wave waits in line for every reservation, and large chunks (the
+// obvious cure) leave a long tail, because the wave that takes the last 256 rays works on them for
+// ~0.6 ms while the rest of the machine idles.  So the queue is cut into RT_HEADS sub-queues with a head
+// each (4 KB apart: separate L2 channels); a wave reserves from its home sub-queue, sizes the
+// reservation by what is left there (256 entries early on, 64 near the end), and moves on to the other
+// sub-queues when its own is empty.
+#define RT_HEADS 16
+#define RT_HEAD_STRIDE 1024 // ints between two heads
 template <bool ANY, bool COUNT, bool HEAD, class Policy>
-__device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* head, float t_min, int tuning,
+__device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
 	const int refillMin = tuning & 0xFF, stepMin = (tuning >> 8) & 0xFF;
-	// queue entries a wave reserves per atomic on the work head: RT_CHUNK for long queues (one atomic per
-	// 256 rays), down to 64 for short ones so that the last reservations are small and waves finish together
-	int chunk = n / (int)((gridDim.x * blockDim.x >> 6) * RT_CHUNK_DIV);
-	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= 64 ? 64 : (chunk & ~63));
 	const uint lane = threadIdx.x & 63;
 	const unsigned long long below = (1ull << lane) - 1;
+	// sub-queue h = [h * subLen, (h + 1) * subLen) cut at n; all of this is wave-uniform (SGPRs)
+	const int waveId = (int)(blockIdx.x * (blockDim.x >> 6)) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int subLen = ((n + RT_HEADS - 1) / RT_HEADS + 63) & ~63;
+	int wavesPerHead = (int)((gridDim.x * blockDim.x) >> 6) / RT_HEADS;
+	if (wavesPerHead < 1) wavesPerHead = 1;
+	int home = waveId % RT_HEADS;   // sub-queue this wave is drawing from
+	int tried = 0;                  // sub-queues found empty since the last successful reservation
+	int chunk = subLen / (wavesPerHead * 2); // size of the next reservation
+	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= 64 ? 64 : (chunk & ~63));
 	Stack st = make_stack(ldsStack, spill, overflow);
 	int work = -1;           // queue entry this lane is tracing, -1 = idle
 	int chunkNext = 0, chunkEnd = 0; // wave-uniform: reserved, not yet handed out
-	bool exhausted = false;  // wave-uniform: the queue has no more entries
+	bool exhausted = n <= 0; // wave-uniform: the queue has no more entries
 	f3 O(0.0f), D(0.0f), rD(0.0f);
 	float rayT = 0;
 	uint link = RT_LINK_DONE;
@@ -253,12 +263,25 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 					work = -1;
 				}
 				if (!exhausted) {
-					if (chunkNext >= chunkEnd) {
-						int base = 0;
-						if (lane == 0) base = atomicAdd(head, chunk);
-						base = __shfl(base, 0);
-						chunkNext = base, chunkEnd = base + chunk < n ? base + chunk : n;
-						if (base >= n) exhausted = true;
+					while (chunkNext >= chunkEnd && !exhausted) {
+						const int lo = home * subLen, hi = lo + subLen < n ? lo + subLen : n;
+						int base = subLen; // "empty"
+						if (lo < hi) {
+							if (lane == 0) base = atomicAdd(heads + home * RT_HEAD_STRIDE, chunk);
+							base = __builtin_amdgcn_readfirstlane(base); // lane 0's value, in an SGPR: everything derived from it stays scalar
+						}
+						if (lo + base < hi) {
+							chunkNext = lo + base, chunkEnd = chunkNext + chunk < hi ? chunkNext + chunk : hi;
+							// the next reservation: a share of what is left in this sub-queue
+							int next = (hi - chunkEnd) / (wavesPerHead * 2);
+							chunk = next >= RT_CHUNK ? RT_CHUNK : (next <= 64 ? 64 : (next & ~63));
+							tried = 0;
+						} else {
+							// this sub-queue is empty: help with the next one, in small pieces
+							home = home + 1 == RT_HEADS ? 0 : home + 1;
+							chunk = 64;
+							if (++tried == RT_HEADS) exhausted = true;
+						}
 					}
 					if (!exhausted) {
 						const int mine = chunkNext + __popcll(freeMask & below);
