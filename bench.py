@@ -116,7 +116,7 @@ def main():
         r.synchronize()
 
     # ---- untimed: counting pass (algorithmic work of this rank's rows), then warmup ----
-    r.set_counting(True)
+    r.set_counting(ha.RT_COUNT_EXECUTED)  # the walk the timed kernels make (same results, fewer TLAS / instance visits than the reference's)
     r.counters()
     step()
     near, occl = r.counters_split()
@@ -149,7 +149,7 @@ def main():
         sec_per_step = dt / args.steps
         value = W * H * spp / sec_per_step / 1e6
         ext = prof["extend"]
-        bytes_extend = ha.algorithmic_bytes(near)  # this rank, one step
+        bytes_extend = ha.algorithmic_bytes(near, executed=True)  # this rank, one step
         launches_per_step = ext["launches"] / args.steps
         avg_ms = ext["ms"] / max(1, ext["launches"])
         achieved = (bytes_extend / max(1.0, launches_per_step)) / (avg_ms * 1e-3) / 1e9 if ext["launches"] else 0.0
@@ -176,6 +176,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_extend (Scene::FindNearest)", "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_extend / max(1.0, launches_per_step)),
+                         "algorithmic_work_per_step": {k: int(near[k]) for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits", "brute_tests", "rays_nearest")},
                          "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches_per_step,
                          "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}},
         }

@@ -187,7 +187,14 @@ int rt_primary_hits(rt_ctx* ctx, float t_min, int32_t* obj_idx_out, float* t_out
 int rt_trace_batch(rt_ctx* ctx, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, float* rgb_out);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
-/* counting != 0: kernels tally rt_counters (slower; keep off when timing) */
+/* Kernels tally rt_counters (slower; keep off when timing).
+ *   RT_COUNT_REFERENCE  the walk bvh::BIntersect / tlas::Intersect make: the DataCollector tallies
+ *                       (bvh.cpp:610-631), identical to the oracle's
+ *   RT_COUNT_EXECUTED   the walk the timed kernels make: they skip TLAS children whose geometry the ray
+ *                       cannot reach, so fewer instance / node visits; same results */
+#define RT_COUNT_OFF 0
+#define RT_COUNT_REFERENCE 1
+#define RT_COUNT_EXECUTED 2
 int rt_set_counting(rt_ctx* ctx, int counting);
 int rt_get_counters(rt_ctx* ctx, rt_counters* out, int reset);
 /* the same tallies kept apart: nearest-hit queries (extend kernel) / occlusion queries (connect) */

@@ -53,7 +53,7 @@ struct rt_ctx {
 		hipEvent_t done = nullptr;
 	};
 	Pool pools[RT_MAX_POOLS];
-	int nPoolsWanted = 2;
+	int nPoolsWanted = 1; // RT_POOLS; measured: 2 pools overlap their kernels but do not shorten the frame
 	hipEvent_t fork = nullptr;
 	// traversal stack spill of pool 0 and of the batch queries + flags
 	uint* spill = nullptr;
@@ -63,7 +63,8 @@ struct rt_ctx {
 	int refillAny = 32; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
-	bool counting = false, profiling = false;
+	int counting = 0; // 0 off, 1 the reference's walk (RT_COUNT_REFERENCE), 2 the walk the timed kernels make (RT_COUNT_EXECUTED)
+	bool profiling = false;
 	rt_profile prof;
 	std::vector<Timer> timers; // pending event pairs, resolved lazily
 	std::vector<int> timerKind;
@@ -97,6 +98,8 @@ static void free_pool(std::vector<void*>& pool)
 	for (void* p : pool) (void)hipFree(p);
 	pool.clear();
 }
+
+static int tuning(const rt_ctx* c, int base) { return base | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0); }
 
 // ---- profiling helpers ---------------------------------------------------------------------
 enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_CONNECT, K_QUERY };
@@ -180,7 +183,6 @@ rt_ctx* rt_create(int device, int width, int height)
 		const void* qk[6] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true> };
 		for (int i = 0; i < 6; i++) { const int r = resident(qk[i]); if (r < q) q = r; }
 		c->gridQuery = q;
-		if (getenv("RT_DEBUG")) fprintf(stderr, "rt_create: resident blocks extend %d connect %d query %d (CUs %d)\n", c->gridExtend, c->gridConnect, c->gridQuery, prop.multiProcessorCount);
 	}
 	if (getenv("RT_REFILL")) c->refillMin = atoi(getenv("RT_REFILL"));
 	if (c->refillMin < 1) c->refillMin = 1;
@@ -687,16 +689,16 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, P[k].pendCount ? 0 : 1);
 			hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ACTIVE, Q.active, &Q.counts[0]);
 			prof_begin(c, K_EXTEND, st);
-			if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, c->refillMin, pl.spill, c->counters);
-			else hipLaunchKernelGGL(k_extend<false>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, c->refillMin, pl.spill, c->counters);
+			if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
+			else hipLaunchKernelGGL(k_extend<false>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
 			prof_end(c, st);
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
 			prof_end(c, st);
 			hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
 			prof_begin(c, K_CONNECT, st);
-			if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, (c->refillMin & ~0xFF) | c->refillAny, pl.spill, c->counters + 1);
-			else hipLaunchKernelGGL(k_connect<false>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, (c->refillMin & ~0xFF) | c->refillAny, pl.spill, c->counters + 1);
+			if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, tuning(c, (c->refillMin & ~0xFF) | c->refillAny), pl.spill, c->counters + 1);
+			else hipLaunchKernelGGL(k_connect<false>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, tuning(c, (c->refillMin & ~0xFF) | c->refillAny), pl.spill, c->counters + 1);
 			prof_end(c, st);
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
@@ -954,8 +956,8 @@ int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const f
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_query_nearest<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, c->refillMin, dH, c->spill, c->flags, c->counters);
-		else hipLaunchKernelGGL(k_query_nearest<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, c->refillMin, dH, c->spill, c->flags, c->counters);
+		if (c->counting) hipLaunchKernelGGL(k_query_nearest<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
+		else hipLaunchKernelGGL(k_query_nearest<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}
@@ -987,8 +989,8 @@ int rt_occluded_batch(rt_ctx* c, int n, const float* O, const float* D, const fl
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, c->refillMin, dR, c->spill, c->flags, c->counters + 1);
-		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, c->refillMin, dR, c->spill, c->flags, c->counters + 1);
+		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1);
+		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1);
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}
@@ -1014,8 +1016,8 @@ int rt_primary_hits(rt_ctx* c, float t_min, int32_t* obj_out, float* t_out)
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_primary_hits<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, c->refillMin, dO, dT, c->spill, c->flags, c->counters);
-		else hipLaunchKernelGGL(k_primary_hits<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, c->refillMin, dO, dT, c->spill, c->flags, c->counters);
+		if (c->counting) hipLaunchKernelGGL(k_primary_hits<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, tuning(c, c->refillMin), dO, dT, c->spill, c->flags, c->counters);
+		else hipLaunchKernelGGL(k_primary_hits<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, tuning(c, c->refillMin), dO, dT, c->spill, c->flags, c->counters);
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}
@@ -1028,7 +1030,13 @@ int rt_primary_hits(rt_ctx* c, float t_min, int32_t* obj_out, float* t_out)
 }
 
 // ---- measurement ------------------------------------------------------------------------------
-int rt_set_counting(rt_ctx* c, int counting) { if (!c) return RT_E_ARG; c->counting = counting != 0; return RT_OK; }
+int rt_set_counting(rt_ctx* c, int counting)
+{
+	if (!c) return RT_E_ARG;
+	if (counting < 0 || counting > RT_COUNT_EXECUTED) return fail(c, RT_E_ARG, "rt_set_counting: mode %d", counting);
+	c->counting = counting;
+	return RT_OK;
+}
 int rt_get_counters_split(rt_ctx* c, rt_counters* nearest, rt_counters* occluded, int reset)
 {
 	if (!c || !nearest || !occluded) return fail(c, RT_E_ARG, "rt_get_counters: null argument");

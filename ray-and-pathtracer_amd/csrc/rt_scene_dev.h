@@ -28,8 +28,9 @@
 //            the magnitudes involved, scaled by the transform's condition number).  A child whose
 //            inflated reach box the ray misses cannot yield a hit and is dropped; the ORDER in which the
 //            remaining children are visited still comes from the reference's boxes, so the first-found
-//            rule for equal t is untouched and results are identical.  Counting launches do not cull:
-//            the counters stay those of the reference's walk.
+//            rule for equal t is untouched and results are identical.  Counting launches either walk like
+//            the reference (no culling: the counters are the reference's tallies) or like the timed
+//            kernels (RT_TUNE_CULL_COUNTED: the counters are the work actually done).
 // All of it is read-only and a few MB at most: every XCD's 4 MiB L2 ends up holding its own copy.
 #pragma once
 #include "rt_dmath.h"
@@ -210,6 +211,7 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // each (4 KB apart: separate L2 channels); a wave reserves from its home sub-queue, sizes the
 // reservation by what is left there (256 entries early on, 64 near the end), and moves on to the other
 // sub-queues when its own is empty.
+#define RT_TUNE_CULL_COUNTED 0x10000 // 'tuning' bit: a counting launch drops unreachable TLAS children like a timed one
 #define RT_HEADS 16
 #define RT_HEAD_STRIDE 1024 // ints between two heads
 template <bool ANY, bool COUNT, bool HEAD, class Policy>
@@ -341,7 +343,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
 			else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
 			uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
-			if (!COUNT && S.useTLAS && inst < 0 && clean) {
+			if ((!COUNT || (tuning & RT_TUNE_CULL_COUNTED)) && S.useTLAS && inst < 0 && clean) {
 				// TLAS level: drop children whose geometry the ray cannot reach (see reach[] above)
 				const float4* q = S.reach + 4 * (size_t)(lk - S.tlasBase);
 				const float4 ra0 = q[0], ra1 = q[1], rb0 = q[2], rb1 = q[3];

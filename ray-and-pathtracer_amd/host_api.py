@@ -15,6 +15,7 @@ RT_SO = os.path.join(_HERE, "csrc", "librt_amd.so")
 HOST_SO = os.path.join(_HERE, "host", "librapt_host.so")
 
 RT_MODE_WHITTED, RT_MODE_PATH = 0, 1
+RT_COUNT_OFF, RT_COUNT_REFERENCE, RT_COUNT_EXECUTED = 0, 1, 2
 COUNTER_NAMES = ["inner_visits", "prim_tests", "tlas_inner", "instance_visits",
                  "rays_nearest", "rays_occluded", "brute_tests", "light_tests"]
 
@@ -383,6 +384,7 @@ class HostRenderer:
         return out
 
     def set_counting(self, on):
+        """False / 0 off, True / RT_COUNT_REFERENCE the reference's walk, RT_COUNT_EXECUTED the timed kernels' walk"""
         self._rt(self.rt.rt_set_counting(self.ctx, int(on)))
 
     def counters(self, reset=True):
@@ -405,10 +407,12 @@ class HostRenderer:
         return {k: dict(launches=int(getattr(p, k).launches), ms=float(getattr(p, k).ms)) for k in ("generate", "extend", "shade", "connect", "query")}
 
 
-def algorithmic_bytes(counters):
+def algorithmic_bytes(counters, executed=False):
     """Algorithmic bytes of a set of queries, SURVEY.md section 8(d): 64 B per BLAS inner-node visit
     (two 32-B children), 52 B per primitive test (4-B index + 48-B triangle), 48 B per ray (32 in,
-    16 out); TLAS adds 64 B per TLAS inner visit and 128 B per instance entry (two mat4)."""
+    16 out); TLAS adds 64 B per TLAS inner visit and 128 B per instance entry (two mat4).
+    executed=True prices tallies taken with RT_COUNT_EXECUTED: a TLAS visit of the timed kernels also
+    reads the 64-B reach record of the pair."""
     rays = counters["rays_nearest"] + counters["rays_occluded"]
     return (64 * counters["inner_visits"] + 52 * (counters["prim_tests"] + counters.get("brute_tests", 0)) + 48 * rays
-            + 64 * counters["tlas_inner"] + 128 * counters["instance_visits"])
+            + (128 if executed else 64) * counters["tlas_inner"] + 128 * counters["instance_visits"])

@@ -528,3 +528,12 @@ def test_tlas_reach_culling_keeps_results(name, kw, scenes, oracle_api, host_api
     assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
     for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits"):
         assert cnt[k] == ref["counters"][k], k
+    # RT_COUNT_EXECUTED: the tallies of the culled walk -- same answers, never more work than the reference's
+    r.set_counting(host_api.RT_COUNT_EXECUTED)
+    r.counters()
+    got = r.find_nearest(O, D)
+    cnt2 = r.counters()
+    r.set_counting(False)
+    assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert cnt2["rays_nearest"] == cnt["rays_nearest"] and cnt2["prim_tests"] <= cnt["prim_tests"]
+    assert cnt2["instance_visits"] < cnt["instance_visits"] and cnt2["inner_visits"] < cnt["inner_visits"] and cnt2["tlas_inner"] <= cnt["tlas_inner"]
