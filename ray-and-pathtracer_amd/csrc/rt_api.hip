@@ -690,7 +690,7 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 			const Queues Q = pl.Q;
 			hipStream_t st = pl.stream;
 			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, P[k].pendCount ? 0 : 1);
-			hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ACTIVE, Q.active, &Q.counts[0]);
+			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ACTIVE, Q.active, &Q.counts[0]);
 			prof_begin(c, K_EXTEND, st);
 			if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
 			else hipLaunchKernelGGL(k_extend<false>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
@@ -698,14 +698,14 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
 			prof_end(c, st);
-			hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
+			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
 			prof_begin(c, K_CONNECT, st);
 			if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, tuning(c, (c->refillMin & ~0xFF) | c->refillAny), pl.spill, c->counters + 1);
 			else hipLaunchKernelGGL(k_connect<false>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, tuning(c, (c->refillMin & ~0xFF) | c->refillAny), pl.spill, c->counters + 1);
 			prof_end(c, st);
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
-			hipLaunchKernelGGL(k_compact, dim3(grid / 4), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ENDED, Q.ended, &Q.counts[1]);
+			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ENDED, Q.ended, &Q.counts[1]);
 			hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, Rs[k], P[k], Q, parity);
 			prof_end(c, st);
 		}

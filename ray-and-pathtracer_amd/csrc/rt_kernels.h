@@ -220,11 +220,12 @@ __device__ __forceinline__ uint4 status16(const PathState& P, int slot0, int las
 	}
 	return v;
 }
-#define RT_COMPACT_BLOCK 1024
+#define RT_COMPACT_BLOCK 512
 __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int bit, uint* queue, int* count)
 {
 	__shared__ int waveTotal[RT_COMPACT_BLOCK / 64];
 	__shared__ int blockBase;
+	__shared__ uint stage[RT_COMPACT_BLOCK / 64][1024]; // per wave: the slots selected in one iteration, in order
 	const uint lane = threadIdx.x & 63;
 	const uint bits = (uint)bit * 0x01010101u;
 	const int waves = (gridDim.x * blockDim.x) >> 6;
@@ -255,23 +256,30 @@ __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int b
 	int base = blockBase;
 	for (int w = 0; w < wib; w++) base += waveTotal[w];
 	if (total == 0) return;
+	uint* mystage = stage[wib];
 	for (int s0 = first; s0 < last; s0 += 1024) {
 		const int slot0 = s0 + (int)lane * 16;
 		const uint4 v = status16(P, slot0, last, bits);
 		const int c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
 		int incl = c; // inclusive prefix sum over the wave
 		for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
-		uint* q = queue + base + incl - c;
+		// a lane's slots go to LDS at its prefix; the wave then writes them out 64 consecutive dwords at
+		// a time (a lane storing its own up-to-16 entries straight to memory touches 16 cache lines)
+		int at = incl - c;
 		const uint w[4] = { v.x, v.y, v.z, v.w };
 		for (int k = 0; k < 4; k++) {
 			uint x = w[k];
 			while (x) {
 				const int b = __ffs(x) - 1;
-				*q++ = (uint)(slot0 + 4 * k + (b >> 3));
+				mystage[at++] = (uint)(slot0 + 4 * k + (b >> 3));
 				x &= x - 1;
 			}
 		}
-		base += __shfl(incl, 63);
+		const int n = __shfl(incl, 63);
+		__builtin_amdgcn_wave_barrier(); // the stage is private to this wave and its LDS accesses execute in order: no s_barrier needed
+		for (int i = (int)lane; i < n; i += 64) queue[base + i] = mystage[i];
+		__builtin_amdgcn_wave_barrier();
+		base += n;
 	}
 }
 
