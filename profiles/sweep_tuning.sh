@@ -1,5 +1,7 @@
 #!/bin/bash
 # Sweep the traversal scheduling thresholds on the bench workload.  Usage: profiles/sweep_tuning.sh > log
-for sm in 8 12 16 24 32; do for rf in 16 24 32; do
- echo "stepmin $sm refill $rf: $(RT_STEPMIN=$sm RT_REFILL=$rf python bench.py --no-cpu-baseline --steps 2 --warmup 1 2>/dev/null | grep -o 'kernel_ms_per_step.*}}')"
-done; done
+run() { echo "$1: $(env $1 python bench.py --no-cpu-baseline --steps 2 --warmup 1 2>/dev/null | grep -o 'kernel_ms_per_step.*}}')"; }
+for rf in 8 12 16 24; do run "RT_REFILL=$rf"; done
+for ra in 12 16 24 32 48; do run "RT_REFILL_ANY=$ra"; done
+for sm in 6 8 12 16 20; do run "RT_STEPMIN=$sm"; done
+for pa in 8 16 24; do run "RT_PAIRAGAIN=$pa"; done

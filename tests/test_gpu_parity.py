@@ -537,3 +537,22 @@ def test_tlas_reach_culling_keeps_results(name, kw, scenes, oracle_api, host_api
     assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
     assert cnt2["rays_nearest"] == cnt["rays_nearest"] and cnt2["prim_tests"] <= cnt["prim_tests"]
     assert cnt2["instance_visits"] < cnt["instance_visits"] and cnt2["inner_visits"] < cnt["inner_visits"] and cnt2["tlas_inner"] <= cnt["tlas_inner"]
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1023, 1025, 4097, 70001])
+def test_batch_sizes_cover_the_work_heads(n, scenes, oracle_api, host_api):
+    """The traversal kernels cut a queue into 16 sub-queues of a multiple of 64 entries and hand them out
+    in pieces of 64..256 (csrc/rt_scene_dev.h): every entry must be traced exactly once for any length."""
+    o, orr, r, d = make_pair(scenes.REGISTRY["tlas_test2"], oracle_api, host_api, 32, 24)
+    O, D = random_rays(n, 1000 + n, center=(0.0, 1.0, 3.0), spread=5.0)
+    ref = o.find_nearest(O, D)
+    r.set_counting(True)
+    r.counters()
+    got = r.find_nearest(O, D)
+    cnt = r.counters()
+    r.set_counting(False)
+    assert cnt["rays_nearest"] == n
+    assert np.array_equal(got["obj"], ref["obj"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits"):
+        assert cnt[k] == ref["counters"][k], k
+    assert np.array_equal(r.is_occluded(O, D), o.is_occluded(O, D)["occluded"])
