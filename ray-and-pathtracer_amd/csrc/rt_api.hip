@@ -534,6 +534,13 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			walk.pop_back();
 		}
 		const uint tlasBase = (uint)tlasSlots.size() ? tlasSlotBase : 0;
+		// the boxes are stored inflated for every world origin with |O|_1 <= originMax: 64 x the extent of
+		// the instanced geometry (camera and bounce rays start inside that; a ray from further away is
+		// simply not culled)
+		double extent = 1.0;
+		for (uint i = 0; i < d->n_instances; i++)
+			if (instReach[i].b > 0) for (int k = 0; k < 3; k++) extent = std::max(extent, std::max(std::fabs(instReach[i].lo[k]), std::fabs(instReach[i].hi[k])));
+		const double originMax = 64.0 * 3.0 * extent;
 		std::vector<float> reach((size_t)tlasSlots.size() * 16 + 16, 0.0f);
 		for (size_t sI = 0; sI < tlasSlots.size(); sI++) {
 			const rt_tlas_node& nd = d->tlas_nodes[tlasSlots[sI]];
@@ -541,17 +548,18 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			for (int h = 0; h < 2; h++) {
 				const Reach& r = state[ch[h]] == 2 ? nodeReach[ch[h]] : unbounded();
 				float* rec = &reach[sI * 16 + 8 * h];
-				// round outwards: the float box must contain the double one
+				const double m = r.a + r.b * originMax;
+				// round outwards: the float box must contain the inflated double one
 				for (int k = 0; k < 3; k++) {
-					rec[k] = std::nextafterf((float)r.lo[k], -INFINITY), rec[4 + k] = std::nextafterf((float)r.hi[k], INFINITY);
+					rec[k] = std::nextafterf((float)std::max(r.lo[k] - m, -big), -INFINITY), rec[4 + k] = std::nextafterf((float)std::min(r.hi[k] + m, big), INFINITY);
 				}
-				rec[3] = std::nextafterf((float)r.a, INFINITY), rec[7] = std::nextafterf((float)r.b, INFINITY);
 			}
 		}
 		HIPCHK(c, dalloc(c->sceneAllocs, &dp, reach.size()));
 		HIPCHK(c, hipMemcpy(dp, reach.data(), reach.size() * 4, hipMemcpyHostToDevice));
 		S.reach = (const float4*)dp;
 		S.tlasBase = tlasBase;
+		S.reachOriginMax = (float)originMax;
 	}
 	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);
 	for (uint i = 0; i < d->n_lights; i++) {

@@ -146,19 +146,21 @@ __device__ __forceinline__ float intersect_aabb_clean(const f3& O, const f3& rD,
 	const float tz1 = (bmin.z - O.z) * rD.z, tz2 = (bmax.z - O.z) * rD.z;
 	const float tmin = hw_max3(hw_min(tx1, tx2), hw_min(ty1, ty2), hw_min(tz1, tz2));
 	const float tmax = hw_min3(hw_max(tx1, tx2), hw_max(ty1, ty2), hw_max(tz1, tz2));
-	if (tmax >= tmin && tmin < rayT && tmax > 0) return tmin;
-	return 1e30f;
+	// the three comparisons have no side effects: '&' gives the value of '&&' without the branches
+	const bool hit = (tmax >= tmin) & (tmin < rayT) & (tmax > 0);
+	return hit ? tmin : 1e30f;
 }
 // Conservative reachability test used for culling only (never for ordering or for accepting a hit):
-// false means that a ray which is clean in the sense above passes outside the box [bmin - m, bmax + m].
-__device__ __forceinline__ bool box_reachable(const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax, float m)
+// false means that a ray which is clean in the sense above passes outside the box (which the caller has
+// inflated by the rounding margin).
+__device__ __forceinline__ bool box_reachable(const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
 {
-	const float tx1 = ((bmin.x - m) - O.x) * rD.x, tx2 = ((bmax.x + m) - O.x) * rD.x;
-	const float ty1 = ((bmin.y - m) - O.y) * rD.y, ty2 = ((bmax.y + m) - O.y) * rD.y;
-	const float tz1 = ((bmin.z - m) - O.z) * rD.z, tz2 = ((bmax.z + m) - O.z) * rD.z;
+	const float tx1 = (bmin.x - O.x) * rD.x, tx2 = (bmax.x - O.x) * rD.x;
+	const float ty1 = (bmin.y - O.y) * rD.y, ty2 = (bmax.y - O.y) * rD.y;
+	const float tz1 = (bmin.z - O.z) * rD.z, tz2 = (bmax.z - O.z) * rD.z;
 	const float tmin = hw_max3(hw_min(tx1, tx2), hw_min(ty1, ty2), hw_min(tz1, tz2));
 	const float tmax = hw_min3(hw_max(tx1, tx2), hw_max(ty1, ty2), hw_max(tz1, tz2));
-	return tmax >= tmin && tmin < rayT && tmax > 0;
+	return (tmax >= tmin) & (tmin < rayT) & (tmax > 0);
 }
 __device__ __forceinline__ float intersect_aabb(bool clean, const f3& O, const f3& rD, float rayT, const f3& bmin, const f3& bmax)
 {

@@ -18,14 +18,16 @@
 //            parent's record, link = pair index or INST_BIT | instance), so one piece of code walks both
 //            levels; tlas::Intersect tests child (leftRight & 0xFFFF) first, which is slot A here.
 //   inst[]   128-byte records: invTransform rows 0-2, matTransform rows 0-2, root link.
-//   reach[]  one 64-byte record per TLAS pair, beside pairs[]: {minA.xyz, a}{maxA.xyz, b}{minB.xyz, a}{maxB.xyz, b}.
+//   reach[]  one 64-byte record per TLAS pair, beside pairs[]: {minA.xyz, -}{maxA.xyz, -}{minB.xyz, -}{maxB.xyz, -}.
 //            The reference's instance bounds are the union of the BLAS's LOCAL box and its transformed
 //            box (bvhInstance.h:15-30 never resets 'bounds'), so TLAS boxes overlap nearly everywhere and
 //            a ray enters almost every instance only to fail the first BLAS test.  reach holds, per child,
 //            the world box of what the subtree can really contain: the corners of (BLAS root's two child
-//            boxes) under the exact inverse of invTransform, evaluated in double at upload; a and b give a
-//            margin m = a + b * |O|_1 covering the float rounding of the object-space ray (~500 ulps of
-//            the magnitudes involved, scaled by the transform's condition number).  A child whose
+//            boxes) under the exact inverse of invTransform, evaluated in double at upload, inflated by
+//            a margin m = a + b * reachOriginMax that covers the float rounding of the object-space ray
+//            (~500 ulps of the magnitudes involved, scaled by the transform's condition number) for every
+//            ray whose world origin has |O|_1 <= reachOriginMax (64 x the extent of the instanced geometry;
+//            rays from further away are not culled).  A child whose
 //            inflated reach box the ray misses cannot yield a hit and is dropped; the ORDER in which the
 //            remaining children are visited still comes from the reference's boxes, so the first-found
 //            rule for equal t is untouched and results are identical.  Counting launches either walk like
@@ -77,6 +79,7 @@ struct DScene {
 	const unsigned char* sky;
 	uint rootLink; // scene BVH root, or the TLAS root in TLAS mode
 	uint tlasBase; // pair index of the first TLAS record
+	float reachOriginMax; // reach[] boxes are inflated for world ray origins with |O|_1 up to this
 	int useTLAS;
 	int nBruteSph, nBrutePla;
 	int nLights;
@@ -351,13 +354,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
 				else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
 				uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
-				if ((!COUNT || (tuning & RT_TUNE_CULL_COUNTED)) && S.useTLAS && inst < 0 && clean) {
+				if ((!COUNT || (tuning & RT_TUNE_CULL_COUNTED)) && S.useTLAS && inst < 0 && clean && fabsf(O.x) + fabsf(O.y) + fabsf(O.z) <= S.reachOriginMax) {
 					// TLAS level: drop children whose geometry the ray cannot reach (see reach[] above)
 					const float4* q = S.reach + 4 * (size_t)(lk - S.tlasBase);
 					const float4 ra0 = q[0], ra1 = q[1], rb0 = q[2], rb1 = q[3];
-					const float oAbs = fabsf(O.x) + fabsf(O.y) + fabsf(O.z);
-					if (!box_reachable(O, rD, rayT, xyz(ra0), xyz(ra1), ra0.w + ra1.w * oAbs)) dist1 = 1e30f;
-					if (!box_reachable(O, rD, rayT, xyz(rb0), xyz(rb1), rb0.w + rb1.w * oAbs)) dist2 = 1e30f;
+					if (!box_reachable(O, rD, rayT, xyz(ra0), xyz(ra1))) dist1 = 1e30f;
+					if (!box_reachable(O, rD, rayT, xyz(rb0), xyz(rb1))) dist2 = 1e30f;
 				}
 				if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
 				if (dist1 == 1e30f) pop_next();
