@@ -541,17 +541,17 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		for (uint i = 0; i < d->n_instances; i++)
 			if (instReach[i].b > 0) for (int k = 0; k < 3; k++) extent = std::max(extent, std::max(std::fabs(instReach[i].lo[k]), std::fabs(instReach[i].hi[k])));
 		const double originMax = 64.0 * 3.0 * extent;
-		std::vector<float> reach((size_t)tlasSlots.size() * 16 + 16, 0.0f);
+		std::vector<float> reach((size_t)tlasSlots.size() * 12 + 16, 0.0f);
 		for (size_t sI = 0; sI < tlasSlots.size(); sI++) {
 			const rt_tlas_node& nd = d->tlas_nodes[tlasSlots[sI]];
 			const uint ch[2] = { nd.left_right & 0xFFFFu, nd.left_right >> 16 };
 			for (int h = 0; h < 2; h++) {
 				const Reach& r = state[ch[h]] == 2 ? nodeReach[ch[h]] : unbounded();
-				float* rec = &reach[sI * 16 + 8 * h];
+				float* rec = &reach[sI * 12 + 6 * h]; // {min.xyz, max.xyz} of child h
 				const double m = r.a + r.b * originMax;
 				// round outwards: the float box must contain the inflated double one
 				for (int k = 0; k < 3; k++) {
-					rec[k] = std::nextafterf((float)std::max(r.lo[k] - m, -big), -INFINITY), rec[4 + k] = std::nextafterf((float)std::min(r.hi[k] + m, big), INFINITY);
+					rec[k] = std::nextafterf((float)std::max(r.lo[k] - m, -big), -INFINITY), rec[3 + k] = std::nextafterf((float)std::min(r.hi[k] + m, big), INFINITY);
 				}
 			}
 		}
@@ -560,6 +560,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		S.reach = (const float4*)dp;
 		S.tlasBase = tlasBase;
 		S.reachOriginMax = (float)originMax;
+		S.tlasPairs = (int)tlasSlots.size();
 	}
 	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);
 	for (uint i = 0; i < d->n_lights; i++) {

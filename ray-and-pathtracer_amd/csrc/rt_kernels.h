@@ -555,7 +555,10 @@ struct ConnectPolicy {
 	}
 };
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_connect(DScene S, PathState P, Queues Q, int parity, int refillMin, uint* spill, DCounters* counters)
+#ifndef RT_CONNECT_WAVES
+#define RT_CONNECT_WAVES 6
+#endif
+__global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S, PathState P, Queues Q, int parity, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
 	LaneCounters lc;

@@ -18,7 +18,7 @@
 //            parent's record, link = pair index or INST_BIT | instance), so one piece of code walks both
 //            levels; tlas::Intersect tests child (leftRight & 0xFFFF) first, which is slot A here.
 //   inst[]   128-byte records: invTransform rows 0-2, matTransform rows 0-2, root link.
-//   reach[]  one 64-byte record per TLAS pair, beside pairs[]: {minA.xyz, -}{maxA.xyz, -}{minB.xyz, -}{maxB.xyz, -}.
+//   reach[]  one 48-byte record per TLAS pair, beside pairs[]: {minA.xyz, maxA.x}{maxA.yz, minB.xy}{minB.z, maxB.xyz}.
 //            The reference's instance bounds are the union of the BLAS's LOCAL box and its transformed
 //            box (bvhInstance.h:15-30 never resets 'bounds'), so TLAS boxes overlap nearly everywhere and
 //            a ray enters almost every instance only to fail the first BLAS test.  reach holds, per child,
@@ -80,6 +80,7 @@ struct DScene {
 	uint rootLink; // scene BVH root, or the TLAS root in TLAS mode
 	uint tlasBase; // pair index of the first TLAS record
 	float reachOriginMax; // reach[] boxes are inflated for world ray origins with |O|_1 up to this
+	int tlasPairs; // number of TLAS pair records
 	int useTLAS;
 	int nBruteSph, nBrutePla;
 	int nLights;
@@ -348,18 +349,19 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				// one sibling pair: of the BLAS (bvh.cpp:638-654 / :788-804) or, outside an instance in TLAS
 				// mode, of the TLAS (tlas.cpp:77-91 / :106-120) -- same test, same ordering rule
 				if (COUNT) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
+				const bool atTlas = S.useTLAS && inst < 0;
 				const float4* p = S.pairs + 4 * (size_t)lk;
 				const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
 				float dist1, dist2;
 				if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
 				else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
 				uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
-				if ((!COUNT || (tuning & RT_TUNE_CULL_COUNTED)) && S.useTLAS && inst < 0 && clean && fabsf(O.x) + fabsf(O.y) + fabsf(O.z) <= S.reachOriginMax) {
+				if ((!COUNT || (tuning & RT_TUNE_CULL_COUNTED)) && atTlas && clean && fabsf(O.x) + fabsf(O.y) + fabsf(O.z) <= S.reachOriginMax) {
 					// TLAS level: drop children whose geometry the ray cannot reach (see reach[] above)
-					const float4* q = S.reach + 4 * (size_t)(lk - S.tlasBase);
-					const float4 ra0 = q[0], ra1 = q[1], rb0 = q[2], rb1 = q[3];
-					if (!box_reachable(O, rD, rayT, xyz(ra0), xyz(ra1))) dist1 = 1e30f;
-					if (!box_reachable(O, rD, rayT, xyz(rb0), xyz(rb1))) dist2 = 1e30f;
+					const float4* q = S.reach + 3 * (size_t)(lk - S.tlasBase);
+					const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+					if (!box_reachable(O, rD, rayT, xyz(r0), f3(r0.w, r1.x, r1.y))) dist1 = 1e30f;
+					if (!box_reachable(O, rD, rayT, f3(r1.z, r1.w, r2.x), f3(r2.y, r2.z, r2.w))) dist2 = 1e30f;
 				}
 				if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
 				if (dist1 == 1e30f) pop_next();
