@@ -556,3 +556,45 @@ def test_batch_sizes_cover_the_work_heads(n, scenes, oracle_api, host_api):
     for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits"):
         assert cnt[k] == ref["counters"][k], k
     assert np.array_equal(r.is_occluded(O, D), o.is_occluded(O, D)["occluded"])
+
+
+@pytest.mark.parametrize("slots", ["777", "4096", "20000"])
+@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("pretty_tlas", {"n_instances": 4})])
+def test_fewer_slots_than_samples(slots, name, kw, scenes, oracle_api, host_api, monkeypatch):
+    """With fewer slots than samples a slot whose sample is finished pulls the next one from the pool
+    (k_finish); by default every sample of a batch has its own slot, so this path needs RT_SLOTS.  The
+    frames must not depend on the slot count: same accumulator bits as with one slot per sample."""
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 96, 54, **kw)
+    r.clear()
+    r.render(host_api.RT_MODE_PATH, 0, 12)
+    full = r.accumulator()
+    monkeypatch.setenv("RT_SLOTS", slots)
+    err, _ = check_frames(orr, r, "path", 12, host_api)
+    assert np.array_equal(r.accumulator().view(np.uint32), full.view(np.uint32))
+    # Whitted: pending branches + pool
+    r.clear()
+    r.render(host_api.RT_MODE_WHITTED, 0, 1)
+    few = r.accumulator()
+    monkeypatch.delenv("RT_SLOTS")
+    r.clear()
+    r.render(host_api.RT_MODE_WHITTED, 0, 1)
+    assert np.array_equal(r.accumulator().view(np.uint32), few.view(np.uint32))
+
+
+def test_sample_pools_on_separate_streams(scenes, oracle_api, host_api, monkeypatch):
+    """RT_POOLS > 1 splits a batch of >= 1M samples over independent pools that run on their own streams
+    (csrc/rt_api.hip run_rounds); the frame must be the one a single pool renders, bit for bit.  A new
+    context per setting: the pool count is read at rt_create."""
+    frames = []
+    for pools in ("1", "3"):
+        monkeypatch.setenv("RT_POOLS", pools)
+        r = host_api.HostRenderer(320, 200)
+        d = scenes.REGISTRY["pretty_tlas"](r.scene, n_instances=4)
+        r.commit()
+        c = d["camera"]
+        r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+        r.render(host_api.RT_MODE_PATH, 0, 17)  # 1,088,000 samples
+        frames.append(r.accumulator().copy())
+        r.close()
+    assert np.isfinite(frames[0][..., :3]).mean() > 0.5
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
