@@ -672,8 +672,11 @@ static int slot_budget();
 // stream, so while one pool's traversal launch drains (its longest rays finish alone, at memory latency
 // per step) or its small kernels start up, the other pools' kernels fill the machine.  The context's
 // stream waits for all pools at the end.
-static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRounds)
+static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRounds, int knownRounds)
 {
+	// knownRounds > 0: the caller knows how many rounds empty every pool (path mode with a slot per sample:
+	// one round per path segment, depth + 1 of them), so no queue length is read back before the end
+	if (knownRounds > 0) maxRounds = knownRounds;
 	const int mode = Rs[0].mode;
 	const float t_min = mode == RT_MODE_WHITTED ? (float)1e-6 : 0.001f; // renderer.cpp:24, :131
 	const int grid = c->gridBlocks;
@@ -720,7 +723,7 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 		}
 		parity = 1 - parity;
 		// look at the queue lengths every few rounds (one small D2H copy + sync per pool); a pool stops when its queue is empty
-		if ((round & 3) == 3 || round + 1 == maxRounds) {
+		if ((knownRounds <= 0 && (round & 3) == 3) || round + 1 == maxRounds) {
 			for (int k = 0; k < nPools; k++)
 				if (live[k]) HIPCHK(c, hipMemcpyAsync(c->hostCounts + 16 * k, c->pools[k].Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->pools[k].stream));
 			bool any = false;
@@ -731,7 +734,7 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 				if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 				else if (hc[3] == 2) rc = fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
 				if (hc[3] != 0) (void)hipMemsetAsync(c->pools[k].Q.counts + 3, 0, sizeof(int), c->pools[k].stream);
-				if (hc[0] == 0) live[k] = false;
+				if (hc[0] == 0 || knownRounds > 0) live[k] = false;
 				any = any || live[k];
 			}
 			if (rc != RT_OK || !any) break;
@@ -752,8 +755,9 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 }
 
 // Split 'total' samples over the pools and size their slots.
-static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& base, RenderParams* Rs, int& nPools, int& maxSlots)
+static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& base, RenderParams* Rs, int& nPools, int& maxSlots, bool& slotPerSample)
 {
+	slotPerSample = true;
 	nPools = total >= ((size_t)1 << 20) ? c->nPoolsWanted : 1; // small batches: one pool
 	const size_t per = (total + nPools - 1) / nPools;
 	maxSlots = 0;
@@ -766,6 +770,7 @@ static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& b
 		if (rc != RT_OK) return rc;
 		Rs[k] = base;
 		Rs[k].sampleFirst = (uint)first, Rs[k].nSamples = (uint)cnt;
+		if ((size_t)slots < cnt) slotPerSample = false;
 		if (slots > maxSlots) maxSlots = slots;
 		first += cnt;
 	}
@@ -831,11 +836,12 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		}
 		RenderParams Rs[RT_MAX_POOLS];
 		int nPools = 1, slots = 1;
-		rc = setup_pools(c, total, mode == RT_MODE_WHITTED, R, Rs, nPools, slots);
+		bool slotPerSample = false;
+		rc = setup_pools(c, total, mode == RT_MODE_WHITTED, R, Rs, nPools, slots, slotPerSample);
 		if (rc != RT_OK) return rc;
 		const int seg = segments_per_sample(mode, mode == RT_MODE_PATH ? 4 : max_depth, c->S.nLights);
 		const int maxRounds = (int)((total / nPools + slots) / slots) * seg + seg + 4;
-		rc = run_rounds(c, Rs, nPools, maxRounds);
+		rc = run_rounds(c, Rs, nPools, maxRounds, mode == RT_MODE_PATH && slotPerSample ? seg : 0);
 		if (rc != RT_OK) return rc;
 		hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 	}
@@ -880,9 +886,10 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 	} else {
 		RenderParams Rs[RT_MAX_POOLS];
 		int nPools = 1, slots = 1;
-		rc = setup_pools(c, (size_t)n, mode == RT_MODE_WHITTED, R, Rs, nPools, slots);
+		bool slotPerSample = false;
+		rc = setup_pools(c, (size_t)n, mode == RT_MODE_WHITTED, R, Rs, nPools, slots, slotPerSample);
 		const int seg = segments_per_sample(mode, depth, c->S.nLights);
-		if (rc == RT_OK) rc = run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4);
+		if (rc == RT_OK) rc = run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, mode == RT_MODE_PATH && slotPerSample ? seg : 0);
 	}
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);
