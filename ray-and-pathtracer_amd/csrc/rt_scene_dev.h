@@ -221,6 +221,11 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #define RT_PAIR_REPEAT 4 // pair steps per iteration at most (unrolled)
 #endif
 #define RT_HEAD_STRIDE 1024 // ints between two heads
+#ifndef RT_HEADS_PROBE
+#define RT_HEADS_PROBE 6 // sub-queues a wave finds empty in a row before it stops looking (every probe is one more
+                         // same-address atomic per wave at the end of a launch: 16 -> 3 took a 2 M-ray frame from 5.1 to
+                         // 4.7 ms, but 3 costs balance on the full frame)
+#endif
 template <bool ANY, bool COUNT, bool HEAD, class Policy>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
@@ -289,7 +294,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 							// this sub-queue is empty: help with the next one, in small pieces
 							home = home + 1 == RT_HEADS ? 0 : home + 1;
 							chunk = 64;
-							if (++tried == RT_HEADS) exhausted = true;
+							if (++tried == RT_HEADS_PROBE) exhausted = true;
 						}
 					}
 					if (!exhausted) {
