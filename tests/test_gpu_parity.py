@@ -115,6 +115,8 @@ RENDER_SCENES = [
     ("scene3", {"force_diffuse": True, "split": 3}, 96, 54),
     ("tlas_test2", {}, 96, 64),
     ("pretty_tlas", {"n_instances": 4}, 96, 54),
+    ("pretty_tlas", {"n_instances": 8}, 240, 135),  # the bench scene (BASELINE config 3) at 1/8 size
+    ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 128, 72),  # BASELINE config 5's layout with the small mesh
 ]
 
 
