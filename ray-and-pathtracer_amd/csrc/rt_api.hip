@@ -717,8 +717,10 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 			prof_end(c, st);
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
-			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ENDED, Q.ended, &Q.counts[1]);
-			hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, Rs[k], P[k], Q, parity);
+			if (!Rs[k].finishInline) {
+				hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ENDED, Q.ended, &Q.counts[1]);
+				hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, Rs[k], P[k], Q, parity);
+			}
 			prof_end(c, st);
 		}
 		parity = 1 - parity;
@@ -841,7 +843,9 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		if (rc != RT_OK) return rc;
 		const int seg = segments_per_sample(mode, mode == RT_MODE_PATH ? 4 : max_depth, c->S.nLights);
 		const int maxRounds = (int)((total / nPools + slots) / slots) * seg + seg + 4;
-		rc = run_rounds(c, Rs, nPools, maxRounds, mode == RT_MODE_PATH && slotPerSample ? seg : 0);
+		const bool direct = mode == RT_MODE_PATH && slotPerSample;
+		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
+		rc = run_rounds(c, Rs, nPools, maxRounds, direct ? seg : 0);
 		if (rc != RT_OK) return rc;
 		hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 	}
@@ -889,7 +893,9 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 		bool slotPerSample = false;
 		rc = setup_pools(c, (size_t)n, mode == RT_MODE_WHITTED, R, Rs, nPools, slots, slotPerSample);
 		const int seg = segments_per_sample(mode, depth, c->S.nLights);
-		if (rc == RT_OK) rc = run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, mode == RT_MODE_PATH && slotPerSample ? seg : 0);
+		const bool direct = mode == RT_MODE_PATH && slotPerSample;
+		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
+		if (rc == RT_OK) rc = run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, direct ? seg : 0);
 	}
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);

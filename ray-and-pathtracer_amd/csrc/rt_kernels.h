@@ -64,6 +64,8 @@ struct RenderParams {
 	float4* accum;     // accumulator, whole image
 	// rt_trace_batch: caller rays instead of camera rays, raw radiance out instead of accumulation
 	const float* customO; const float* customD; float4* customOut; int customDepth;
+	int finishInline;  // path mode with a slot per sample: nothing to resume and no sample to pull when a segment ends,
+	                   // so shade / light store the finished sample themselves and the round has no finish pass
 };
 
 #define ST_ACTIVE 1      // has a ray for extend + shade
@@ -342,6 +344,15 @@ __device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, 
 	if (P.pendCount) P.pendCount[slot] = 0;
 }
 
+// A finished sample goes to the [frame][pixel] buffer (renderer.cpp:270 / :279-282: gamma per sample in path
+// mode) or to the caller's array (rt_trace_batch).
+__device__ __forceinline__ void store_sample(const RenderParams& R, uint sid, const f3& L)
+{
+	if (R.customOut) R.customOut[sid] = mk4(L, 0.0f);
+	else if (R.mode == 0) R.samples[sid] = make_float4(L.x / (float)1, L.y / (float)1, L.z / (float)1, 0.0f);
+	else R.samples[sid] = make_float4(x_powf(L.x * 1, RT_GAMMA), x_powf(L.y * 1, RT_GAMMA), x_powf(L.z * 1, RT_GAMMA), 0.0f);
+}
+
 __device__ __forceinline__ void push_pending(PathState& P, int slot, const f3& O, const f3& D, const f3& W, const f3& E, int depth, int* overflow)
 {
 	int n = P.pendCount[slot];
@@ -416,7 +427,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, 
 // shade: everything Trace / Sample do at a hit except the occlusion-dependent direct terms.
 // Outcomes per slot: continue with a new ray (next active queue), hand the diffuse direct terms to
 // connect + light (shadow queue), or end the segment (done queue).
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity)
+__global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity)
 {
 	const int pout = 1 - parity;
 	const int nActive = Q.counts[0];
@@ -523,6 +534,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene S, RenderParams R, Pa
 				keep = true;
 			} else if (!wantShadow) {
 				ended = true;
+				if (R.finishInline) store_sample(R, __float_as_uint(l4.w), Lsum), ended = false; // the slot is simply done
 			}
 		}
 		P.status[slot] = (keep ? ST_ACTIVE : 0) | (wantShadow ? ST_SHADOW : 0) | (wantShadow && !keep ? ST_ENDS_AFTER : 0) | (ended ? ST_ENDED : 0);
@@ -612,7 +624,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 			}
 			P.E[slot] = mk4(E, e4.w);
 			P.L[slot] = mk4(Lsum, l4.w);
-			P.status[slot] = (stBits & ST_ACTIVE) | ((stBits & ST_ENDS_AFTER) ? ST_ENDED : 0);
+			const bool endsHere = (stBits & ST_ENDS_AFTER) != 0;
+			if (endsHere && R.finishInline) store_sample(R, __float_as_uint(l4.w), Lsum);
+			P.status[slot] = (stBits & ST_ACTIVE) | (endsHere && !R.finishInline ? ST_ENDED : 0);
 		}
 	}
 }
@@ -668,9 +682,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, Render
 			} else {
 				const float4 l4 = P.L[slot];
 				const uint sid = __float_as_uint(l4.w);
-				if (R.customOut) R.customOut[sid] = make_float4(l4.x, l4.y, l4.z, 0.0f);
-				else if (R.mode == 0) R.samples[sid] = make_float4(l4.x / (float)1, l4.y / (float)1, l4.z / (float)1, 0.0f);
-				else R.samples[sid] = make_float4(x_powf(l4.x * 1, RT_GAMMA), x_powf(l4.y * 1, RT_GAMMA), x_powf(l4.z * 1, RT_GAMMA), 0.0f);
+				store_sample(R, sid, xyz(l4));
 				completes = true;
 			}
 		}
