@@ -412,7 +412,7 @@ def algorithmic_bytes(counters, executed=False):
     (two 32-B children), 52 B per primitive test (4-B index + 48-B triangle), 48 B per ray (32 in,
     16 out); TLAS adds 64 B per TLAS inner visit and 128 B per instance entry (two mat4).
     executed=True prices tallies taken with RT_COUNT_EXECUTED: a TLAS visit of the timed kernels also
-    reads the 64-B reach record of the pair."""
+    reads the 48-B reach record of the pair."""
     rays = counters["rays_nearest"] + counters["rays_occluded"]
     return (64 * counters["inner_visits"] + 52 * (counters["prim_tests"] + counters.get("brute_tests", 0)) + 48 * rays
-            + (128 if executed else 64) * counters["tlas_inner"] + 128 * counters["instance_visits"])
+            + (112 if executed else 64) * counters["tlas_inner"] + 128 * counters["instance_visits"])
