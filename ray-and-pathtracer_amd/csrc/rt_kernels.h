@@ -400,10 +400,11 @@ struct ExtendPolicy {
 	{
 		// the ray in registers may be the object-space one; the sphere normal needs the world ray
 		const int slot = (int)queue[work];
-		const f3 O = xyz(P.O[parity][slot]), D = xyz(P.D[parity][slot]);
 		int objIdx, mat;
 		f3 normal;
-		resolve_hit(S, hit, O, D, objIdx, mat, normal);
+		const PathState& Pc = P;
+		const int par = parity;
+		resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = xyz(Pc.O[par][slot]), d = xyz(Pc.D[par][slot]); }, objIdx, mat, normal);
 		P.hitN[slot] = mk4(normal, hit.t);
 		P.hitId[slot] = make_int2(objIdx, mat);
 	}

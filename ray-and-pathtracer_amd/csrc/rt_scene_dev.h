@@ -524,7 +524,10 @@ __device__ __forceinline__ bool is_occluded_one(const DScene& S, const f3& O, co
 // Fill the fields FindNearest leaves in the Ray: objIdx, material, hitNormal (for the sphere the
 // normal is (P - pos) * invr at the accepted t, template/scene.h:361; for an instanced triangle
 // normalize(TransformVector(N, matTransform)), bvhInstance.cpp:19).
-__device__ __forceinline__ void resolve_hit(const DScene& S, const HitRef& hit, const f3& O, const f3& D, int& objIdx, int& mat, f3& normal)
+// 'ray' is called only for a sphere (it is the one primitive whose normal needs the ray), so a caller that
+// would have to fetch the ray from memory does not do so for the triangles, planes and lights.
+template <class RayFn>
+__device__ __forceinline__ void resolve_hit_lazy(const DScene& S, const HitRef& hit, RayFn ray, int& objIdx, int& mat, f3& normal)
 {
 	objIdx = -1, mat = -1, normal = f3(0.0f);
 	if (hit.kind < 0) return;
@@ -543,10 +546,16 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const HitRef& hit, 
 		if (hit.inst >= 0) normal = normalize(xform_vec(S.inst[hit.inst].T, normal));
 	} else if (kind == RT_KIND_SPHERE) {
 		const float4 r1 = rec[1];
+		f3 O, D;
+		ray(O, D);
 		normal = ((O + hit.t * D) - xyz(r0)) * r1.x;
 	} else {
 		normal = xyz(r0);
 	}
+}
+__device__ __forceinline__ void resolve_hit(const DScene& S, const HitRef& hit, const f3& O, const f3& D, int& objIdx, int& mat, f3& normal)
+{
+	resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = O, d = D; }, objIdx, mat, normal);
 }
 
 } // namespace rtd
