@@ -186,6 +186,15 @@ int rt_primary_hits(rt_ctx* ctx, float t_min, int32_t* obj_idx_out, float* t_out
  * InitSeed(seed_base + i). */
 int rt_trace_batch(rt_ctx* ctx, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, float* rgb_out);
 
+/* ---- acceleration structure build ("next" row N1) ------------------------------------------------ */
+/* bvh::Build() with splitMethod BINNEDSAH (bvh.cpp:18-56; FindBestSplitPlane :116-193, Subdivide :223-333,
+ * separatePlanes :202-221, Refit :556-594) on the device.  The result is the reference's tree bit for bit: node
+ * numbering, boxes and primitiveIdx order.  nodes_out: 2 * (n_tri + n_sph + n_pla + 1) entries (bvh.cpp:33),
+ * prim_idx_out: n_tri + n_sph + n_pla entries.  RT_E_UNSUPPORTED (never a silent fallback) for an input with
+ * no triangle or sphere, or with a non-finite vertex / centre / radius. */
+int rt_build_bvh(rt_ctx* ctx, const rt_triangle* tris, uint32_t n_tri, const rt_sphere* spheres, uint32_t n_sph, const rt_plane* planes, uint32_t n_pla,
+                 rt_bvh_node* nodes_out, uint32_t* prim_idx_out, uint32_t* nodes_used_out);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernels tally rt_counters (slower; keep off when timing).
  *   RT_COUNT_REFERENCE  the walk bvh::BIntersect / tlas::Intersect make: the DataCollector tallies

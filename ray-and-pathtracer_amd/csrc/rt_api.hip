@@ -2,6 +2,7 @@
 // Host part: context, repacking of the reference-shaped scene arrays into the HBM traversal layout
 // (rt_scene_dev.h), the round loop of the wavefront pixel loop, batch queries, counters, profiling.
 #include "rt_kernels.h"
+#include "rt_build.h"
 #include "../../include/rt_amd.h"
 #include <cstdarg>
 #include <cstdio>
@@ -593,6 +594,115 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	}
 	c->S = S;
 	c->sceneLoaded = true;
+	return RT_OK;
+}
+
+// bvh::Build (splitMethod BINNEDSAH) on the device; see rt_build.h.  Planes never take part in the subdivision
+// (separatePlanes, bvh.cpp:202-221: they become the right child of the root), so their node is made here.
+int rt_build_bvh(rt_ctx* c, const rt_triangle* tris, uint32_t n_tri, const rt_sphere* spheres, uint32_t n_sph, const rt_plane* planes, uint32_t n_pla,
+                 rt_bvh_node* nodes_out, uint32_t* prim_idx_out, uint32_t* nodes_used_out)
+{
+	if (!c || !nodes_out || !prim_idx_out || !nodes_used_out) return fail(c, RT_E_ARG, "rt_build_bvh: null argument");
+	if ((n_tri && !tris) || (n_sph && !spheres) || (n_pla && !planes)) return fail(c, RT_E_ARG, "rt_build_bvh: null primitive array");
+	const uint M = n_tri + n_sph, N = M + n_pla;
+	if (M == 0) return fail(c, RT_E_UNSUPPORTED, "rt_build_bvh: no triangle or sphere to subdivide (the reference's paths for an empty or plane-only bvh stay on the host)");
+	HIPCHK(c, hipSetDevice(c->device));
+	std::vector<void*> tmp;
+	struct Guard { std::vector<void*>& v; ~Guard() { free_pool(v); } } guard{ tmp };
+	BuildArrays B;
+	memset(&B, 0, sizeof(B));
+	float *dTri = nullptr, *dSph = nullptr;
+	int *openA = nullptr, *openB = nullptr;
+	HIPCHK(c, dalloc(tmp, &dTri, (size_t)n_tri * 14 + 4));
+	HIPCHK(c, dalloc(tmp, &dSph, (size_t)n_sph * 8 + 4));
+	HIPCHK(c, dalloc(tmp, &B.cen, M));
+	HIPCHK(c, dalloc(tmp, &B.nlo, M));
+	HIPCHK(c, dalloc(tmp, &B.nhi, M));
+	HIPCHK(c, dalloc(tmp, &B.blo, M));
+	HIPCHK(c, dalloc(tmp, &B.bhi, M));
+	HIPCHK(c, dalloc(tmp, &B.idx, M));
+	HIPCHK(c, dalloc(tmp, &B.tmp, M));
+	HIPCHK(c, dalloc(tmp, &B.hpos, M));
+	HIPCHK(c, dalloc(tmp, &B.fpos, M));
+	HIPCHK(c, dalloc(tmp, &B.nodes, (size_t)2 * M + 2));
+	HIPCHK(c, dalloc(tmp, &B.counters, 4));
+	HIPCHK(c, dalloc(tmp, &openA, (size_t)2 * M + 2));
+	HIPCHK(c, dalloc(tmp, &openB, (size_t)2 * M + 2));
+	static_assert(sizeof(rt_triangle) == 56 && sizeof(rt_sphere) == 32, "primitive layouts of rt_amd.h");
+	if (n_tri) HIPCHK(c, hipMemcpyAsync(dTri, tris, (size_t)n_tri * sizeof(rt_triangle), hipMemcpyHostToDevice, c->stream));
+	if (n_sph) HIPCHK(c, hipMemcpyAsync(dSph, spheres, (size_t)n_sph * sizeof(rt_sphere), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipMemsetAsync(B.counters, 0, 4 * sizeof(int), c->stream));
+	const int zero = 0;
+	HIPCHK(c, hipMemcpyAsync(openA, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(k_build_prep, dim3((M + 255) / 256), dim3(256), 0, c->stream, dTri, 14, (int)n_tri, dSph, 8, (int)n_sph, B);
+	hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, c->stream, B, M);
+	int nOpen = 1, host[4] = { 0, 0, 0, 0 };
+	int *open = openA, *next = openB;
+	for (uint level = 0; nOpen > 0; level++) {
+		if (level > M + 2) return fail(c, RT_E_STATE, "rt_build_bvh: more levels than primitives");
+		HIPCHK(c, hipMemsetAsync(B.counters + 1, 0, sizeof(int), c->stream));
+		hipLaunchKernelGGL(k_build_level, dim3((unsigned)nOpen), dim3(64), 0, c->stream, B, open, next);
+		HIPCHK(c, hipMemcpyAsync(host, B.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if (host[2]) return fail(c, RT_E_UNSUPPORTED, "rt_build_bvh: non-finite vertex, centre or radius (the reference's NaN-order-dependent min / max stay on the host)");
+		nOpen = host[1];
+		std::swap(open, next);
+	}
+	HIPCHK(c, hipGetLastError());
+	const int nT = host[0];
+	std::vector<TNode> t((size_t)nT);
+	HIPCHK(c, hipMemcpy(t.data(), B.nodes, (size_t)nT * sizeof(TNode), hipMemcpyDeviceToHost));
+	HIPCHK(c, hipMemcpy(prim_idx_out, B.idx, (size_t)M * sizeof(uint), hipMemcpyDeviceToHost));
+	for (uint i = 0; i < n_pla; i++) prim_idx_out[M + i] = M + i;
+
+	// the reference's numbering: Subdivide allocates a node's children (an adjacent pair) when it reaches the
+	// node, depth first, left subtree before right (bvh.cpp:317-332)
+	memset(nodes_out, 0, (size_t)2 * (N + 1) * sizeof(rt_bvh_node));
+	uint nodesUsed = 2;
+	uint rootAt = 0;
+	if (n_pla > 0) {
+		// separatePlanes: root -> { node 2 = what was subdivided above, node 3 = the planes }
+		nodesUsed = 4, rootAt = 2;
+		rt_bvh_node& pl = nodes_out[3];
+		float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+		for (uint i = 0; i < n_pla; i++) { // UpdateNodeBounds for planes, Q1 (bvh.cpp:90-111)
+			const float* Np = planes[i].N;
+			const float invLen = 1.0f / sqrtf(Np[0] * Np[0] + Np[1] * Np[1] + Np[2] * Np[2]);
+			const float n[3] = { Np[0] * invLen, Np[1] * invLen, Np[2] * invLen };
+			int ax = -1;
+			if (n[0] + n[1] + n[2] == 1 && (n[0] == 1 || n[1] == 1 || n[2] == 1)) ax = n[0] == 1 ? 0 : (n[1] == 1 ? 1 : 2);
+			if (ax < 0) { for (int k = 0; k < 3; k++) lo[k] = -1e30f, hi[k] = 1e30f; break; }
+			for (int k = 0; k < 3; k++) {
+				const float sl = k == ax ? 0.0f : -1e30f, sh = k == ax ? 0.0f : 1e30f;
+				lo[k] = lo[k] < sl ? lo[k] : sl, hi[k] = hi[k] > sh ? hi[k] : sh;
+			}
+		}
+		memcpy(pl.aabb_min, lo, 12), memcpy(pl.aabb_max, hi, 12);
+		pl.left_first = M, pl.prim_count = n_pla;
+	}
+	std::vector<std::pair<int, uint>> stack; // (TNode, final index)
+	stack.push_back({ 0, rootAt });
+	while (!stack.empty()) {
+		const int id = stack.back().first;
+		const uint at = stack.back().second;
+		stack.pop_back();
+		const TNode& tn = t[(size_t)id];
+		rt_bvh_node& o = nodes_out[at];
+		memcpy(o.aabb_min, tn.lo, 12), memcpy(o.aabb_max, tn.hi, 12);
+		if (tn.left < 0) { o.left_first = tn.first, o.prim_count = tn.count; continue; }
+		const uint pair = nodesUsed;
+		nodesUsed += 2;
+		o.left_first = pair, o.prim_count = 0;
+		stack.push_back({ tn.right, pair + 1 }); // popped after the whole left subtree
+		stack.push_back({ tn.left, pair });
+	}
+	if (n_pla > 0) { // Refit of the root (bvh.cpp:556-594): union of its two children
+		rt_bvh_node& r = nodes_out[0];
+		const rt_bvh_node &a = nodes_out[2], &b = nodes_out[3];
+		for (int k = 0; k < 3; k++) r.aabb_min[k] = a.aabb_min[k] < b.aabb_min[k] ? a.aabb_min[k] : b.aabb_min[k], r.aabb_max[k] = a.aabb_max[k] > b.aabb_max[k] ? a.aabb_max[k] : b.aabb_max[k];
+		r.left_first = 2, r.prim_count = 0;
+	}
+	*nodes_used_out = nodesUsed;
 	return RT_OK;
 }
 

@@ -1,0 +1,285 @@
+// bvh::Build with splitMethod BINNEDSAH (bvh.cpp:18-56, 67-114, 116-200, 223-333) on the device: the step
+// immediately before the trace loop.  The tree must come out IDENTICAL to the
+// reference's -- node numbering, boxes, primitiveIdx order -- because the stored boxes and the leaf order
+// decide which primitive a ray reports, so this is a restatement of the same arithmetic, reorganised:
+//
+//   * level by level instead of depth first: every open node of a level is subdivided by one wave; the
+//     depth-first numbering (children pairs are allocated in the order Subdivide reaches their parents) is
+//     restored at the end from the tree's shape;
+//   * centroid bounds, bin counts and bin boxes are min / max / integer sums: any order gives the same bits
+//     (inputs are checked to be finite: NaN would make the reference's ternary min / max order dependent);
+//   * the 7-plane sweep and the '<' comparisons run on one lane in the reference's order;
+//   * the in-place partition loop (bvh.cpp:296-313) moves elements in a fixed pattern that has a closed
+//     form: with L = "centroid < splitPos", nL = #L, holes h_1 < h_2 < ... = positions below nL holding an R,
+//     fillers f_1 > f_2 > ... = positions from nL up holding an L (f_0 = count, K of each):
+//         L below nL          stays
+//         hole h_k            -> f_(k-1) - 1
+//         filler f_k          -> h_k
+//         R at q > f_K        -> q - 1
+//         R at q < f_K        -> q - 1, except q = nL -> f_K - 1
+//     (tests/test_host_cpu.py checks the closed form against the loop on random arrays.)
+#pragma once
+#include "rt_dmath.h"
+
+namespace rtd {
+
+#define RT_BUILD_BINS 8 // bvh.cpp:118
+
+struct TNode { // a node in creation order (not yet the reference's numbering)
+	float lo[3]; uint first;
+	float hi[3]; uint count;
+	int left, right; // TNode indices of the children, -1: leaf
+};
+
+struct BuildArrays {
+	float4* cen;  // centroid (triangle: (v0 + v1 + v2) * 0.333f, template/scene.h:186; sphere: pos)
+	float4* nlo;  // what UpdateNodeBounds grows a node by (triangle: its vertices; sphere: pos -+ r)
+	float4* nhi;
+	float4* blo;  // what FindBestSplitPlane grows a bin by (sphere: pos -+ 2r, Q3)
+	float4* bhi;
+	uint* idx;    // primitiveIdx
+	uint* tmp;    // partition target
+	uint* hpos;   // holes / fillers of the node being partitioned, at the node's own range
+	uint* fpos;
+	TNode* nodes;
+	int* counters; // [0] nodes used, [1] open nodes of the next level, [2] error flag
+};
+
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_sum(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ int wave_excl(int v, uint lane) // exclusive prefix sum over the wave
+{
+	int incl = v;
+	for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
+	return incl - v;
+}
+__device__ __forceinline__ bool finite3(const float* v) { return fabsf(v[0]) < 1e30f && fabsf(v[1]) < 1e30f && fabsf(v[2]) < 1e30f; }
+
+// per-primitive quantities; primitives [0, nTri) are triangles, [nTri, nTri + nSph) spheres
+__global__ void k_build_prep(const float* tris, int triStride, int nTri, const float* sph, int sphStride, int nSph, BuildArrays B)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nTri + nSph) return;
+	float c[3], lo[3], hi[3], l2[3], h2[3];
+	bool ok;
+	if (i < nTri) {
+		const float* t = tris + (size_t)i * triStride; // v0[3] v1[3] v2[3]
+		ok = finite3(t) && finite3(t + 3) && finite3(t + 6);
+		for (int k = 0; k < 3; k++) {
+			c[k] = ((t[k] + t[3 + k]) + t[6 + k]) * 0.333f;
+			lo[k] = fminf(fminf(t[k], t[3 + k]), t[6 + k]), hi[k] = fmaxf(fmaxf(t[k], t[3 + k]), t[6 + k]);
+			l2[k] = lo[k], h2[k] = hi[k];
+		}
+	} else {
+		const float* s = sph + (size_t)(i - nTri) * sphStride; // pos[3] r2 invr r
+		const float r = s[5];
+		ok = finite3(s) && fabsf(r) < 1e30f;
+		for (int k = 0; k < 3; k++) {
+			c[k] = s[k];
+			lo[k] = s[k] - r, hi[k] = s[k] + r;
+			l2[k] = s[k] - 2 * r, h2[k] = s[k] + 2 * r;
+		}
+	}
+	if (!ok) B.counters[2] = 1;
+	B.cen[i] = make_float4(c[0], c[1], c[2], 0);
+	B.nlo[i] = make_float4(lo[0], lo[1], lo[2], 0), B.nhi[i] = make_float4(hi[0], hi[1], hi[2], 0);
+	B.blo[i] = make_float4(l2[0], l2[1], l2[2], 0), B.bhi[i] = make_float4(h2[0], h2[1], h2[2], 0);
+	B.idx[i] = (uint)i;
+}
+
+// UpdateNodeBounds over a range of primitiveIdx (bvh.cpp:67-114), one wave
+__device__ __forceinline__ void range_bounds(const BuildArrays& B, uint first, uint count, uint lane, float* lo, float* hi)
+{
+	float l[3] = { 1e30f, 1e30f, 1e30f }, h[3] = { -1e30f, -1e30f, -1e30f };
+	for (uint i = lane; i < count; i += 64) {
+		const uint p = B.idx[first + i];
+		const float4 a = B.nlo[p], b = B.nhi[p];
+		l[0] = fminf(l[0], a.x), l[1] = fminf(l[1], a.y), l[2] = fminf(l[2], a.z);
+		h[0] = fmaxf(h[0], b.x), h[1] = fmaxf(h[1], b.y), h[2] = fmaxf(h[2], b.z);
+	}
+	for (int k = 0; k < 3; k++) lo[k] = wave_min(l[k]), hi[k] = wave_max(h[k]);
+}
+
+__global__ void k_build_root(BuildArrays B, uint count)
+{
+	const uint lane = threadIdx.x & 63;
+	float lo[3], hi[3];
+	range_bounds(B, 0, count, lane, lo, hi);
+	if (lane == 0) {
+		TNode& n = B.nodes[0];
+		for (int k = 0; k < 3; k++) n.lo[k] = lo[k], n.hi[k] = hi[k];
+		n.first = 0, n.count = count, n.left = n.right = -1;
+		B.counters[0] = 1;
+	}
+}
+
+struct SweepBox { // aabb of template/precomp.h as FindBestSplitPlane uses it
+	float lo[3], hi[3];
+	__device__ __forceinline__ void reset() { for (int k = 0; k < 3; k++) lo[k] = 1e30f, hi[k] = -1e30f; }
+	__device__ __forceinline__ void grow(const float* blo, const float* bhi) // aabb::grow(const aabb&): skipped for an untouched box
+	{
+		if (blo[0] != 1e30f) {
+			for (int k = 0; k < 3; k++) { lo[k] = t_fminf(lo[k], blo[k]); hi[k] = t_fmaxf(hi[k], blo[k]); }
+			for (int k = 0; k < 3; k++) { lo[k] = t_fminf(lo[k], bhi[k]); hi[k] = t_fmaxf(hi[k], bhi[k]); }
+		}
+	}
+	__device__ __forceinline__ float area() const { const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2]; return ex * ey + ey * ez + ez * ex; }
+};
+
+// Subdivide (bvh.cpp:223-333) for every open node of one level: one wave per node
+__global__ void __launch_bounds__(64) k_build_level(BuildArrays B, const int* open, int* next)
+{
+	__shared__ float binLo[RT_BUILD_BINS * 3][64], binHi[RT_BUILD_BINS * 3][64]; // [bin * 3 + axis of the box][lane]: private columns
+	__shared__ int binCnt[RT_BUILD_BINS][64];
+	__shared__ float redLo[RT_BUILD_BINS * 3], redHi[RT_BUILD_BINS * 3];
+	__shared__ int redCnt[RT_BUILD_BINS];
+	const uint lane = threadIdx.x;
+	const int id = open[blockIdx.x];
+	const TNode node = B.nodes[id];
+	const uint first = node.first, count = node.count;
+
+	// ---- FindBestSplitPlane (bvh.cpp:116-193) ----
+	float bestCost = 1e30f, splitPos = 0;
+	int axis = 0;
+	for (int a = 0; a < 3; a++) {
+		float mn = 1e30f, mx = -1e30f;
+		for (uint i = lane; i < count; i += 64) {
+			const float4 c4 = B.cen[B.idx[first + i]];
+			const float c = a == 0 ? c4.x : (a == 1 ? c4.y : c4.z);
+			mn = fminf(mn, c), mx = fmaxf(mx, c);
+		}
+		mn = wave_min(mn), mx = wave_max(mx);
+		if (mn == mx) continue;
+		float scale = RT_BUILD_BINS / (mx - mn);
+		for (int b = 0; b < RT_BUILD_BINS; b++) {
+			binCnt[b][lane] = 0;
+			for (int k = 0; k < 3; k++) binLo[b * 3 + k][lane] = 1e30f, binHi[b * 3 + k][lane] = -1e30f;
+		}
+		for (uint i = lane; i < count; i += 64) {
+			const uint p = B.idx[first + i];
+			const float4 c4 = B.cen[p];
+			const float c = a == 0 ? c4.x : (a == 1 ? c4.y : c4.z);
+			int b = f2i((c - mn) * scale);
+			b = b < RT_BUILD_BINS - 1 ? b : RT_BUILD_BINS - 1; // std::min(BINS - 1, ...)
+			if (b < 0) { B.counters[2] = 1; b = 0; }
+			const float4 l = B.blo[p], h = B.bhi[p];
+			binCnt[b][lane]++;
+			binLo[b * 3 + 0][lane] = fminf(binLo[b * 3 + 0][lane], l.x), binHi[b * 3 + 0][lane] = fmaxf(binHi[b * 3 + 0][lane], h.x);
+			binLo[b * 3 + 1][lane] = fminf(binLo[b * 3 + 1][lane], l.y), binHi[b * 3 + 1][lane] = fmaxf(binHi[b * 3 + 1][lane], h.y);
+			binLo[b * 3 + 2][lane] = fminf(binLo[b * 3 + 2][lane], l.z), binHi[b * 3 + 2][lane] = fmaxf(binHi[b * 3 + 2][lane], h.z);
+		}
+		__syncthreads();
+		if (lane < RT_BUILD_BINS * 3) {
+			float l = 1e30f, h = -1e30f;
+			for (int t = 0; t < 64; t++) l = fminf(l, binLo[lane][t]), h = fmaxf(h, binHi[lane][t]);
+			redLo[lane] = l, redHi[lane] = h;
+		}
+		if (lane >= 32 && lane < 32 + RT_BUILD_BINS) {
+			int s = 0;
+			for (int t = 0; t < 64; t++) s += binCnt[lane - 32][t];
+			redCnt[lane - 32] = s;
+		}
+		__syncthreads();
+		if (lane == 0) {
+			float leftArea[RT_BUILD_BINS - 1], rightArea[RT_BUILD_BINS - 1];
+			int leftCount[RT_BUILD_BINS - 1], rightCount[RT_BUILD_BINS - 1];
+			SweepBox leftBox, rightBox;
+			leftBox.reset(), rightBox.reset();
+			int leftSum = 0, rightSum = 0;
+			for (int i = 0; i < RT_BUILD_BINS - 1; i++) {
+				leftSum += redCnt[i];
+				leftCount[i] = leftSum;
+				leftBox.grow(&redLo[i * 3], &redHi[i * 3]);
+				leftArea[i] = leftBox.area();
+				rightSum += redCnt[RT_BUILD_BINS - 1 - i];
+				rightCount[RT_BUILD_BINS - 2 - i] = rightSum;
+				rightBox.grow(&redLo[(RT_BUILD_BINS - 1 - i) * 3], &redHi[(RT_BUILD_BINS - 1 - i) * 3]);
+				rightArea[RT_BUILD_BINS - 2 - i] = rightBox.area();
+			}
+			scale = (mx - mn) / RT_BUILD_BINS;
+			for (int i = 0; i < RT_BUILD_BINS - 1; i++) {
+				const float planeCost = leftCount[i] * leftArea[i] + rightCount[i] * rightArea[i];
+				if (planeCost < bestCost) axis = a, splitPos = mn + scale * (i + 1), bestCost = planeCost;
+			}
+		}
+		__syncthreads();
+	}
+	bestCost = __shfl(bestCost, 0), splitPos = __shfl(splitPos, 0), axis = __shfl(axis, 0);
+	// CalculateNodeCost (bvh.cpp:196-200)
+	const float ex = node.hi[0] - node.lo[0], ey = node.hi[1] - node.lo[1], ez = node.hi[2] - node.lo[2];
+	const float nosplitCost = count * (ex * ey + ey * ez + ez * ex);
+	if (bestCost >= nosplitCost) return; // stays a leaf, primitiveIdx untouched
+
+	// ---- the partition loop (bvh.cpp:296-313) in closed form ----
+	auto isLeft = [&](uint p) { const float4 c4 = B.cen[p]; return (axis == 0 ? c4.x : (axis == 1 ? c4.y : c4.z)) < splitPos; };
+	int nL = 0;
+	for (uint i0 = 0; i0 < count; i0 += 64) {
+		const uint i = i0 + lane;
+		nL += i < count && isLeft(B.idx[first + i]) ? 1 : 0;
+	}
+	nL = wave_sum(nL);
+	// holes, front to back
+	int K = 0;
+	for (uint i0 = 0; i0 < (uint)nL; i0 += 64) {
+		const uint i = i0 + lane;
+		const int hole = i < (uint)nL && !isLeft(B.idx[first + i]) ? 1 : 0;
+		const int k = K + wave_excl(hole, lane);
+		if (hole) B.hpos[first + k] = i;
+		K += wave_sum(hole);
+	}
+	// fillers, back to front
+	int F = 0;
+	for (uint j0 = 0; j0 < count - (uint)nL; j0 += 64) {
+		const uint j = j0 + lane; // distance from the right end
+		const bool in = j < count - (uint)nL;
+		const uint q = count - 1 - j;
+		const int fill = in && isLeft(B.idx[first + q]) ? 1 : 0;
+		const int k = F + wave_excl(fill, lane);
+		if (fill) B.fpos[first + k] = q;
+		F += wave_sum(fill);
+	}
+	__syncthreads(); // one wave per block: orders the hpos / fpos writes before the reads below
+	const uint fK = K > 0 ? B.fpos[first + K - 1] : count;
+	int holesSeen = 0, fillersSeen = 0;
+	for (uint i0 = 0; i0 < count; i0 += 64) {
+		const uint i = i0 + lane;
+		const bool in = i < count;
+		const uint p = in ? B.idx[first + i] : 0;
+		const bool L = in && isLeft(p);
+		const int hole = in && i < (uint)nL && !L ? 1 : 0;
+		const int fill = in && i >= (uint)nL && L ? 1 : 0;
+		const int hk = holesSeen + wave_excl(hole, lane);
+		const int fk = K - 1 - (fillersSeen + wave_excl(fill, lane));
+		if (in) {
+			uint dest;
+			if (i < (uint)nL) dest = L ? i : (hk == 0 ? count : B.fpos[first + hk - 1]) - 1;
+			else if (L) dest = B.hpos[first + fk];
+			else dest = i > fK ? i - 1 : (i == (uint)nL ? fK - 1 : i - 1);
+			B.tmp[first + dest] = p;
+		}
+		holesSeen += wave_sum(hole), fillersSeen += wave_sum(fill);
+	}
+	__syncthreads();
+	for (uint i = lane; i < count; i += 64) B.idx[first + i] = B.tmp[first + i];
+	__syncthreads();
+	if (nL == 0 || nL == (int)count) return; // a leaf after all, with its primitiveIdx range permuted (bvh.cpp:315)
+
+	// ---- children (bvh.cpp:317-330) ----
+	float alo[3], ahi[3], blo[3], bhi[3];
+	range_bounds(B, first, (uint)nL, lane, alo, ahi);
+	range_bounds(B, first + (uint)nL, count - (uint)nL, lane, blo, bhi);
+	if (lane == 0) {
+		const int c = atomicAdd(&B.counters[0], 2);
+		TNode& l = B.nodes[c];
+		TNode& r = B.nodes[c + 1];
+		for (int k = 0; k < 3; k++) l.lo[k] = alo[k], l.hi[k] = ahi[k], r.lo[k] = blo[k], r.hi[k] = bhi[k];
+		l.first = first, l.count = (uint)nL, l.left = l.right = -1;
+		r.first = first + (uint)nL, r.count = count - (uint)nL, r.left = r.right = -1;
+		B.nodes[id].left = c, B.nodes[id].right = c + 1;
+		const int o = atomicAdd(&B.counters[1], 2);
+		next[o] = c, next[o + 1] = c + 1;
+	}
+}
+
+} // namespace rtd

@@ -23,7 +23,8 @@ COUNTER_NAMES = ["inner_visits", "prim_tests", "tlas_inner", "instance_visits",
 RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_set_camera", "rt_set_time",
               "rt_render", "rt_render_rows", "rt_clear", "rt_download_accumulator", "rt_resolve", "rt_accumulator_device_ptr",
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
-              "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize"]
+              "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
+              "rt_build_bvh"]
 
 
 class RtCamera(C.Structure):
@@ -40,6 +41,10 @@ class RtProfile(C.Structure):
                 ("connect", RtKernelTime), ("query", RtKernelTime)]
 
 
+RT_TRIANGLE_DTYPE = np.dtype([("v0", np.float32, 3), ("v1", np.float32, 3), ("v2", np.float32, 3), ("N", np.float32, 3), ("obj_idx", np.int32), ("material", np.int32)])
+RT_SPHERE_DTYPE = np.dtype([("pos", np.float32, 3), ("r2", np.float32), ("invr", np.float32), ("r", np.float32), ("obj_idx", np.int32), ("material", np.int32)])
+RT_PLANE_DTYPE = np.dtype([("N", np.float32, 3), ("d", np.float32), ("obj_idx", np.int32), ("material", np.int32)])
+RT_BVH_NODE_DTYPE = np.dtype([("aabb_min", np.float32, 3), ("left_first", np.uint32), ("aabb_max", np.float32, 3), ("prim_count", np.uint32)])
 RT_HIT_DTYPE = np.dtype([("t", np.float32), ("obj_idx", np.int32), ("material", np.int32), ("normal", np.float32, 3)])
 
 
@@ -85,6 +90,7 @@ def rt_lib():
         L.rt_primary_hits.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         L.rt_trace_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
+        L.rt_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.rt_get_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -369,6 +375,27 @@ class HostRenderer:
         tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
         self._rt(self.rt.rt_occluded_batch(self.ctx, len(O), _p(O), _p(D), tm, _p(out)))
         return out
+
+    def build_bvh(self, tri_v9=None, spheres=None, planes=None):
+        """rt_build_bvh: the reference's binned-SAH bvh::Build on the device.  tri_v9: (n, 9) vertices,
+        spheres: (n, 4) pos + r, planes: (n, 4) N + d.  Returns (nodes[:nodes_used] as an (n, 8) uint32 view
+        like the oracle's dump, prim_idx)."""
+        tv = np.zeros((0, 9), np.float32) if tri_v9 is None else np.ascontiguousarray(tri_v9, dtype=np.float32).reshape(-1, 9)
+        sp = np.zeros((0, 4), np.float32) if spheres is None else np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+        pl = np.zeros((0, 4), np.float32) if planes is None else np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 4)
+        T = np.zeros(len(tv), dtype=RT_TRIANGLE_DTYPE)
+        T["v0"], T["v1"], T["v2"] = tv[:, 0:3], tv[:, 3:6], tv[:, 6:9]
+        S = np.zeros(len(sp), dtype=RT_SPHERE_DTYPE)
+        S["pos"], S["r"] = sp[:, :3], sp[:, 3]
+        P = np.zeros(len(pl), dtype=RT_PLANE_DTYPE)
+        P["N"], P["d"] = pl[:, :3], pl[:, 3]
+        n = len(T) + len(S) + len(P)
+        nodes = np.zeros(2 * (n + 1), dtype=RT_BVH_NODE_DTYPE)
+        prim = np.zeros(max(n, 1), dtype=np.uint32)
+        used = C.c_uint32(0)
+        self._rt(self.rt.rt_build_bvh(self.ctx, _p(T) if len(T) else None, len(T), _p(S) if len(S) else None, len(S),
+                                      _p(P) if len(P) else None, len(P), _p(nodes), _p(prim), C.byref(used)))
+        return nodes[:used.value].view(np.uint32).reshape(-1, 8).copy(), prim[:n].copy()
 
     def primary_hits(self, t_min=1e-6):
         obj = np.zeros((self.hgt, self.w), dtype=np.int32)

@@ -600,3 +600,101 @@ def test_sample_pools_on_separate_streams(scenes, oracle_api, host_api, monkeypa
         r.close()
     assert np.isfinite(frames[0][..., :3]).mean() > 0.5
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+
+
+# ---- rt_build_bvh: bvh::Build (binned SAH) on the device, SURVEY.md section 8f N1 ----------------------
+
+class _Recorder:
+    """Scene-builder protocol front that forwards to an OracleScene and keeps the spheres and planes."""
+
+    def __init__(self, o):
+        self.o, self.spheres, self.planes, self.meshes = o, [], [], []
+
+    def __getattr__(self, name):
+        return getattr(self.o, name)
+
+    def sphere(self, idx, mat, pos, r):
+        self.spheres.append(list(pos) + [r])
+        return self.o.sphere(idx, mat, pos, r)
+
+    def plane(self, idx, mat, N, d):
+        self.planes.append(list(N) + [d])
+        return self.o.plane(idx, mat, N, d)
+
+    def mesh_obj(self, *a, **k):
+        m = self.o.mesh_obj(*a, **k)
+        self.meshes.append(m)
+        return m
+
+    def mesh_tri(self, *a, **k):
+        m = self.o.mesh_tri(*a, **k)
+        self.meshes.append(m)
+        return m
+
+    def mesh_raw(self, *a, **k):
+        m = self.o.mesh_raw(*a, **k)
+        self.meshes.append(m)
+        return m
+
+
+def _same_tree(got, ref):
+    nodes, prim = got
+    assert len(nodes) == ref["nodes_used"]
+    assert np.array_equal(prim, ref["prim_idx"])
+    keep = np.ones(len(nodes), dtype=bool)
+    keep[1] = False  # node 1 is never allocated (Q4)
+    assert np.array_equal(nodes[keep], ref["nodes"][:ref["nodes_used"]][keep])
+
+
+@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("scene3", {"force_diffuse": False, "split": 0}), ("background", {}), ("tower", {})])
+def test_device_build_equals_reference_build_scene(name, kw, scenes, oracle_api, host_api):
+    """Scene bvh over triangles + spheres + planes: the device builder must return the tree the oracle's
+    restatement of bvh::Build returns, bit for bit (numbering, boxes, primitiveIdx)."""
+    o = oracle_api.OracleScene()
+    rec = _Recorder(o)
+    scenes.REGISTRY[name](rec, **kw)
+    ref = o.bvh_dump(-1)
+    tris = [o.mesh_tris(m)[0][:, :9] for m in rec.meshes]
+    tv = np.concatenate(tris) if tris else np.zeros((0, 9), np.float32)
+    assert len(tv) == ref["NTri"] and len(rec.spheres) == ref["NSph"] and len(rec.planes) == ref["NPla"]
+    r = host_api.HostRenderer(8, 8)
+    _same_tree(r.build_bvh(tv, rec.spheres or None, rec.planes or None), ref)
+    r.close()
+
+
+@pytest.mark.parametrize("mesh", ["unity", "BigB", "lowBigB"])
+def test_device_build_equals_reference_build_mesh(mesh, scenes, oracle_api, host_api):
+    """The BLAS of a mesh (bvh(Mesh*)): 12,584 / 11,830 triangles, ~24 levels."""
+    o = oracle_api.OracleScene()
+    scenes.REGISTRY["tlas_test2"](o, mesh=mesh) if mesh != "unity" else scenes.REGISTRY["pretty_tlas"](o, n_instances=2)
+    ref = o.bvh_dump(0)
+    tv = o.mesh_tris(0)[0][:, :9]
+    r = host_api.HostRenderer(8, 8)
+    if not np.isfinite(tv).all():
+        with pytest.raises(RuntimeError):
+            r.build_bvh(tv)
+    else:
+        _same_tree(r.build_bvh(tv), ref)
+    r.close()
+
+
+def test_device_build_degenerate_inputs(oracle_api, host_api):
+    """Equal centroids (no split plane), one / two primitives, all primitives on one side of every plane,
+    and the refusals."""
+    r = host_api.HostRenderer(8, 8)
+    rng = np.random.default_rng(3)
+    for tv in (rng.uniform(-1, 1, (1, 9)), rng.uniform(-1, 1, (2, 9)), np.tile(rng.uniform(-1, 1, (1, 9)), (40, 1)),
+               np.concatenate([np.tile(rng.uniform(-1, 1, (1, 9)), (30, 1)), rng.uniform(5, 6, (1, 9))]),
+               rng.uniform(-3, 3, (5000, 9)), rng.normal(size=(777, 9)) * np.array([10, 0.01, 1] * 3)):
+        tv = tv.astype(np.float32)
+        o = oracle_api.OracleScene()
+        m = o.mesh_raw(1, o.diffuse(0.8, (1, 1, 1)), tv)
+        o.build(0)
+        _same_tree(r.build_bvh(tv), o.bvh_dump(-1))
+    with pytest.raises(RuntimeError):
+        r.build_bvh(None, None, [[0, 1, 0, 1]])  # planes only
+    bad = rng.uniform(-1, 1, (10, 9)).astype(np.float32)
+    bad[3, 4] = np.nan
+    with pytest.raises(RuntimeError):
+        r.build_bvh(bad)
+    r.close()

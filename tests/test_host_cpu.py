@@ -159,3 +159,56 @@ def test_scene_file_errors(tmp_path, host_api):
     with pytest.raises(RuntimeError):
         host_api.HostScene().load_file(str(bad))
     s.close()
+
+
+def test_partition_closed_form_equals_the_loop():
+    """csrc/rt_build.h replaces the reference's in-place partition loop (bvh.cpp:296-313) by a closed form
+    for where every element ends up; this checks that form against the loop itself on random arrays."""
+    import random
+
+    def loop(a, is_left):
+        a = list(a)
+        i, j = 0, len(a) - 1
+        while i <= j:
+            if is_left[a[i]]:
+                i += 1
+            else:
+                a[i], a[j] = a[j], a[i]
+                j -= 1
+        return a, i
+
+    def closed_form(a, is_left):
+        n = len(a)
+        L = [is_left[x] for x in a]
+        n_l = sum(L)
+        holes = [p for p in range(n_l) if not L[p]]
+        fillers = [q for q in range(n - 1, n_l - 1, -1) if L[q]]
+        k_total = len(holes)
+        assert k_total == len(fillers)
+        f_last = fillers[-1] if k_total else n
+        out = [None] * n
+        seen_h = seen_f = 0
+        for i in range(n):
+            if i < n_l:
+                if L[i]:
+                    d = i
+                else:
+                    d = (n if seen_h == 0 else fillers[seen_h - 1]) - 1
+                    seen_h += 1
+            elif L[i]:
+                d = holes[k_total - 1 - seen_f]
+                seen_f += 1
+            else:
+                d = i - 1 if i > f_last else (f_last - 1 if i == n_l else i - 1)
+            assert out[d] is None
+            out[d] = a[i]
+        return out, n_l
+
+    rnd = random.Random(11)
+    for _ in range(20000):
+        n = rnd.randint(0, 40)
+        a = list(range(n))
+        rnd.shuffle(a)
+        p = rnd.random()
+        is_left = {x: rnd.random() < p for x in a}
+        assert loop(a, is_left) == closed_form(a, is_left)
