@@ -625,28 +625,36 @@ int rt_build_bvh(rt_ctx* c, const rt_triangle* tris, uint32_t n_tri, const rt_sp
 	HIPCHK(c, dalloc(tmp, &B.hpos, M));
 	HIPCHK(c, dalloc(tmp, &B.fpos, M));
 	HIPCHK(c, dalloc(tmp, &B.nodes, (size_t)2 * M + 2));
-	HIPCHK(c, dalloc(tmp, &B.counters, 4));
+	HIPCHK(c, dalloc(tmp, &B.counters, 8));
 	HIPCHK(c, dalloc(tmp, &openA, (size_t)2 * M + 2));
 	HIPCHK(c, dalloc(tmp, &openB, (size_t)2 * M + 2));
 	static_assert(sizeof(rt_triangle) == 56 && sizeof(rt_sphere) == 32, "primitive layouts of rt_amd.h");
 	if (n_tri) HIPCHK(c, hipMemcpyAsync(dTri, tris, (size_t)n_tri * sizeof(rt_triangle), hipMemcpyHostToDevice, c->stream));
 	if (n_sph) HIPCHK(c, hipMemcpyAsync(dSph, spheres, (size_t)n_sph * sizeof(rt_sphere), hipMemcpyHostToDevice, c->stream));
-	HIPCHK(c, hipMemsetAsync(B.counters, 0, 4 * sizeof(int), c->stream));
-	const int zero = 0;
-	HIPCHK(c, hipMemcpyAsync(openA, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipMemsetAsync(B.counters, 0, 8 * sizeof(int), c->stream));
+	const int rootList[1] = { 0 }, one = 1;
+	HIPCHK(c, hipMemcpyAsync(openA, rootList, sizeof(int), hipMemcpyHostToDevice, c->stream));
 	hipLaunchKernelGGL(k_build_prep, dim3((M + 255) / 256), dim3(256), 0, c->stream, dTri, 14, (int)n_tri, dSph, 8, (int)n_sph, B);
-	hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, c->stream, B, M);
-	int nOpen = 1, host[4] = { 0, 0, 0, 0 };
+	hipLaunchKernelGGL(k_build_root, dim3(1), dim3(RT_BUILD_THREADS), 0, c->stream, B, M);
+	HIPCHK(c, hipMemcpyAsync(B.counters + 4, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+	// Levels are launched in groups without looking at the device: a level's launch covers the most nodes the
+	// level can hold (2^level, at most M) and its surplus blocks return at once; the open count is read back
+	// after each group.
+	int host[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	int *open = openA, *next = openB;
-	for (uint level = 0; nOpen > 0; level++) {
-		if (level > M + 2) return fail(c, RT_E_STATE, "rt_build_bvh: more levels than primitives");
-		HIPCHK(c, hipMemsetAsync(B.counters + 1, 0, sizeof(int), c->stream));
-		hipLaunchKernelGGL(k_build_level, dim3((unsigned)nOpen), dim3(64), 0, c->stream, B, open, next);
-		HIPCHK(c, hipMemcpyAsync(host, B.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+	int level = 0;
+	for (bool done = false; !done;) {
+		for (int g = 0; g < 16 && (uint)level <= M + 2; g++, level++) { // a tree over M primitives has at most M levels
+			const unsigned cap = level < 31 && (1u << level) < M ? (1u << level) : M;
+			hipLaunchKernelGGL(k_build_level, dim3(cap), dim3(RT_BUILD_THREADS), 0, c->stream, B, open, next, level);
+			hipLaunchKernelGGL(k_build_advance, dim3(1), dim3(1), 0, c->stream, B, level);
+			std::swap(open, next);
+		}
+		HIPCHK(c, hipMemcpyAsync(host, B.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		if (host[2]) return fail(c, RT_E_UNSUPPORTED, "rt_build_bvh: non-finite vertex, centre or radius (the reference's NaN-order-dependent min / max stay on the host)");
-		nOpen = host[1];
-		std::swap(open, next);
+		done = host[4 + (level & 1)] == 0;
+		if (!done && (uint)level > M + 2) return fail(c, RT_E_STATE, "rt_build_bvh: more levels than primitives");
 	}
 	HIPCHK(c, hipGetLastError());
 	const int nT = host[0];

@@ -3,7 +3,7 @@
 // reference's -- node numbering, boxes, primitiveIdx order -- because the stored boxes and the leaf order
 // decide which primitive a ray reports, so this is a restatement of the same arithmetic, reorganised:
 //
-//   * level by level instead of depth first: every open node of a level is subdivided by one wave; the
+//   * level by level instead of depth first: every open node of a level is subdivided by one block; the
 //     depth-first numbering (children pairs are allocated in the order Subdivide reaches their parents) is
 //     restored at the end from the tree's shape;
 //   * centroid bounds, bin counts and bin boxes are min / max / integer sums: any order gives the same bits
@@ -42,7 +42,7 @@ struct BuildArrays {
 	uint* hpos;   // holes / fillers of the node being partitioned, at the node's own range
 	uint* fpos;
 	TNode* nodes;
-	int* counters; // [0] nodes used, [1] open nodes of the next level, [2] error flag
+	int* counters; // [0] nodes used, [2] error flag, [4] / [5] open nodes of the even / odd levels
 };
 
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
@@ -53,6 +53,43 @@ __device__ __forceinline__ int wave_excl(int v, uint lane) // exclusive prefix s
 	int incl = v;
 	for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
 	return incl - v;
+}
+#define RT_BUILD_THREADS 256 // threads that subdivide one node
+#define RT_BUILD_WAVES (RT_BUILD_THREADS / 64)
+// block-wide reductions over RT_BUILD_THREADS threads ('sh': RT_BUILD_WAVES words of LDS per call site)
+__device__ __forceinline__ float block_min(float v, float* sh)
+{
+	v = wave_min(v);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+	__syncthreads();
+	float r = sh[0];
+	for (int w = 1; w < RT_BUILD_WAVES; w++) r = fminf(r, sh[w]);
+	__syncthreads();
+	return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh)
+{
+	v = wave_max(v);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+	__syncthreads();
+	float r = sh[0];
+	for (int w = 1; w < RT_BUILD_WAVES; w++) r = fmaxf(r, sh[w]);
+	__syncthreads();
+	return r;
+}
+// exclusive prefix sum over the block and the block's total
+__device__ __forceinline__ int block_excl(int v, int* sh, int& total)
+{
+	const uint lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int inWave = wave_excl(v, lane);
+	const int ws = wave_sum(v);
+	if (lane == 0) sh[wave] = ws;
+	__syncthreads();
+	int before = 0;
+	total = 0;
+	for (int w = 0; w < RT_BUILD_WAVES; w++) { if (w < (int)wave) before += sh[w]; total += sh[w]; }
+	__syncthreads();
+	return before + inWave;
 }
 __device__ __forceinline__ bool finite3(const float* v) { return fabsf(v[0]) < 1e30f && fabsf(v[1]) < 1e30f && fabsf(v[2]) < 1e30f; }
 
@@ -88,25 +125,25 @@ __global__ void k_build_prep(const float* tris, int triStride, int nTri, const f
 	B.idx[i] = (uint)i;
 }
 
-// UpdateNodeBounds over a range of primitiveIdx (bvh.cpp:67-114), one wave
-__device__ __forceinline__ void range_bounds(const BuildArrays& B, uint first, uint count, uint lane, float* lo, float* hi)
+// UpdateNodeBounds over a range of primitiveIdx (bvh.cpp:67-114), one block
+__device__ __forceinline__ void range_bounds(const BuildArrays& B, uint first, uint count, float* sh, float* lo, float* hi)
 {
 	float l[3] = { 1e30f, 1e30f, 1e30f }, h[3] = { -1e30f, -1e30f, -1e30f };
-	for (uint i = lane; i < count; i += 64) {
+	for (uint i = threadIdx.x; i < count; i += RT_BUILD_THREADS) {
 		const uint p = B.idx[first + i];
 		const float4 a = B.nlo[p], b = B.nhi[p];
 		l[0] = fminf(l[0], a.x), l[1] = fminf(l[1], a.y), l[2] = fminf(l[2], a.z);
 		h[0] = fmaxf(h[0], b.x), h[1] = fmaxf(h[1], b.y), h[2] = fmaxf(h[2], b.z);
 	}
-	for (int k = 0; k < 3; k++) lo[k] = wave_min(l[k]), hi[k] = wave_max(h[k]);
+	for (int k = 0; k < 3; k++) lo[k] = block_min(l[k], sh), hi[k] = block_max(h[k], sh);
 }
 
-__global__ void k_build_root(BuildArrays B, uint count)
+__global__ void __launch_bounds__(RT_BUILD_THREADS) k_build_root(BuildArrays B, uint count)
 {
-	const uint lane = threadIdx.x & 63;
+	__shared__ float shf[RT_BUILD_WAVES];
 	float lo[3], hi[3];
-	range_bounds(B, 0, count, lane, lo, hi);
-	if (lane == 0) {
+	range_bounds(B, 0, count, shf, lo, hi);
+	if (threadIdx.x == 0) {
 		TNode& n = B.nodes[0];
 		for (int k = 0; k < 3; k++) n.lo[k] = lo[k], n.hi[k] = hi[k];
 		n.first = 0, n.count = count, n.left = n.right = -1;
@@ -127,36 +164,41 @@ struct SweepBox { // aabb of template/precomp.h as FindBestSplitPlane uses it
 	__device__ __forceinline__ float area() const { const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2]; return ex * ey + ey * ez + ez * ex; }
 };
 
-// Subdivide (bvh.cpp:223-333) for every open node of one level: one wave per node
-__global__ void __launch_bounds__(64) k_build_level(BuildArrays B, const int* open, int* next)
+// Subdivide (bvh.cpp:223-333) for every open node of one level: one block per node
+__global__ void __launch_bounds__(RT_BUILD_THREADS) k_build_level(BuildArrays B, const int* open, int* next, int level)
 {
-	__shared__ float binLo[RT_BUILD_BINS * 3][64], binHi[RT_BUILD_BINS * 3][64]; // [bin * 3 + axis of the box][lane]: private columns
-	__shared__ int binCnt[RT_BUILD_BINS][64];
+	__shared__ float binLo[RT_BUILD_BINS * 3][RT_BUILD_THREADS], binHi[RT_BUILD_BINS * 3][RT_BUILD_THREADS]; // [bin * 3 + axis of the box][thread]: private columns
+	__shared__ int binCnt[RT_BUILD_BINS][RT_BUILD_THREADS];
 	__shared__ float redLo[RT_BUILD_BINS * 3], redHi[RT_BUILD_BINS * 3];
 	__shared__ int redCnt[RT_BUILD_BINS];
-	const uint lane = threadIdx.x;
+	__shared__ float shf[RT_BUILD_WAVES];
+	__shared__ int shi[RT_BUILD_WAVES];
+	__shared__ float bestS[2];
+	__shared__ int axisS;
+	const uint tid = threadIdx.x;
+	// the open list of a level: counters[4 + (level & 1)] entries, written by the level before
+	if ((int)blockIdx.x >= B.counters[4 + (level & 1)]) return;
 	const int id = open[blockIdx.x];
 	const TNode node = B.nodes[id];
 	const uint first = node.first, count = node.count;
 
 	// ---- FindBestSplitPlane (bvh.cpp:116-193) ----
-	float bestCost = 1e30f, splitPos = 0;
-	int axis = 0;
+	if (tid == 0) bestS[0] = 1e30f, bestS[1] = 0, axisS = 0;
 	for (int a = 0; a < 3; a++) {
 		float mn = 1e30f, mx = -1e30f;
-		for (uint i = lane; i < count; i += 64) {
+		for (uint i = tid; i < count; i += RT_BUILD_THREADS) {
 			const float4 c4 = B.cen[B.idx[first + i]];
 			const float c = a == 0 ? c4.x : (a == 1 ? c4.y : c4.z);
 			mn = fminf(mn, c), mx = fmaxf(mx, c);
 		}
-		mn = wave_min(mn), mx = wave_max(mx);
+		mn = block_min(mn, shf), mx = block_max(mx, shf);
 		if (mn == mx) continue;
 		float scale = RT_BUILD_BINS / (mx - mn);
 		for (int b = 0; b < RT_BUILD_BINS; b++) {
-			binCnt[b][lane] = 0;
-			for (int k = 0; k < 3; k++) binLo[b * 3 + k][lane] = 1e30f, binHi[b * 3 + k][lane] = -1e30f;
+			binCnt[b][tid] = 0;
+			for (int k = 0; k < 3; k++) binLo[b * 3 + k][tid] = 1e30f, binHi[b * 3 + k][tid] = -1e30f;
 		}
-		for (uint i = lane; i < count; i += 64) {
+		for (uint i = tid; i < count; i += RT_BUILD_THREADS) {
 			const uint p = B.idx[first + i];
 			const float4 c4 = B.cen[p];
 			const float c = a == 0 ? c4.x : (a == 1 ? c4.y : c4.z);
@@ -164,24 +206,29 @@ __global__ void __launch_bounds__(64) k_build_level(BuildArrays B, const int* op
 			b = b < RT_BUILD_BINS - 1 ? b : RT_BUILD_BINS - 1; // std::min(BINS - 1, ...)
 			if (b < 0) { B.counters[2] = 1; b = 0; }
 			const float4 l = B.blo[p], h = B.bhi[p];
-			binCnt[b][lane]++;
-			binLo[b * 3 + 0][lane] = fminf(binLo[b * 3 + 0][lane], l.x), binHi[b * 3 + 0][lane] = fmaxf(binHi[b * 3 + 0][lane], h.x);
-			binLo[b * 3 + 1][lane] = fminf(binLo[b * 3 + 1][lane], l.y), binHi[b * 3 + 1][lane] = fmaxf(binHi[b * 3 + 1][lane], h.y);
-			binLo[b * 3 + 2][lane] = fminf(binLo[b * 3 + 2][lane], l.z), binHi[b * 3 + 2][lane] = fmaxf(binHi[b * 3 + 2][lane], h.z);
+			binCnt[b][tid]++;
+			binLo[b * 3 + 0][tid] = fminf(binLo[b * 3 + 0][tid], l.x), binHi[b * 3 + 0][tid] = fmaxf(binHi[b * 3 + 0][tid], h.x);
+			binLo[b * 3 + 1][tid] = fminf(binLo[b * 3 + 1][tid], l.y), binHi[b * 3 + 1][tid] = fmaxf(binHi[b * 3 + 1][tid], h.y);
+			binLo[b * 3 + 2][tid] = fminf(binLo[b * 3 + 2][tid], l.z), binHi[b * 3 + 2][tid] = fmaxf(binHi[b * 3 + 2][tid], h.z);
 		}
 		__syncthreads();
-		if (lane < RT_BUILD_BINS * 3) {
+		// columns -> one value per bin: wave w of the block folds rows w, w + WAVES, ...
+		for (int row = (int)(tid >> 6); row < RT_BUILD_BINS * 3; row += RT_BUILD_WAVES) {
 			float l = 1e30f, h = -1e30f;
-			for (int t = 0; t < 64; t++) l = fminf(l, binLo[lane][t]), h = fmaxf(h, binHi[lane][t]);
-			redLo[lane] = l, redHi[lane] = h;
+			for (int t = (int)(tid & 63); t < RT_BUILD_THREADS; t += 64) l = fminf(l, binLo[row][t]), h = fmaxf(h, binHi[row][t]);
+			l = wave_min(l), h = wave_max(h);
+			if ((tid & 63) == 0) redLo[row] = l, redHi[row] = h;
 		}
-		if (lane >= 32 && lane < 32 + RT_BUILD_BINS) {
-			int s = 0;
-			for (int t = 0; t < 64; t++) s += binCnt[lane - 32][t];
-			redCnt[lane - 32] = s;
+		for (int row = (int)(tid >> 6); row < RT_BUILD_BINS; row += RT_BUILD_WAVES) {
+			int sN = 0;
+			for (int t = (int)(tid & 63); t < RT_BUILD_THREADS; t += 64) sN += binCnt[row][t];
+			sN = wave_sum(sN);
+			if ((tid & 63) == 0) redCnt[row] = sN;
 		}
 		__syncthreads();
-		if (lane == 0) {
+		if (tid == 0) {
+			float bestCost = bestS[0], splitPos = bestS[1];
+			int axis = axisS;
 			float leftArea[RT_BUILD_BINS - 1], rightArea[RT_BUILD_BINS - 1];
 			int leftCount[RT_BUILD_BINS - 1], rightCount[RT_BUILD_BINS - 1];
 			SweepBox leftBox, rightBox;
@@ -202,10 +249,13 @@ __global__ void __launch_bounds__(64) k_build_level(BuildArrays B, const int* op
 				const float planeCost = leftCount[i] * leftArea[i] + rightCount[i] * rightArea[i];
 				if (planeCost < bestCost) axis = a, splitPos = mn + scale * (i + 1), bestCost = planeCost;
 			}
+			bestS[0] = bestCost, bestS[1] = splitPos, axisS = axis;
 		}
 		__syncthreads();
 	}
-	bestCost = __shfl(bestCost, 0), splitPos = __shfl(splitPos, 0), axis = __shfl(axis, 0);
+	__syncthreads();
+	const float bestCost = bestS[0], splitPos = bestS[1];
+	const int axis = axisS;
 	// CalculateNodeCost (bvh.cpp:196-200)
 	const float ex = node.hi[0] - node.lo[0], ey = node.hi[1] - node.lo[1], ez = node.hi[2] - node.lo[2];
 	const float nosplitCost = count * (ex * ey + ey * ez + ez * ex);
@@ -213,44 +263,46 @@ __global__ void __launch_bounds__(64) k_build_level(BuildArrays B, const int* op
 
 	// ---- the partition loop (bvh.cpp:296-313) in closed form ----
 	auto isLeft = [&](uint p) { const float4 c4 = B.cen[p]; return (axis == 0 ? c4.x : (axis == 1 ? c4.y : c4.z)) < splitPos; };
-	int nL = 0;
-	for (uint i0 = 0; i0 < count; i0 += 64) {
-		const uint i = i0 + lane;
-		nL += i < count && isLeft(B.idx[first + i]) ? 1 : 0;
+	int nL = 0, part;
+	for (uint i0 = 0; i0 < count; i0 += RT_BUILD_THREADS) {
+		const uint i = i0 + tid;
+		block_excl(i < count && isLeft(B.idx[first + i]) ? 1 : 0, shi, part);
+		nL += part;
 	}
-	nL = wave_sum(nL);
 	// holes, front to back
 	int K = 0;
-	for (uint i0 = 0; i0 < (uint)nL; i0 += 64) {
-		const uint i = i0 + lane;
+	for (uint i0 = 0; i0 < (uint)nL; i0 += RT_BUILD_THREADS) {
+		const uint i = i0 + tid;
 		const int hole = i < (uint)nL && !isLeft(B.idx[first + i]) ? 1 : 0;
-		const int k = K + wave_excl(hole, lane);
+		const int k = K + block_excl(hole, shi, part);
 		if (hole) B.hpos[first + k] = i;
-		K += wave_sum(hole);
+		K += part;
 	}
 	// fillers, back to front
 	int F = 0;
-	for (uint j0 = 0; j0 < count - (uint)nL; j0 += 64) {
-		const uint j = j0 + lane; // distance from the right end
+	for (uint j0 = 0; j0 < count - (uint)nL; j0 += RT_BUILD_THREADS) {
+		const uint j = j0 + tid; // distance from the right end
 		const bool in = j < count - (uint)nL;
 		const uint q = count - 1 - j;
 		const int fill = in && isLeft(B.idx[first + q]) ? 1 : 0;
-		const int k = F + wave_excl(fill, lane);
+		const int k = F + block_excl(fill, shi, part);
 		if (fill) B.fpos[first + k] = q;
-		F += wave_sum(fill);
+		F += part;
 	}
-	__syncthreads(); // one wave per block: orders the hpos / fpos writes before the reads below
+	__threadfence_block();
+	__syncthreads(); // the hpos / fpos writes above are read by other threads below
 	const uint fK = K > 0 ? B.fpos[first + K - 1] : count;
 	int holesSeen = 0, fillersSeen = 0;
-	for (uint i0 = 0; i0 < count; i0 += 64) {
-		const uint i = i0 + lane;
+	for (uint i0 = 0; i0 < count; i0 += RT_BUILD_THREADS) {
+		const uint i = i0 + tid;
 		const bool in = i < count;
 		const uint p = in ? B.idx[first + i] : 0;
 		const bool L = in && isLeft(p);
 		const int hole = in && i < (uint)nL && !L ? 1 : 0;
 		const int fill = in && i >= (uint)nL && L ? 1 : 0;
-		const int hk = holesSeen + wave_excl(hole, lane);
-		const int fk = K - 1 - (fillersSeen + wave_excl(fill, lane));
+		int holesHere, fillersHere;
+		const int hk = holesSeen + block_excl(hole, shi, holesHere);
+		const int fk = K - 1 - (fillersSeen + block_excl(fill, shi, fillersHere));
 		if (in) {
 			uint dest;
 			if (i < (uint)nL) dest = L ? i : (hk == 0 ? count : B.fpos[first + hk - 1]) - 1;
@@ -258,18 +310,20 @@ __global__ void __launch_bounds__(64) k_build_level(BuildArrays B, const int* op
 			else dest = i > fK ? i - 1 : (i == (uint)nL ? fK - 1 : i - 1);
 			B.tmp[first + dest] = p;
 		}
-		holesSeen += wave_sum(hole), fillersSeen += wave_sum(fill);
+		holesSeen += holesHere, fillersSeen += fillersHere;
 	}
+	__threadfence_block();
 	__syncthreads();
-	for (uint i = lane; i < count; i += 64) B.idx[first + i] = B.tmp[first + i];
+	for (uint i = tid; i < count; i += RT_BUILD_THREADS) B.idx[first + i] = B.tmp[first + i];
+	__threadfence_block();
 	__syncthreads();
 	if (nL == 0 || nL == (int)count) return; // a leaf after all, with its primitiveIdx range permuted (bvh.cpp:315)
 
 	// ---- children (bvh.cpp:317-330) ----
 	float alo[3], ahi[3], blo[3], bhi[3];
-	range_bounds(B, first, (uint)nL, lane, alo, ahi);
-	range_bounds(B, first + (uint)nL, count - (uint)nL, lane, blo, bhi);
-	if (lane == 0) {
+	range_bounds(B, first, (uint)nL, shf, alo, ahi);
+	range_bounds(B, first + (uint)nL, count - (uint)nL, shf, blo, bhi);
+	if (tid == 0) {
 		const int c = atomicAdd(&B.counters[0], 2);
 		TNode& l = B.nodes[c];
 		TNode& r = B.nodes[c + 1];
@@ -277,9 +331,12 @@ __global__ void __launch_bounds__(64) k_build_level(BuildArrays B, const int* op
 		l.first = first, l.count = (uint)nL, l.left = l.right = -1;
 		r.first = first + (uint)nL, r.count = count - (uint)nL, r.left = r.right = -1;
 		B.nodes[id].left = c, B.nodes[id].right = c + 1;
-		const int o = atomicAdd(&B.counters[1], 2);
+		const int o = atomicAdd(&B.counters[4 + ((level + 1) & 1)], 2);
 		next[o] = c, next[o + 1] = c + 1;
 	}
 }
+
+// between two levels: the list just consumed becomes the empty list the level after next appends to
+__global__ void k_build_advance(BuildArrays B, int level) { B.counters[4 + (level & 1)] = 0; }
 
 } // namespace rtd
