@@ -330,6 +330,44 @@ void bvh::Build(bool isQ)
 	Refit();
 }
 
+void bvh::BuildOnDevice(rt_ctx* ctx)
+{
+	if (splitMethod != BINNEDSAH) throw std::runtime_error("bvh::BuildOnDevice: the device builder is the binned SAH only");
+	Builder bl(*this);
+	NTri = bl.nTri, NSph = bl.nSph, NPla = bl.nPla, N = bl.nAll;
+	std::vector<rt_triangle> T(NTri);
+	std::vector<rt_sphere> S(NSph);
+	std::vector<rt_plane> P(NPla);
+	for (uint i = 0; i < NTri; i++) {
+		const Triangle& t = *bl.tri[i];
+		memset(&T[i], 0, sizeof(rt_triangle));
+		memcpy(T[i].v0, &t.v0, 12), memcpy(T[i].v1, &t.v1, 12), memcpy(T[i].v2, &t.v2, 12);
+	}
+	for (uint i = 0; i < NSph; i++) { memset(&S[i], 0, sizeof(rt_sphere)); memcpy(S[i].pos, &bl.sph[i].pos, 12); S[i].r = bl.sph[i].r; }
+	for (uint i = 0; i < NPla; i++) { memset(&P[i], 0, sizeof(rt_plane)); memcpy(P[i].N, &bl.pla[i].N, 12); P[i].d = bl.pla[i].d; }
+	delete[] primitiveIdx;
+	delete[] bvhNode;
+	primitiveIdx = new uint[N ? N : 1];
+	bvhNode = new BVHNode[2 * (N + 1)]();
+	static_assert(sizeof(BVHNode) == sizeof(rt_bvh_node), "BVHNode must match rt_bvh_node");
+	uint32_t used = 0;
+	if (rt_build_bvh(ctx, T.data(), NTri, S.data(), NSph, P.data(), NPla, (rt_bvh_node*)bvhNode, primitiveIdx, &used) != RT_OK)
+		throw std::runtime_error(std::string("bvh::BuildOnDevice: ") + rt_last_error(ctx));
+	nodesUsed = used;
+	// DataCollector::maxTreeDepth analogue: deepest leaf, counted in nodes from the root
+	treeDepth = 0;
+	std::vector<std::pair<uint, int>> walk(1, { rootNodeIdx, 1 });
+	while (!walk.empty()) {
+		const uint n = walk.back().first;
+		const int d = walk.back().second;
+		walk.pop_back();
+		if (d > treeDepth) treeDepth = d;
+		if (!bvhNode[n].isLeaf()) { walk.push_back({ bvhNode[n].leftFirst, d + 1 }); walk.push_back({ bvhNode[n].leftFirst + 1, d + 1 }); }
+	}
+	bounds.grow(bvhNode[rootNodeIdx].aabbMin);
+	bounds.grow(bvhNode[rootNodeIdx].aabbMax);
+}
+
 void bvh::Refit() // bvh.cpp:556-594
 {
 	Builder bl(*this);

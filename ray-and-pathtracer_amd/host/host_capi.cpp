@@ -132,6 +132,7 @@ void rth_set_raytracer(void* h, int rt)
 	if (sc.raytracer != (rt != 0)) sc.toogleRaytracer();
 }
 int rth_get_raytracer(void* h) { return ((RthScene*)h)->sc->raytracer ? 1 : 0; }
+void rth_scene_device_build(void* h, void* ctx) { ((RthScene*)h)->sc->deviceBuild = (rt_ctx*)ctx; }
 int rth_build(void* h, int splitMethod)
 {
 	RthScene* s = (RthScene*)h;

@@ -195,6 +195,9 @@ public:
 	bvh(Mesh* m);
 	~bvh();
 	void Build(bool isQ = false);
+	// Build() through rt_build_bvh (include/rt_amd.h): the same tree, made on the device.  BINNEDSAH only;
+	// throws for what the device builder refuses (no triangle or sphere, non-finite geometry)
+	void BuildOnDevice(rt_ctx* ctx);
 	void Refit();
 	uint rootNodeIdx = 0, nodesUsed = 2, NTri = 0, NSph = 0, NPla = 0, N = 0;
 	uint* primitiveIdx = nullptr;
@@ -269,6 +272,8 @@ public:
 	~Scene();
 	// the default construction path of the reference (template/scene.h:688-716): after filling the
 	// containers call BuildBVH() (new bvh(this); Build) or BuildTLAS() (tlas(bvhList, bvhCount); build)
+	// deviceBuild != nullptr: BuildBVH / BuildTLAS make their BINNEDSAH trees with bvh::BuildOnDevice(deviceBuild)
+	rt_ctx* deviceBuild = nullptr;
 	void BuildBVH(int splitMethod = BINNEDSAH);
 	// instances reference meshes by index; one bvh per distinct mesh (TLASSceneTest2 shares one)
 	void BuildTLAS(const std::vector<int>& meshOfInstance, const std::vector<mat4>& transforms, int splitMethod = BINNEDSAH);

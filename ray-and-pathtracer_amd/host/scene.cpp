@@ -231,7 +231,8 @@ void Scene::BuildBVH(int splitMethod)
 	useTLAS = false;
 	b = new bvh(this);
 	b->splitMethod = splitMethod;
-	b->Build(false);
+	if (deviceBuild && splitMethod == BINNEDSAH) b->BuildOnDevice(deviceBuild);
+	else b->Build(false);
 }
 
 void Scene::BuildTLAS(const std::vector<int>& meshOfInstance, const std::vector<mat4>& transforms, int splitMethod)
@@ -251,7 +252,8 @@ void Scene::BuildTLAS(const std::vector<int>& meshOfInstance, const std::vector<
 		if (!bl) {
 			bl = new bvh(&meshes[mi]);
 			bl->splitMethod = splitMethod;
-			bl->Build();
+			if (deviceBuild && splitMethod == BINNEDSAH) bl->BuildOnDevice(deviceBuild);
+			else bl->Build();
 			blasOwned.push_back(bl);
 		}
 		Transforms[i] = transforms[i];

@@ -197,6 +197,10 @@ class HostScene:
         self.L.rth_mat4_trs(_f3(t), C.c_float(s), C.c_float(rx), C.c_float(ry), C.c_float(rz), _p(out))
         return out
 
+    def device_build(self, ctx):
+        """Build BINNEDSAH trees with rt_build_bvh on the device of 'ctx' (None: on the host again)."""
+        self.L.rth_scene_device_build(self.h, ctx)
+
     def build(self, split=0):
         self._chk(self.L.rth_build(self.h, split))
 

@@ -698,3 +698,28 @@ def test_device_build_degenerate_inputs(oracle_api, host_api):
     with pytest.raises(RuntimeError):
         r.build_bvh(bad)
     r.close()
+
+
+@pytest.mark.parametrize("name,kw,blas", [("mixed_small", {}, -1), ("tlas_test2", {}, 0), ("pretty_tlas", {"n_instances": 3}, 1)])
+def test_host_mirror_builds_on_the_device(name, kw, blas, scenes, oracle_api, host_api):
+    """rapt::Scene with deviceBuild set: BuildBVH / BuildTLAS go through bvh::BuildOnDevice -> rt_build_bvh.
+    Same arrays as the oracle's builder, and the rendered frame is the host-built scene's frame."""
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 64, 40, **kw)
+    r.render(host_api.RT_MODE_WHITTED, 0, 1)
+    want = r.accumulator().copy()
+    r2 = host_api.HostRenderer(64, 40)
+    r2.scene.device_build(r2.ctx)
+    scenes.REGISTRY[name](r2.scene, **kw)
+    ref, got = o.bvh_dump(blas), r2.scene.bvh_dump(blas)
+    assert got["nodes_used"] == ref["nodes_used"] and np.array_equal(got["prim_idx"], ref["prim_idx"])
+    keep = np.ones(ref["nodes_used"], dtype=bool)
+    keep[1] = False
+    assert np.array_equal(got["nodes"][:ref["nodes_used"]][keep], ref["nodes"][:ref["nodes_used"]][keep])
+    assert got["max_depth"] == ref["max_depth"]
+    r2.commit()
+    if "camera" in d:
+        c = d["camera"]
+        r2.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+    r2.render(host_api.RT_MODE_WHITTED, 0, 1)
+    assert np.array_equal(r2.accumulator().view(np.uint32), want.view(np.uint32))
+    r2.close()
