@@ -826,7 +826,7 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 			else hipLaunchKernelGGL(k_extend<false>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
 			prof_end(c, st);
 			prof_begin(c, K_SHADE, st);
-			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
+			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity, round == 0 && Rs[k].finishInline ? 1 : 0);
 			prof_end(c, st);
 			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
 			prof_begin(c, K_CONNECT, st);

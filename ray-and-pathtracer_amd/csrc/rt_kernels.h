@@ -312,7 +312,11 @@ __device__ __forceinline__ void emit_ray(const DScene& S, PathState& P, int buf,
 __device__ __forceinline__ float mode_t_min(int mode) { return mode == 0 ? (float)1e-6 : 0.001f; } // renderer.cpp:24, :131
 
 // Put sample 'sid' of the pool into a slot: seed, jitter, primary ray (renderer.cpp:263-278)
-__device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, const RenderParams& R, PathState& P, int slot, uint sid, int parityOut)
+// depth a fresh sample starts with (renderer.cpp:269 / :278; rt_trace_batch: the caller's)
+__device__ __forceinline__ int start_depth(const RenderParams& R) { return R.customO ? R.customDepth : (R.mode == 0 ? R.maxDepth : 4); }
+// writeWL = false: the caller guarantees that the first shade of this slot runs with 'fresh' set and rebuilds
+// W = (1,1,1,depth) and L = (0,0,0,sid) itself instead of reading them
+__device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, const RenderParams& R, PathState& P, int slot, uint sid, int parityOut, bool writeWL = true)
 {
 	f3 O, D;
 	uint seed = 0;
@@ -338,9 +342,11 @@ __device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, 
 		}
 	}
 	emit_ray(S, P, parityOut, slot, O, D, mode_t_min(R.mode));
-	P.W[slot] = make_float4(1, 1, 1, __int_as_float(depth));
 	P.E[slot] = make_float4(1, 1, 1, __uint_as_float(seed));
-	P.L[slot] = make_float4(0, 0, 0, __uint_as_float(sid));
+	if (writeWL) {
+		P.W[slot] = make_float4(1, 1, 1, __int_as_float(depth));
+		P.L[slot] = make_float4(0, 0, 0, __uint_as_float(sid));
+	}
 	if (P.pendCount) P.pendCount[slot] = 0;
 }
 
@@ -368,7 +374,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DScene S, DCamera C, Rend
 {
 	const int slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= P.nSlots) return;
-	start_sample(S, C, R, P, slot, R.sampleFirst + (uint)slot, 0); // slots take the first nSlots samples of the pool
+	// slots take the first nSlots samples of the pool; with a slot per sample (finishInline) round 0 shades every
+	// slot 'fresh', so the constant W and L are not written here and not read there (64 B per sample)
+	start_sample(S, C, R, P, slot, R.sampleFirst + (uint)slot, 0, !R.finishInline);
 	P.status[slot] = ST_ACTIVE;
 	if (slot == 0) Q.counts[7] = P.nSlots, Q.counts[1] = 0;
 }
@@ -428,7 +436,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, 
 // shade: everything Trace / Sample do at a hit except the occlusion-dependent direct terms.
 // Outcomes per slot: continue with a new ray (next active queue), hand the diffuse direct terms to
 // connect + light (shadow queue), or end the segment (done queue).
-__global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity)
+__global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity, int fresh)
 {
 	const int pout = 1 - parity;
 	const int nActive = Q.counts[0];
@@ -438,7 +446,10 @@ __global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R,
 		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
 			const int2 id = P.hitId[slot];
-			const float4 w4 = P.W[slot], e4 = P.E[slot], l4 = P.L[slot];
+			// fresh: first segment of a sample whose slot index is its sample (k_generate did not write W and L)
+			const float4 e4 = P.E[slot];
+			const float4 w4 = fresh ? make_float4(1, 1, 1, __int_as_float(start_depth(R))) : P.W[slot];
+			const float4 l4 = fresh ? make_float4(0, 0, 0, __uint_as_float(R.sampleFirst + (uint)slot)) : P.L[slot];
 			const f3 O = xyz(o4), D = xyz(d4), normal = xyz(hn);
 			const float t = hn.w;
 			f3 W = xyz(w4), E = xyz(e4), Lsum = xyz(l4);
