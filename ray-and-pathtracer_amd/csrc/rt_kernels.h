@@ -533,8 +533,13 @@ __global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R,
 				}
 			}
 
-			P.E[slot] = mk4(E, __uint_as_float(seed));
-			P.L[slot] = mk4(Lsum, l4.w);
+			// a slot that is finished right here (stored below) is never read again; otherwise E and L go back
+			// only if they changed (a fresh slot's L has never been written)
+			const bool doneHere = R.finishInline && segmentEnds && !wantShadow;
+			if (!doneHere) {
+				if (E.x != e4.x || E.y != e4.y || E.z != e4.z || seed != __float_as_uint(e4.w)) P.E[slot] = mk4(E, __uint_as_float(seed));
+				if (fresh || Lsum.x != l4.x || Lsum.y != l4.y || Lsum.z != l4.z) P.L[slot] = mk4(Lsum, l4.w);
+			}
 			if (wantShadow) {
 				// light keeps working on THIS segment: it needs the segment's own weight and whether the
 				// segment ends there (the continuation's weight goes to P.W below)
