@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 			const bool path = R.mode != 0;
 			const DMaterial m = S.mats[id.y];
 			const f3 col(m.col[0], m.col[1], m.col[2]);
-			const int depth = __float_as_int(P.W[slot].w); // Whitted: depth of this segment (a diffuse hit stores no continuation)
+			const int depth = path ? 0 : __float_as_int(P.W[slot].w); // Whitted: depth of this segment (a diffuse hit stores no continuation)
 			f3 direct(0.0f);
 			for (int i = 0; i < S.nLights; i++) {
 				const f3 pickedPos = xyz(P.sh[(size_t)i * P.nSlots + slot]);
@@ -639,10 +639,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 			} else {
 				Lsum = Lsum + W * direct;
 			}
-			P.E[slot] = mk4(E, e4.w);
-			P.L[slot] = mk4(Lsum, l4.w);
 			const bool endsHere = (stBits & ST_ENDS_AFTER) != 0;
-			if (endsHere && R.finishInline) store_sample(R, __float_as_uint(l4.w), Lsum);
+			if (endsHere && R.finishInline) store_sample(R, __float_as_uint(l4.w), Lsum); // finished: E and L are not read again
+			else {
+				if (E.x != e4.x || E.y != e4.y || E.z != e4.z) P.E[slot] = mk4(E, e4.w);
+				if (Lsum.x != l4.x || Lsum.y != l4.y || Lsum.z != l4.z) P.L[slot] = mk4(Lsum, l4.w);
+			}
 			P.status[slot] = (stBits & ST_ACTIVE) | (endsHere && !R.finishInline ? ST_ENDED : 0);
 		}
 	}
