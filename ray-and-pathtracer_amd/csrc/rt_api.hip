@@ -750,6 +750,7 @@ static int ensure_state(rt_ctx* c, int k, int nSlots, bool pend)
 	for (int b = 0; b < 2; b++) { HIPCHK(c, dalloc(pl.allocs, &P.O[b], n)); HIPCHK(c, dalloc(pl.allocs, &P.D[b], n)); }
 	HIPCHK(c, dalloc(pl.allocs, &P.hitN, n));
 	HIPCHK(c, dalloc(pl.allocs, &P.hitId, n));
+	HIPCHK(c, dalloc(pl.allocs, &P.hitP, n));
 	HIPCHK(c, dalloc(pl.allocs, &P.W, n));
 	HIPCHK(c, dalloc(pl.allocs, &P.E, n));
 	HIPCHK(c, dalloc(pl.allocs, &P.L, n));

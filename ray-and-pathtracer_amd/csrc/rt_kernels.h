@@ -44,6 +44,7 @@ struct PathState {
 	float4* E;       // energy xyz, w = RNG state (uint bits)
 	float4* L;       // radiance of the current sample xyz, w = sample id in the pool (uint bits)
 	float4* sh;      // [light][slot] sampled light position xyz (plane 0: w = flags); plane nLights: weight of the segment
+	float4* hitP;    // ray.IntersectionPoint() of a diffuse hit (written by shade: connect needs nothing else of the ray)
 	unsigned char* vis; // [light][slot] 1: the light is occluded
 	unsigned char* status; // [slot] ST_* bits: what the slot needs this round
 	float4* pend;    // [slot][RT_PEND_CAP][4]: pending Whitted branches {O,depth} {D,-} {W,-} {E,-}
@@ -544,6 +545,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R,
 				// light keeps working on THIS segment: it needs the segment's own weight and whether the
 				// segment ends there (the continuation's weight goes to P.W below)
 				P.sh[(size_t)S.nLights * P.nSlots + slot] = mk4(W, segmentEnds ? 1.0f : 0.0f);
+				P.hitP[slot] = mk4(I, 0.0f);
 			}
 			if (!segmentEnds) {
 				emit_ray(S, P, pout, slot, nO, nD, mode_t_min(R.mode));
@@ -568,8 +570,7 @@ struct ConnectPolicy {
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef&) const
 	{
 		const int slot = (int)queue[work / nLights], li = work % nLights;
-		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
-		const f3 I = xyz(o4) + hn.w * xyz(d4);
+		const f3 I = xyz(P.hitP[slot]); // O + t * D, as shade computed it
 		const f3 pickedPos = xyz(P.sh[(size_t)li * P.nSlots + slot]);
 		f3 lightRayDirection = pickedPos - I;
 		const float len2 = dot(lightRayDirection, lightRayDirection);
