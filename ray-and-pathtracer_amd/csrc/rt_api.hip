@@ -4,6 +4,7 @@
 #include "rt_kernels.h"
 #include "rt_build.h"
 #include "../../include/rt_amd.h"
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -178,7 +179,7 @@ rt_ctx* rt_create(int device, int width, int height)
 		// the traversal kernels give every wave a fixed first chunk of the queue, so their grids must be
 		// fully resident: blocks per CU from the occupancy calculator, per kernel
 		auto resident = [&](const void* fn) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, RT_BLOCK, 0) != hipSuccess || b < 1) b = 1; if (b > 8) b = 8; return b * prop.multiProcessorCount; };
-		const int e0 = resident((const void*)k_extend<false>), e1 = resident((const void*)k_extend<true>);
+		const int e0 = std::min(resident((const void*)k_extend<false, false>), resident((const void*)k_extend<false, true>)), e1 = std::min(resident((const void*)k_extend<true, false>), resident((const void*)k_extend<true, true>));
 		const int c0 = resident((const void*)k_connect<false>), c1 = resident((const void*)k_connect<true>);
 		c->gridExtend = e0 < e1 ? e0 : e1, c->gridConnect = c0 < c1 ? c0 : c1;
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
@@ -820,11 +821,16 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 			rt_ctx::Pool& pl = c->pools[k];
 			const Queues Q = pl.Q;
 			hipStream_t st = pl.stream;
-			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, P[k].pendCount ? 0 : 1);
-			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ACTIVE, Q.active, &Q.counts[0]);
+			// round 0 of a batch with a slot per sample: every slot is ACTIVE, so no queue is built and extend /
+			// shade address slots directly
+			const int allActive = round == 0 && Rs[k].finishInline ? P[k].nSlots : 0;
+			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, P[k].pendCount ? 0 : 1, allActive);
+			if (!allActive) hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ACTIVE, Q.active, &Q.counts[0]);
 			prof_begin(c, K_EXTEND, st);
-			if (c->counting) hipLaunchKernelGGL(k_extend<true>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
-			else hipLaunchKernelGGL(k_extend<false>, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
+			{
+				auto extendKernel = c->counting ? (allActive ? k_extend<true, true> : k_extend<true, false>) : (allActive ? k_extend<false, true> : k_extend<false, false>);
+				hipLaunchKernelGGL(extendKernel, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
+			}
 			prof_end(c, st);
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity, round == 0 && Rs[k].finishInline ? 1 : 0);

@@ -383,15 +383,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DScene S, DCamera C, Rend
 }
 
 // round bookkeeping between kernels: reset the work heads and the queue counts
-__global__ void k_round_begin(Queues Q, int poolFollowsEnded)
+__global__ void k_round_begin(Queues Q, int poolFollowsEnded, int allActive)
 {
 	if (poolFollowsEnded) Q.counts[7] += Q.counts[1]; // k_finish handed out one pool sample per ended slot
-	Q.counts[0] = 0, Q.counts[1] = 0, Q.counts[2] = 0;
+	Q.counts[0] = allActive, Q.counts[1] = 0, Q.counts[2] = 0; // allActive: the number of slots when all are ACTIVE and no queue is built (0 otherwise)
 	for (int h = 0; h < 2 * RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
 }
 
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
 // (renderer.cpp:24, :131); it applies to lights and brute-force primitives, the BVH uses 0.0001.
+template <bool DENSE> // DENSE: every slot is active and the queue is the identity (round 0 with a slot per sample)
 struct ExtendPolicy {
 	const DScene& S;
 	PathState& P;
@@ -399,7 +400,7 @@ struct ExtendPolicy {
 	int parity;
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
 	{
-		const int slot = (int)queue[work];
+		const int slot = DENSE ? work : (int)queue[work];
 		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
 		O = xyz(o4), D = xyz(d4), tmax = o4.w; // o4.w: ray.t after the head tests made when the ray was created
 		unpack_head(__float_as_uint(d4.w), head);
@@ -408,7 +409,7 @@ struct ExtendPolicy {
 	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
 	{
 		// the ray in registers may be the object-space one; the sphere normal needs the world ray
-		const int slot = (int)queue[work];
+		const int slot = DENSE ? work : (int)queue[work];
 		int objIdx, mat;
 		f3 normal;
 		const PathState& Pc = P;
@@ -418,14 +419,14 @@ struct ExtendPolicy {
 		P.hitId[slot] = make_int2(objIdx, mat);
 	}
 };
-template <bool COUNT>
+template <bool COUNT, bool DENSE>
 __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	ExtendPolicy pol{ S, P, Q.active, parity };
+	ExtendPolicy<DENSE> pol{ S, P, Q.active, parity };
 	trace_persistent<false, COUNT, false>(S, pol, Q.counts[0], Q.heads, t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) {
 		// the head tests ran where the rays were created: per ray, every light and every brute-force primitive
@@ -442,7 +443,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R,
 	const int pout = 1 - parity;
 	const int nActive = Q.counts[0];
 	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nActive; e += gridDim.x * blockDim.x) {
-		const int slot = (int)Q.active[e]; // the slots extend just traced, in slot order
+		const int slot = fresh ? e : (int)Q.active[e]; // the slots extend just traced, in slot order (fresh: all of them, no queue)
 		bool keep = false, wantShadow = false, ended = false;
 		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
