@@ -910,7 +910,7 @@ static int slot_budget()
 	// launch drain unevenly, and the longest rays finish alone at memory latency per step (measured
 	// ~0.7 ms per traversal launch, ~1.5 ms per round, on the bench scene).  Fewer, larger rounds win until
 	// every sample of the batch has its own slot: 16M -> 64M -> 128M slots took the 1080p x 64 spp frame
-	// from 97.8 to 79.0 to 76.4 ms.  ~200 B of state per slot: 128M slots = 26 GB of the 288 GB.
+	// from 97.8 to 79.0 to 76.4 ms.  ~216 B of state per slot: 128M slots = 29 GB of the 288 GB.
 	// RT_SLOTS overrides.
 	const char* e = getenv("RT_SLOTS");
 	long v = e ? atol(e) : 0;
