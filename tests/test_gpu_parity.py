@@ -89,6 +89,19 @@ def test_config1_primary_hits(scenes, oracle_api, host_api):
     r.close()
 
 
+@pytest.mark.parametrize("name,kw,w,h", [("pretty_tlas", {"n_instances": 8}, 960, 540), ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 640, 360)])
+def test_primary_hits_at_scale(name, kw, w, h, scenes, oracle_api, host_api):
+    """The bench scene (and the config-5 layout) at a quarter of the bench resolution: objIdx and t of every
+    primary ray, timed kernels (TLAS children the ray cannot reach are skipped) against the oracle's walk."""
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
+    obj_ref, t_ref, _ = orr.primary_hits(0.001)
+    obj, t = r.primary_hits(0.001)
+    assert np.array_equal(obj, obj_ref)
+    assert np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    assert (obj_ref >= 100).mean() > 0.02  # instanced triangles are in view
+    r.close()
+
+
 def check_frames(orr, r, mode, frames, host_api, tol=RADIANCE_TOL):
     orr.scene.set_raytracer(mode == "whitted")
     orr.clear()
