@@ -14,6 +14,8 @@ _LIB = None
 
 COUNTER_NAMES = ["inner_visits", "prim_tests", "tlas_inner", "instance_visits",
                  "rays_nearest", "rays_occluded", "brute_tests", "light_tests"]
+# the oracle also tallies what gprof reported for the reference: Triangle::Intersect calls
+ORACLE_COUNTER_NAMES = COUNTER_NAMES + ["tri_intersect_calls"]
 
 
 def build(force=False):
@@ -24,10 +26,17 @@ def build(force=False):
     return so
 
 
+def build_clang():
+    """The same sources through ROCm's clang++ (tests/test_oracle_cpu.py: both compilers must produce the
+    committed golden vectors bit for bit)."""
+    subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle_clang.so"])
+    return os.path.join(_HERE, "liboracle_clang.so")
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # ORACLE_LIB: another build of the same oracle
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
@@ -167,20 +176,20 @@ class OracleScene:
         obj = np.zeros(n, dtype=np.int32)
         mat = np.zeros(n, dtype=np.int32)
         nrm = np.zeros((n, 3), dtype=np.float32)
-        cnt = np.zeros(8, dtype=np.uint64)
+        cnt = np.zeros(9, dtype=np.uint64)
         tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
         self.L.orc_find_nearest_batch(self.h, n, _p(O), _p(D), tm, C.c_float(t_min), _p(t), _p(obj), _p(mat), _p(nrm), _p(cnt))
-        return dict(t=t, obj=obj, mat=mat, normal=nrm, counters=dict(zip(COUNTER_NAMES, cnt.tolist())))
+        return dict(t=t, obj=obj, mat=mat, normal=nrm, counters=dict(zip(ORACLE_COUNTER_NAMES, cnt.tolist())))
 
     def is_occluded(self, O, D, tmax=None):
         O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
         D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
         n = len(O)
         out = np.zeros(n, dtype=np.uint8)
-        cnt = np.zeros(8, dtype=np.uint64)
+        cnt = np.zeros(9, dtype=np.uint64)
         tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
         self.L.orc_is_occluded_batch(self.h, n, _p(O), _p(D), tm, _p(out), _p(cnt))
-        return dict(occluded=out, counters=dict(zip(COUNTER_NAMES, cnt.tolist())))
+        return dict(occluded=out, counters=dict(zip(ORACLE_COUNTER_NAMES, cnt.tolist())))
 
 
 class OracleRenderer:
@@ -210,10 +219,10 @@ class OracleRenderer:
         self.L.orc_renderer_clear(self.h)
 
     def render(self, frame0=0, nframes=1, seed_base=0x12345678, y0=0, y1=None, nthreads=1, max_depth=4):
-        cnt = np.zeros(8, dtype=np.uint64)
+        cnt = np.zeros(9, dtype=np.uint64)
         self.L.orc_render(self.h, C.c_uint(frame0), nframes, C.c_uint(seed_base), y0, self.hgt if y1 is None else y1,
                           nthreads, max_depth, _p(cnt))
-        return dict(zip(COUNTER_NAMES, cnt.tolist()))
+        return dict(zip(ORACLE_COUNTER_NAMES, cnt.tolist()))
 
     def accumulator(self):
         out = np.zeros((self.hgt, self.w, 4), dtype=np.float32)
@@ -228,9 +237,9 @@ class OracleRenderer:
     def primary_hits(self, t_min=1e-6):
         obj = np.zeros((self.hgt, self.w), dtype=np.int32)
         t = np.zeros((self.hgt, self.w), dtype=np.float32)
-        cnt = np.zeros(8, dtype=np.uint64)
+        cnt = np.zeros(9, dtype=np.uint64)
         self.L.orc_primary_hits(self.h, C.c_float(t_min), _p(obj), _p(t), _p(cnt))
-        return obj, t, dict(zip(COUNTER_NAMES, cnt.tolist()))
+        return obj, t, dict(zip(ORACLE_COUNTER_NAMES, cnt.tolist()))
 
     def primary_rays(self):
         O = np.zeros((self.hgt * self.w, 3), dtype=np.float32)

@@ -216,6 +216,7 @@ static void counters_out(const Counters& c, unsigned long long* out)
 	if (!out) return;
 	out[0] = c.inner_visits, out[1] = c.prim_tests, out[2] = c.tlas_inner, out[3] = c.instance_visits;
 	out[4] = c.rays_nearest, out[5] = c.rays_occluded, out[6] = c.brute_tests, out[7] = c.light_tests;
+	out[8] = c.tri_intersect_calls;
 }
 
 // Scene::FindNearest on n rays (O, D: n*3 floats; tmax: n floats or NULL for 1e34f).

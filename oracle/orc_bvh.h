@@ -363,6 +363,7 @@ struct bvh {
 				for (uint i = 0; i < n.primCount; i++) {
 					leafIntersect(primitiveIdx[n.leftFirst + i], ray, t_min);
 					cnt.prim_tests++;
+					if (primitiveIdx[n.leftFirst + i] < NTri) cnt.tri_intersect_calls++;
 				}
 				if (stackPtr == 0) break; else node = stack[--stackPtr];
 				continue;

@@ -28,11 +28,12 @@ struct Counters {
 	uint64_t rays_occluded = 0;  // Scene::IsOccluded calls
 	uint64_t brute_tests = 0;    // TLAS-mode brute force sphere / plane tests (template/scene.h:1260-1261)
 	uint64_t light_tests = 0;    // light->Intersect calls (template/scene.h:1257)
+	uint64_t tri_intersect_calls = 0; // Triangle::Intersect calls from BIntersect leaves (bvh.cpp:619): the figure gprof reports for the reference
 	void add(const Counters& o)
 	{
 		inner_visits += o.inner_visits; prim_tests += o.prim_tests; tlas_inner += o.tlas_inner;
 		instance_visits += o.instance_visits; rays_nearest += o.rays_nearest; rays_occluded += o.rays_occluded;
-		brute_tests += o.brute_tests; light_tests += o.light_tests;
+		brute_tests += o.brute_tests; light_tests += o.light_tests; tri_intersect_calls += o.tri_intersect_calls;
 	}
 };
 

@@ -80,9 +80,10 @@ def synthetic_sky(width=512, height=256, seed=7):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-def lattice_tower(levels=40, sides=12, seed=3):
+def lattice_tower(levels=160, sides=40, seed=3):
     """Procedural stand-in for the missing eifel.obj: a tapering lattice tower of thin triangular
-    struts.  Returns float32 [n, 9] triangles; n = levels * sides * 8."""
+    struts.  Returns float32 [n, 9] triangles; n = levels * sides * 8 = 51,200 by default (SURVEY.md
+    section 8d asks for a stand-in of 50-200 k triangles)."""
     rng = np.random.default_rng(seed)
     tris = []
     def ring(k):

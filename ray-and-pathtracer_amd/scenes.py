@@ -155,15 +155,18 @@ def config3(b):
     return d
 
 
-def tower_scene(b, rt=True):
+TOWER_TRIANGLES = 51200  # assets.lattice_tower(): 160 levels x 40 sides x 8 triangles
+
+
+def tower_scene(b, rt=True, levels=160, sides=40):
     """BASELINE config 4: instantiateEifelScene (template/scene.h:870-878) with a procedural
-    lattice tower (3,840 triangles) standing in for the missing eifel.obj, and a synthetic sky."""
+    lattice tower (51,200 triangles by default) standing in for the missing eifel.obj, and a synthetic sky."""
     b.sky(assets.synthetic_sky(seed=21))
     light_diff = b.diffuse(0.8, WHITE, 0.6, 0.4, 1200, emission=1.2, rt=rt)
     b.plane(2, light_diff, (0, 1, 0), 1)
     b.area_light(11, (0.1, 7.0, 5.0), 8.0, WHITE, 1.0, (0, -1, 0))
     standard_metal = b.metal(0.7, WHITE, rt=rt)
-    tris = assets.lattice_tower().reshape(-1, 3)
+    tris = assets.lattice_tower(levels, sides).reshape(-1, 3)
     tris = (tris * np.float32(0.8) + np.array([0, -1.0, 5.0], dtype=np.float32)).astype(np.float32).reshape(-1, 9)
     b.mesh_raw(2, standard_metal, tris)
     b.build(BINNEDSAH)
@@ -171,8 +174,9 @@ def tower_scene(b, rt=True):
 
 
 def config4(b):
+    """BASELINE config 4: the 51,200-triangle tower stand-in + synthetic sky, 1920x1080, 256 frames, path mode."""
     d = tower_scene(b)
-    d.update(width=1920, height=1080, mode="path", frames=256)
+    d.update(width=1920, height=1080, mode="path", frames=256, triangles=TOWER_TRIANGLES)
     return d
 
 

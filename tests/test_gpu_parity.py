@@ -89,7 +89,9 @@ def test_config1_primary_hits(scenes, oracle_api, host_api):
     r.close()
 
 
-@pytest.mark.parametrize("name,kw,w,h", [("pretty_tlas", {"n_instances": 8}, 960, 540), ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 640, 360)])
+@pytest.mark.parametrize("name,kw,w,h", [("pretty_tlas", {"n_instances": 8}, 960, 540), ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 640, 360),
+                                         ("bigb_instanced", {"n": 16, "mesh": "BigB"}, 960, 540),  # BASELINE config 5's scene: BigB.obj (11,830 triangles) x 16
+                                         ("tower", {}, 960, 540)])  # BASELINE config 4's scene: the 51,200-triangle stand-in
 def test_primary_hits_at_scale(name, kw, w, h, scenes, oracle_api, host_api):
     """The bench scene (and the config-5 layout) at a quarter of the bench resolution: objIdx and t of every
     primary ray, timed kernels (TLAS children the ray cannot reach are skipped) against the oracle's walk."""
@@ -130,6 +132,8 @@ RENDER_SCENES = [
     ("pretty_tlas", {"n_instances": 4}, 96, 54),
     ("pretty_tlas", {"n_instances": 8}, 240, 135),  # the bench scene (BASELINE config 3) at 1/8 size
     ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 128, 72),  # BASELINE config 5's layout with the small mesh
+    ("bigb_instanced", {"n": 16, "mesh": "BigB"}, 192, 108),  # BASELINE config 5's scene itself (189,280 instanced triangles) at 1/20 size
+    ("tower", {}, 192, 108),  # BASELINE config 4's scene (51,200-triangle stand-in for eifel.obj + synthetic sky) at 1/10 size
 ]
 
 
@@ -278,26 +282,36 @@ def test_edge_cases(scenes, oracle_api, host_api):
     r.close(); r2.close()
 
 
-def test_full_size_properties(scenes, oracle_api, host_api):
-    """1920x1080 (BASELINE size), where the oracle is too slow to run whole frames: determinism,
-    tile-shard equivalence, and oracle parity on a sampled set of rows."""
-    w, h = 1920, 1080
-    o, orr, r, d = make_pair(scenes.pretty_tlas, oracle_api, host_api, w, h, n_instances=8)
+@pytest.mark.parametrize("config", ["config2", "config3", "config4", "config5"])
+def test_full_size_properties(config, scenes, oracle_api, host_api):
+    """Every 1-GPU / multi-GPU BASELINE configuration at its full resolution (1920x1080; config 5: 3840x2160), where the
+    oracle is too slow to run whole frames: run-to-run determinism, two-way shard == whole frame bit for bit
+    (contiguous bands and the interleaved rows the multi-GPU path uses), and oracle parity on five sampled rows."""
+    probe = oracle_api.OracleScene()
+    cfg = scenes.REGISTRY[config](probe)
+    probe.close()
+    w, h = cfg["width"], cfg["height"]
+    o, orr, r, d = make_pair(scenes.REGISTRY[config], oracle_api, host_api, w, h)
     r.clear(); r.render(host_api.RT_MODE_PATH, 0, 2)
     a = r.accumulator()
     r.clear(); r.render(host_api.RT_MODE_PATH, 0, 2)
     assert np.array_equal(a.view(np.uint32), r.accumulator().view(np.uint32))  # run-to-run deterministic
     r.clear()
-    r.render(host_api.RT_MODE_PATH, 0, 2, y0=0, y1=540)
-    r.render(host_api.RT_MODE_PATH, 0, 2, y0=540, y1=1080)
+    r.render(host_api.RT_MODE_PATH, 0, 2, y0=0, y1=h // 2)
+    r.render(host_api.RT_MODE_PATH, 0, 2, y0=h // 2, y1=h)
     assert np.array_equal(a.view(np.uint32), r.accumulator().view(np.uint32))  # two-way shard == whole
-    rows = [0, 333, 540, 777, 1079]
+    r.clear()
+    r.render_rows(host_api.RT_MODE_PATH, 0, 2, 0, 2, (h + 1) // 2)
+    r.render_rows(host_api.RT_MODE_PATH, 0, 2, 1, 2, h // 2)
+    assert np.array_equal(a.view(np.uint32), r.accumulator().view(np.uint32))  # interleaved rows (rank r of 2) == whole
+    rows = [0, h // 3 - 27, h // 2, (3 * h) // 4 - 33, h - 1]
     orr.scene.set_raytracer(False)
     for y in rows:
         orr.render(0, 2, y0=y, y1=y + 1, nthreads=0)
     ref = orr.accumulator()
     err, cls_ok = rel_err(a[rows][..., :3], ref[rows][..., :3])
     assert cls_ok and err.max() <= RADIANCE_TOL
+    assert (ref[rows][..., :3] > 0).mean() > 0.5  # the rows show something
     r.close()
 
 

@@ -33,15 +33,15 @@ def test_rng_against_published_algorithms(oracle_api):
     L = oracle_api.lib()
     # Marsaglia (2003) "Xorshift RNGs", triple (13, 17, 5): from state 2463534242 the next state is 723471715
     assert xorshift32(2463534242) == 723471715
-    for seed in (0, 1, 0x12345678, 0xFFFFFFFE):
-        u = np.zeros(64, np.uint32)
-        f = np.zeros(64, np.float32)
-        L.orc_rng_stream(C.c_uint(seed), 64, u.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p))
+    for seed in (0, 1, 2, 61, 0x12345678, 0xDEADBEEF, 0xFFFFFFFE, 1768515948):
+        u = np.zeros(4096, np.uint32)
+        f = np.zeros(4096, np.float32)
+        L.orc_rng_stream(C.c_uint(seed), 4096, u.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p))
         s = wang(((seed + 1) * 17) & 0xFFFFFFFF) or 0x9E3779B9  # InitSeed (template/template.cpp:680-683), zero state replaced
-        for i in range(64):
+        for i in range(4096):
             s = xorshift32(s)
             assert u[i] == s
-            assert f[i] == np.float32(s) * np.float32(2.3283064365387e-10)
+        assert np.array_equal(f, u.astype(np.float32) * np.float32(2.3283064365387e-10))
         assert np.array_equal(u, GOLD["rng_u_%x" % seed])
         assert np.array_equal(f.view(np.uint32), GOLD["rng_f_%x" % seed].view(np.uint32))
 
@@ -49,16 +49,16 @@ def test_rng_against_published_algorithms(oracle_api):
 def test_hemisphere_fresnel_refract_golden(oracle_api):
     L = oracle_api.lib()
     nrm = GOLD["hemi_normals"]
-    out = np.zeros((64, 3), np.float32)
-    L.orc_hemisphere(C.c_uint(99), 64, nrm.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    out = np.zeros((256, 3), np.float32)
+    L.orc_hemisphere(C.c_uint(99), 256, nrm.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert np.array_equal(out.view(np.uint32), GOLD["hemi_out"].view(np.uint32))
     assert ((out * nrm).sum(1) > 0).all()  # on the normal's side
     assert np.allclose(np.linalg.norm(out, axis=1), 1, atol=1e-6)
     I, N = GOLD["fr_I"], GOLD["fr_N"]
-    kr = np.zeros(128, np.float32)
-    rf = np.zeros((128, 3), np.float32)
-    L.orc_fresnel(128, I.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), C.c_float(1.5), kr.ctypes.data_as(C.c_void_p))
-    L.orc_refract(128, I.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), C.c_float(1 / 1.5), rf.ctypes.data_as(C.c_void_p))
+    kr = np.zeros(1024, np.float32)
+    rf = np.zeros((1024, 3), np.float32)
+    L.orc_fresnel(1024, I.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), C.c_float(1.5), kr.ctypes.data_as(C.c_void_p))
+    L.orc_refract(1024, I.ctypes.data_as(C.c_void_p), N.ctypes.data_as(C.c_void_p), C.c_float(1 / 1.5), rf.ctypes.data_as(C.c_void_p))
     assert np.array_equal(kr.view(np.uint32), GOLD["fr_kr"].view(np.uint32))
     assert np.array_equal(rf.view(np.uint32), GOLD["fr_refract"].view(np.uint32))
     assert ((kr >= 0) & (kr <= 1)).all()
@@ -84,28 +84,70 @@ def test_aabb_slab_cases(oracle_api):
         assert v == np.float32(1e30)
 
 
-@pytest.mark.parametrize("name,kw", [("background", {}), ("mixed_small", {}), ("scene3", {"force_diffuse": False}), ("tlas_test2", {})])
-def test_scene_goldens(name, kw, scenes, oracle_api):
+def _golden_mod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_goldens_regenerate_bit_for_bit(oracle_api):
+    """Drift pin: the generator run on today's oracle reproduces every committed array (per-primitive ray
+    vectors, RNG streams, builder / TLAS dumps, primary maps and Whitted / path accumulators of six scenes)."""
+    out = _golden_mod().generate()
+    assert sorted(out) == sorted(GOLD.files)
+    for k in GOLD.files:
+        assert out[k].dtype == GOLD[k].dtype and out[k].tobytes() == GOLD[k].tobytes(), k
+
+
+def test_goldens_do_not_depend_on_the_compiler(oracle_api, tmp_path):
+    """The oracle built with ROCm's clang++ instead of g++ (same strict-fp flags) must give the same bits:
+    a difference would mean the restatement leans on unspecified behaviour or on one compiler's code generation
+    (evaluation order, contraction, libm variants), which the reference's arithmetic must not."""
+    import subprocess, sys
+    so = oracle_api.build_clang()
+    out = str(tmp_path / "clang.npz")
+    env = dict(os.environ, ORACLE_LIB=so)
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"), "--out", out], env=env)
+    other = np.load(out)
+    assert sorted(other.files) == sorted(GOLD.files)
+    for k in GOLD.files:
+        assert other[k].tobytes() == GOLD[k].tobytes(), k
+
+
+def test_reference_probe_observations(scenes, oracle_api):
+    """The only numbers in this repository that come from the REFERENCE ITSELF: the survey's probe build of the
+    patched reference sources rendered the default scene
+    (instantiateBackgroundScene, template/scene.h:791-813) at 600x400 in Whitted mode and observed
+      * 9,790 of 240,000 accumulator pixels are +inf (a directly viewed AreaLight, Q7),
+      * gprof over two frames (480 k primary rays): 1.04 M bvh::BIntersect calls, 29.3 M Triangle::Intersect calls.
+    All three are independent of the (missing) sky texture.  The oracle must reproduce them: the first exactly,
+    the gprof figures to the three digits they were recorded with."""
     s = oracle_api.OracleScene()
-    d = scenes.REGISTRY[name](s, **kw)
-    b = s.bvh_dump(0 if d["tlas"] else -1)
-    assert np.array_equal(np.delete(b["nodes"], 1, axis=0), GOLD[name + "_nodes"])
-    assert np.array_equal(b["prim_idx"], GOLD[name + "_prim_idx"])
-    if d["tlas"]:
-        assert np.array_equal(s.tlas_dump(), GOLD[name + "_tlas"])
-    r = oracle_api.OracleRenderer(s, 48, 32)
-    obj, t, cnt = r.primary_hits(1e-6)
-    assert np.array_equal(obj, GOLD[name + "_obj"])
-    assert np.array_equal(t.view(np.uint32), GOLD[name + "_t"].view(np.uint32))
-    assert [cnt[k] for k in oracle_api.COUNTER_NAMES] == GOLD[name + "_cnt"].tolist()
+    scenes.background_scene(s)
     s.set_raytracer(True)
-    r.render(0, 1)
-    assert np.array_equal(r.accumulator().view(np.uint32), GOLD[name + "_whitted"].view(np.uint32))
-    s.set_raytracer(False)
-    r.clear()
-    r.render(0, 4, nthreads=0)  # OpenMP over scanlines; per-pixel RNG streams make it thread-count independent
-    assert np.array_equal(r.accumulator().view(np.uint32), GOLD[name + "_path4"].view(np.uint32))
+    r = oracle_api.OracleRenderer(s, 600, 400)
+    cnt = r.render(0, 1, nthreads=0)
+    a = r.accumulator()[..., :3]
+    assert int(np.isposinf(a).any(-1).sum()) == 9790
+    assert not np.isnan(a).any()
+    # Whitted frames are deterministic (no RNG), so two frames cost exactly twice one
+    assert round(2 * cnt["rays_nearest"] / 1e6, 2) == 1.04
+    assert round(2 * cnt["tri_intersect_calls"] / 1e6, 1) == 29.3
+    # "~28 triangle tests per traversal" (SURVEY.md section 6)
+    assert round(cnt["tri_intersect_calls"] / cnt["rays_nearest"]) == 28
     r.close(); s.close()
+
+
+def test_primitive_vectors_have_hits():
+    """The per-primitive golden vectors are only worth something if they exercise both outcomes."""
+    for kind in ("triangle", "sphere", "plane", "disk"):
+        obj = GOLD[kind + "_obj_1e-06"]
+        assert 0.1 < (obj != -1).mean() < 0.98, kind
+        assert 0.02 < GOLD[kind + "_occ"].mean() < 0.98 or kind == "disk", kind
+    d = GOLD["aabb_dist"]
+    assert 0.1 < (d != np.float32(1e30)).mean() < 0.9
 
 
 def test_bvh_invariants(scenes, oracle_api):
