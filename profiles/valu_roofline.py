@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Roofline inputs for bench.py from a PMC summary (profiles/pmc_summary.py output) -> profiles/roofline_pmc.json.
+
+For the traversal kernel k_extend (all timed variants summed) per step of the bench workload:
+  lane_ops            SQ_THREAD_CYCLES_VALU: enabled-lane VALU instruction slots (one per lane per VALU instruction)
+  valu_insts          SQ_INSTS_VALU (wave-level)
+  lanes_enabled       SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
+  valu_pipe_busy      2 * SQ_ACTIVE_INST_VALU / (SIMDs * kernel cycles / 4): SQ counts per-wave activity in units of 4
+                      cycles; a SIMD-32 retires a wave64 VALU instruction in 2 cycles (MI355X_MICROARCH.md: v_fma_f32
+                      2 cyc, one wave alone 4), so two waves can be VALU-active at once
+  frac                lane_ops / (peak lane-ops/s * kernel seconds): <= 1 by construction; = lanes_enabled x pipe busy
+  hbm_bytes           FETCH_SIZE x 2 (gfx950 correction of the guide's HBM section) + WRITE_SIZE, in bytes
+The file is stamped with a hash of the kernel sources (csrc/); bench.py ignores it when the sources changed.
+Usage: valu_roofline.py <pmc_summary.json> <launches of k_extend per step> [source json name]"""
+import hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMD-32 x lanes x 2.4 GHz = 78.6 T lane-ops/s (= 157.3 TFLOP/s fp32 FMA)
+SIMDS = 1024
+
+
+def kernel_hash():
+    d = os.path.join(ROOT, "ray-and-pathtracer_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    src = sys.argv[1]
+    d = json.load(open(src))
+    out = {"kernel_hash": kernel_hash(), "source": os.path.relpath(src, ROOT), "peak_lane_ops_per_s": PEAK_LANE_OPS, "kernels": {}}
+    groups = {"k_extend": [k for k in d if k.startswith("k_extend")], "k_connect": [k for k in d if k.startswith("k_connect")],
+              "k_shade": [k for k in d if k.startswith("k_shade")]}
+    for g, ks in groups.items():
+        if not ks:
+            continue
+        c = {}
+        launches, ms = 0, 0.0
+        for k in ks:
+            launches += d[k]["launches"]
+            ms += d[k]["ms_by_pass"].get("sq1", list(d[k]["ms_by_pass"].values())[0])
+            for n, v in d[k]["counters"].items():
+                c[n] = c.get(n, 0.0) + v
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+        sec = ms * 1e-3
+        o = {"launches": launches, "ms": round(ms, 3), "clock_ghz": round(cycles / sec / 1e9, 3),
+             "lane_ops": c["SQ_THREAD_CYCLES_VALU"], "valu_insts": c["SQ_INSTS_VALU"], "salu_insts": c.get("SQ_INSTS_SALU"),
+             "lanes_enabled": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
+             "valu_pipe_busy": round(2.0 * c["SQ_ACTIVE_INST_VALU"] / (SIMDS * cycles / 4.0) / 2.0, 4),
+             "frac_of_peak_lane_ops": round(c["SQ_THREAD_CYCLES_VALU"] / (PEAK_LANE_OPS * sec), 4),
+             "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+             "l1_accesses": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"), "l2_requests": c.get("TCP_TCC_READ_REQ_sum"),
+             "l1_accesses_per_cu_cycle": round(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / (256 * cycles), 4),
+             "l2_hit_rate": round(c["TCC_HIT_sum"] / max(1.0, c["TCC_REQ_sum"]), 4),
+             "hbm_bytes": int(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024)}
+        o["hbm_bytes_per_launch"] = int(o["hbm_bytes"] / launches)
+        o["lane_ops_per_launch"] = o["lane_ops"] / launches
+        out["kernels"][g] = o
+    json.dump(out, open(os.path.join(ROOT, "profiles", "roofline_pmc.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
