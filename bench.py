@@ -12,12 +12,12 @@ accumulator rows are gathered to rank 0 inside the step (strong scaling: total w
 
 Rank 0 prints ONE JSON line.  value = W*H*spp / seconds / 1e6, the reference's own definition of
 "Mrays/s" (renderer.cpp:300-304: primary pixel samples per second); all traced rays per second are
-reported beside it.  roofline: dominant kernel = k_extend (Scene::FindNearest); achieved =
-algorithmic bytes of its launches (SURVEY.md 8d formula over the kernel's own work counters,
-gathered in an untimed counting pass of the identical, deterministic workload) / its device time
-measured with HIP events on its stream during the timed steps.  cpu_baseline: the oracle
-(oracle/, the CPU restatement; kind "port") on this box's host cores, on a bounded sample (whole
-1080p frames of the same workload, as many as fit ~15 s).
+reported beside it.  roofline: dominant kernel = k_extend (Scene::FindNearest), see roofline_block():
+the VALU lane throughput it reaches (it is bound by the CUs' vector pipelines, not by HBM), with the
+SURVEY.md 8(d) algorithmic-bytes rate (work counters from an untimed counting pass of the identical,
+deterministic workload / device time measured with HIP events on the kernel's stream during the timed
+steps) and the counter-measured HBM rate beside it.  cpu_baseline: the oracle (oracle/, the CPU
+restatement; kind "port") on this box's physical host cores and on one thread, on bounded samples.
 """
 import argparse
 import importlib
@@ -149,22 +149,10 @@ def main():
         sec_per_step = dt / args.steps
         value = W * H * spp / sec_per_step / 1e6
         ext = prof["extend"]
-        bytes_extend = ha.algorithmic_bytes(near, executed=True)  # this rank, one step
         launches_per_step = ext["launches"] / args.steps
-        avg_ms = ext["ms"] / max(1, ext["launches"])
-        achieved = (bytes_extend / max(1.0, launches_per_step)) / (avg_ms * 1e-3) / 1e9 if ext["launches"] else 0.0
-        peak = 8000.0  # GB/s, MI355X HBM3E peak (MI355X_MICROARCH.md)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("width") == W and tj.get("height") == H and tj.get("spp") == spp:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        avg_ms = ext["ms"] / max(1, ext["launches"])  # HIP events on the kernel's own stream, inside the timed steps
         out = {
-            "metric": "Mrays/s at 1920×1080×64spp",
+            "metric": "Mrays/s at %d×%d×%dspp" % (W, H, spp),
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -173,12 +161,8 @@ def main():
                        "rays_definition": "value counts primary pixel samples (reference's Mrays/s, renderer.cpp:300); all_rays counts every FindNearest + IsOccluded query"},
             "all_rays_mrays_per_s": round(rays_all / sec_per_step / 1e6, 3),
             "rays_per_step": {"nearest": int(cnt[0].item()), "occluded": int(cnt[1].item())},
-            "roofline": {"bound": "hbm", "kernel": "k_extend (Scene::FindNearest)", "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
-                         "frac": round(achieved / peak, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_extend / max(1.0, launches_per_step)),
-                         "algorithmic_work_per_step": {k: int(near[k]) for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits", "brute_tests", "rays_nearest")},
-                         "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches_per_step,
-                         "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}},
+            "roofline": roofline_block(args, ha, near, avg_ms, launches_per_step, W, H, spp, world,
+                                       {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}),
         }
         out["frame_checksum"] = "%016x" % int(torch.sum(acc.view(torch.int32).to(torch.int64)).item() & 0xFFFFFFFFFFFFFFFF)
         if world == 1 and not args.no_cpu_baseline:
@@ -190,13 +174,93 @@ def main():
         dist.destroy_process_group()
 
 
+def kernel_hash():
+    """Hash of the kernel sources: counter files measured on other kernels are ignored (profiles/valu_roofline.py
+    stamps the same hash; .git does not travel to the GPU box, so a commit id cannot be used)."""
+    import hashlib
+    d = os.path.join(ROOT, "ray-and-pathtracer_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def roofline_block(args, ha, near, avg_ms, launches_per_step, W, H, spp, world, kernel_ms):
+    """Dominant kernel k_extend (Scene::FindNearest).  What binds it, measured (DESIGN.md section 5): neither HBM
+    (the scene is a few MB and lives in L1/L2; counter HBM traffic is ~1.6 TB/s) nor MFMA (none on this path) but
+    the CUs' vector pipelines -- the VALU with ~43 % of its lanes enabled and the vector-memory (TA/L1) gather
+    path.  'frac' is therefore the enabled-lane VALU throughput against the chip's VALU peak (<= 1 by
+    construction), with the SURVEY 8(d) algorithmic-bytes rate and the counter-measured HBM rate beside it.
+      achieved = enabled-lane VALU instruction slots per launch (SQ_THREAD_CYCLES_VALU, from the committed PMC
+                 summary of these very kernel sources; the workload is deterministic, so the count is the same in
+                 every run) / the launch duration measured live with HIP events
+      peak     = 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (157.3 TFLOP/s fp32 at 2 flops per FMA)
+    Counter-derived fields are null when profiles/roofline_pmc.json was measured on other kernel sources, on
+    another workload size, or with more than one rank."""
+    bytes_extend = ha.algorithmic_bytes(near, executed=True)  # this rank, one step: 64 I + 52 P + 48 R + 64 T + 128 X
+    reach_bytes = 48 * near["tlas_inner"]  # the builder's own reach[] records, reported apart from SURVEY 8(d)'s terms
+    sec = avg_ms * 1e-3
+    alg_per_launch = bytes_extend / max(1.0, launches_per_step)
+    rb = {"bound": "valu", "kernel": "k_extend (Scene::FindNearest)", "achieved": None, "peak": 78.6432, "unit": "Tlane-op/s",
+          "frac": None, "traffic": None,
+          "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches_per_step, "kernel_ms_per_step": kernel_ms,
+          "hbm": {"peak_GBps": 8000.0,
+                  "algorithmic_bytes_per_launch": int(alg_per_launch), "reach_bytes_per_launch": int(reach_bytes / max(1.0, launches_per_step)),
+                  "algorithmic_GBps": round(alg_per_launch / sec / 1e9, 2) if sec > 0 else None,
+                  "algorithmic_frac_of_hbm_peak": round(alg_per_launch / sec / 8e12, 4) if sec > 0 else None,
+                  "note": "algorithmic bytes (SURVEY 8d: every node pair and primitive a ray touches, as if fetched from memory) exceed what HBM delivers because the scene is served from L1/L2: a demand figure, not a roofline"},
+          "algorithmic_work_per_step": {k: int(near[k]) for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits", "rays_nearest")}}
+    ppath = os.path.join(ROOT, "profiles", "roofline_pmc.json")
+    try:
+        pj = json.load(open(ppath))
+    except Exception:
+        pj = None
+    usable = (pj is not None and pj.get("kernel_hash") == kernel_hash() and world == 1 and
+              pj.get("workload") == [args.workload, W, H, spp])
+    rb["pmc"] = {"file": "profiles/roofline_pmc.json", "used": bool(usable), "kernel_hash": kernel_hash(),
+                 "file_kernel_hash": pj.get("kernel_hash") if pj else None}
+    if usable and sec > 0:
+        k = pj["kernels"]["k_extend"]
+        lane_ops = k["lane_ops_per_launch"]
+        rb["achieved"] = round(lane_ops / sec / 1e12, 3)
+        rb["frac"] = round(lane_ops / sec / 78.6432e12, 4)
+        rb["traffic"] = k["hbm_bytes_per_launch"]
+        rb["hbm"]["counter_GBps"] = round(k["hbm_bytes_per_launch"] / sec / 1e9, 1)
+        rb["hbm"]["counter_frac_of_hbm_peak"] = round(k["hbm_bytes_per_launch"] / sec / 8e12, 4)
+        rb["valu"] = {"lanes_enabled": k["lanes_enabled"], "valu_pipe_busy": k["valu_pipe_busy"], "wave_wait_frac": k["wave_wait_frac"],
+                      "l1_accesses_per_cu_cycle": k["l1_accesses_per_cu_cycle"], "profile_launch_ms": round(k["ms"] / k["launches"], 4)}
+    return rb
+
+
+def physical_cores():
+    """(physical cores, logical CPUs) this process may run on, from /proc/cpuinfo's (physical id, core id) pairs."""
+    allowed = os.sched_getaffinity(0)
+    cores, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif not line.strip():
+                if "processor" in cur and int(cur["processor"]) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+                cur = {}
+    except Exception:
+        pass
+    return (len(cores) or len(allowed)), len(allowed)
+
+
 def cpu_baseline(args, cfg, W, H):
-    """The oracle (CPU restatement, kind 'port') on the host cores: whole frames of the same
-    workload, OpenMP over scanlines like renderer.cpp:259, per-pixel RNG streams."""
+    """The oracle (CPU restatement, kind 'port') on the host cores: frames of the same workload, OpenMP over
+    scanlines like renderer.cpp:259, per-pixel RNG streams.  value: OMP_NUM_THREADS = physical core count
+    (whole frames); value_1thread: one thread on every 24th scanline of one frame (a bounded sample of the same
+    image)."""
     from oracle import oracle_api as oa
     scenes = pkg("scenes")
     oa.build()
-    cores = len(os.sched_getaffinity(0))
+    phys, logical = physical_cores()
     s = oa.OracleScene()
     scenes.REGISTRY[args.workload](s)
     s.set_raytracer(False)
@@ -205,16 +269,24 @@ def cpu_baseline(args, cfg, W, H):
         c = cfg["camera"]
         orr.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
     t0 = time.perf_counter()
-    orr.render(0, 1, nthreads=cores)
+    orr.render(0, 1, nthreads=phys)
     t1 = time.perf_counter() - t0
     frames = int(max(1, min(64, args.cpu_seconds / max(t1, 1e-3))))
     t0 = time.perf_counter()
-    orr.render(1, frames, nthreads=cores)
+    orr.render(1, frames, nthreads=phys)
     dt = time.perf_counter() - t0
+    rows = list(range(11, H, 24))
+    t0 = time.perf_counter()
+    for y in rows:
+        orr.render(0, 1, y0=y, y1=y + 1, nthreads=1)
+    dt1 = time.perf_counter() - t0
     orr.close()
     s.close()
-    return {"value": round(W * H * frames / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d frame(s) of %dx%d of the same workload (%.1f s)" % (frames, W, H, dt)}
+    return {"value": round(W * H * frames / dt / 1e6, 4), "unit": "Mrays/s", "cores": phys, "kind": "port",
+            "sample": "%d frame(s) of %dx%d of the same workload on %d threads (%.1f s)" % (frames, W, H, phys, dt),
+            "physical_cores": phys, "logical_cpus": logical,
+            "value_1thread": round(W * len(rows) / dt1 / 1e6, 4),
+            "sample_1thread": "%d scanlines (every 24th) of one %dx%d frame on 1 thread (%.1f s)" % (len(rows), W, H, dt1)}
 
 
 if __name__ == "__main__":

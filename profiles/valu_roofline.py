@@ -5,13 +5,15 @@ For the traversal kernel k_extend (all timed variants summed) per step of the be
   lane_ops            SQ_THREAD_CYCLES_VALU: enabled-lane VALU instruction slots (one per lane per VALU instruction)
   valu_insts          SQ_INSTS_VALU (wave-level)
   lanes_enabled       SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
-  valu_pipe_busy      2 * SQ_ACTIVE_INST_VALU / (SIMDs * kernel cycles / 4): SQ counts per-wave activity in units of 4
-                      cycles; a SIMD-32 retires a wave64 VALU instruction in 2 cycles (MI355X_MICROARCH.md: v_fma_f32
-                      2 cyc, one wave alone 4), so two waves can be VALU-active at once
+  valu_pipe_busy      2 cycles * SQ_INSTS_VALU / (SIMDs * kernel cycles): a SIMD-32 retires a wave64 VALU instruction in
+                      2 cycles when two or more waves feed it (MI355X_MICROARCH.md: v_fma_f32 2 cyc, one wave alone 4;
+                      profiles/microbench/valu_rate.hip measures 2.0-2.2)
+  wave_valu_active    4 cycles * SQ_ACTIVE_INST_VALU / (SIMDs * kernel cycles): the SQ's own per-wave view (a wave is
+                      "VALU active" for 4 cycles per instruction; up to two waves of a SIMD can be at once)
   frac                lane_ops / (peak lane-ops/s * kernel seconds): <= 1 by construction; = lanes_enabled x pipe busy
   hbm_bytes           FETCH_SIZE x 2 (gfx950 correction of the guide's HBM section) + WRITE_SIZE, in bytes
 The file is stamped with a hash of the kernel sources (csrc/); bench.py ignores it when the sources changed.
-Usage: valu_roofline.py <pmc_summary.json> <launches of k_extend per step> [source json name]"""
+Usage: valu_roofline.py <pmc_summary.json> <workload> <width> <height> <spp>   (what the profiled bench.py run rendered)"""
 import hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,7 +34,8 @@ def kernel_hash():
 def main():
     src = sys.argv[1]
     d = json.load(open(src))
-    out = {"kernel_hash": kernel_hash(), "source": os.path.relpath(src, ROOT), "peak_lane_ops_per_s": PEAK_LANE_OPS, "kernels": {}}
+    out = {"kernel_hash": kernel_hash(), "source": os.path.relpath(os.path.abspath(src), ROOT), "workload": [sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])],
+           "peak_lane_ops_per_s": PEAK_LANE_OPS, "kernels": {}}
     groups = {"k_extend": [k for k in d if k.startswith("k_extend")], "k_connect": [k for k in d if k.startswith("k_connect")],
               "k_shade": [k for k in d if k.startswith("k_shade")]}
     for g, ks in groups.items():
@@ -50,7 +53,8 @@ def main():
         o = {"launches": launches, "ms": round(ms, 3), "clock_ghz": round(cycles / sec / 1e9, 3),
              "lane_ops": c["SQ_THREAD_CYCLES_VALU"], "valu_insts": c["SQ_INSTS_VALU"], "salu_insts": c.get("SQ_INSTS_SALU"),
              "lanes_enabled": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
-             "valu_pipe_busy": round(2.0 * c["SQ_ACTIVE_INST_VALU"] / (SIMDS * cycles / 4.0) / 2.0, 4),
+             "valu_pipe_busy": round(2.0 * c["SQ_INSTS_VALU"] / (SIMDS * cycles), 4),
+             "wave_valu_active": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (SIMDS * cycles), 4),
              "frac_of_peak_lane_ops": round(c["SQ_THREAD_CYCLES_VALU"] / (PEAK_LANE_OPS * sec), 4),
              "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
              "l1_accesses": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"), "l2_requests": c.get("TCP_TCC_READ_REQ_sum"),

@@ -944,6 +944,10 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 	int batchFrames = (int)(((size_t)4 << 30) / (tilePixels * sizeof(float4)));
 	if (batchFrames < 1) batchFrames = 1;
 	if (batchFrames > nframes) batchFrames = nframes;
+	// path mode: keep a batch within the slot budget when a frame fits, so that every sample has its own slot
+	// (exactly depth + 1 rounds, finished samples stored by shade / light, no finish pass; 4K: 16-frame batches)
+	if (mode == RT_MODE_PATH && tilePixels <= (size_t)slot_budget() && (size_t)batchFrames * tilePixels > (size_t)slot_budget())
+		batchFrames = (int)((size_t)slot_budget() / tilePixels);
 	int rc = ensure_samples(c, tilePixels * batchFrames);
 	if (rc != RT_OK) return rc;
 	for (int f = 0; f < nframes; f += batchFrames) {

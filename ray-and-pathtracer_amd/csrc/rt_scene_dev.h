@@ -254,6 +254,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	hit.kind = -1, hit.inst = -1, hit.prim = 0, hit.t = 0;
 	int inst = -1;
 	bool clean = false; // the current (world or object space) ray cannot produce a NaN slab product
+#ifdef RT_EXPERIMENT_EXTRA_LOADS
+	uint xdummy = 0;
+#endif
 
 	// next node for this lane: pop the stack; an empty stack ends the ray, the sentinel leaves the instance
 	auto pop_next = [&]() {
@@ -322,7 +325,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		}
 		const bool stepping = work >= 0 && link != RT_LINK_DONE;
 		if (__ballot(stepping) == 0) {
-			if (exhausted && __ballot(work >= 0) == 0) break;
+			if (exhausted && __ballot(work >= 0) == 0) {
+#ifdef RT_EXPERIMENT_EXTRA_LOADS
+				if (xdummy == 0x7fc12345u && n < 0) *overflow = 3; // keeps the register allocated to the loads
+#endif
+				break;
+			}
 			continue; // only finished lanes left (they flush above), or nothing was handed out this time
 		}
 
@@ -357,6 +365,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				const bool atTlas = S.useTLAS && inst < 0;
 				const float4* p = S.pairs + 4 * (size_t)lk;
 				const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+#ifdef RT_EXPERIMENT_EXTRA_LOADS
+				// measurement only: N more loads of the record just fetched (L1 hits, nobody waits for them): does the
+				// vector-memory path limit this kernel?
+				for (int xl = 0; xl < RT_EXPERIMENT_EXTRA_LOADS; xl++) asm volatile("global_load_dword %0, %1, off offset:%2" : "+v"(xdummy) : "v"(p), "i"(4 * (xl & 15)));
+#endif
 				float dist1, dist2;
 				if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
 				else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));

@@ -439,11 +439,12 @@ class HostRenderer:
 
 
 def algorithmic_bytes(counters, executed=False):
-    """Algorithmic bytes of a set of queries, SURVEY.md section 8(d): 64 B per BLAS inner-node visit
-    (two 32-B children), 52 B per primitive test (4-B index + 48-B triangle), 48 B per ray (32 in,
-    16 out); TLAS adds 64 B per TLAS inner visit and 128 B per instance entry (two mat4).
-    executed=True prices tallies taken with RT_COUNT_EXECUTED: a TLAS visit of the timed kernels also
-    reads the 48-B reach record of the pair."""
+    """Algorithmic bytes of a set of traversals, SURVEY.md section 8(d) literally: 64 B per BLAS inner-node visit
+    (two 32-B children), 52 B per primitive test made BY THE TRAVERSAL (4-B index + 48-B triangle), 48 B per ray
+    (32 in, 16 out), 64 B per TLAS inner visit and 128 B per instance entry (two mat4).  The head tests of
+    Scene::FindNearest (lights, brute-force spheres / planes) run where rays are created, not in the traversal
+    kernels, and are not priced here; neither are the 48-B reach records the timed kernels read per TLAS visit
+    (bench.py reports those apart).  'executed' is accepted for older callers and ignored."""
     rays = counters["rays_nearest"] + counters["rays_occluded"]
-    return (64 * counters["inner_visits"] + 52 * (counters["prim_tests"] + counters.get("brute_tests", 0)) + 48 * rays
-            + (112 if executed else 64) * counters["tlas_inner"] + 128 * counters["instance_visits"])
+    return (64 * counters["inner_visits"] + 52 * counters["prim_tests"] + 48 * rays
+            + 64 * counters["tlas_inner"] + 128 * counters["instance_visits"])
