@@ -224,6 +224,13 @@ class OracleRenderer:
                           nthreads, max_depth, _p(cnt))
         return dict(zip(ORACLE_COUNTER_NAMES, cnt.tolist()))
 
+    def tick(self, cam_changed, frame, seed_base=0x12345678, nthreads=0):
+        """Renderer::Tick with the reference's iteration bookkeeping; returns (pixels, iteration number after)."""
+        px = np.zeros((self.hgt, self.w), dtype=np.uint32)
+        ch = C.c_int(int(cam_changed))
+        it = self.L.orc_tick(self.h, C.byref(ch), C.c_uint(frame), C.c_uint(seed_base), nthreads, _p(px))
+        return px, it
+
     def accumulator(self):
         out = np.zeros((self.hgt, self.w, 4), dtype=np.float32)
         self.L.orc_get_accumulator(self.h, _p(out))

@@ -299,6 +299,17 @@ int orc_render(void* h, unsigned frame0, int nframes, unsigned seedBase, int y0,
 	counters_out(total, counters);
 	return 0;
 }
+// Renderer::Tick: one frame with the reference's iteration bookkeeping; *camChanged in/out
+int orc_tick(void* h, int* camChanged, unsigned frame, unsigned seedBase, int nthreads, unsigned* pixels)
+{
+	Renderer& r = ((OrcRenderer*)h)->r;
+	if (nthreads > 0) omp_set_num_threads(nthreads);
+	bool ch = *camChanged != 0;
+	r.max_depth_trace = 4;
+	r.Tick(ch, frame, seedBase, pixels);
+	*camChanged = ch ? 1 : 0;
+	return r.iterationNumber;
+}
 void orc_get_accumulator(void* h, float* out) { const Renderer& r = ((OrcRenderer*)h)->r; memcpy(out, r.accumulator.data(), r.accumulator.size() * 16); }
 // screen->pixels for iteration count 'it' (renderer.cpp:287-290)
 void orc_resolve(void* h, int it, unsigned* out)

@@ -295,6 +295,28 @@ struct Renderer {
 		}
 	}
 
+	// Renderer::Tick (:240-305) without animation, input and the performance printf.  'it' is read BEFORE a
+	// camera change resets the iteration number (:247 vs :253-255), so the frame on which the camera changed is
+	// resolved with the stale count, and the count is not advanced on that frame (:293-294).
+	void Tick(bool& cameraChanged, uint frame, uint seedBase, uint* pixels)
+	{
+		const int W = camera.width, H = camera.height;
+		int it = iterationNumber;
+		if (cameraChanged && !scene->raytracer) iterationNumber = 1;
+		const bool changed = cameraChanged;
+#pragma omp parallel for schedule(dynamic)
+		for (int y = 0; y < H; ++y) {
+			Counters local;
+			for (int x = 0; x < W; ++x) {
+				if (!scene->raytracer && changed) accumulator[(size_t)x + (size_t)y * W] = float4{ 0, 0, 0, 0 }; // :273-275
+				Pixel(x, y, frame, seedBase, local);
+			}
+			for (int x = 0; x < W; ++x) pixels[(size_t)y * W + x] = ResolvePixel((size_t)x + (size_t)y * W, it);
+		}
+		if (!scene->raytracer && !changed) iterationNumber = it + 1;
+		cameraChanged = false;
+	}
+
 	// RGBF32_to_RGB8 of accumulator / it (:287-290, template/precomp.h:445-448, non-MSVC branch)
 	uint ResolvePixel(size_t idx, int it) const
 	{

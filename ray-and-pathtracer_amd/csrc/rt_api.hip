@@ -311,6 +311,17 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		const rt_blas& b = d->blas[k];
 		if (b.nodes_used < 1 || (b.nodes_used & 1) || !b.nodes) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u has %u nodes (expected an even count >= 2)", k, b.nodes_used);
 		if (b.n_prims != b.n_tri + b.n_sph + b.n_pla) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u primitive counts disagree", k);
+		// an instanced BLAS is a mesh (bvh(Mesh*), bvh.cpp:5-16): the instance path resolves triangle normals only
+		// (bvhInstance.cpp:19), so spheres / planes below an instance are refused rather than shaded wrongly
+		if (d->use_tlas && (b.n_sph > 0 || b.n_pla > 0)) return fail(c, RT_E_UNSUPPORTED, "rt_upload_scene: blas %u holds spheres / planes; an instanced BLAS must be triangles only", k);
+		// node boxes must be numbers within the reference's +-1e30 sentinels (bvh.cpp:96-109): the hardware min / max
+		// slab test of clean rays relies on it
+		for (uint i = 0; i < b.nodes_used && b.n_prims > 0; i++) {
+			if (i == 1) continue;
+			for (int a = 0; a < 3; a++)
+				if (!(std::fabs(b.nodes[i].aabb_min[a]) <= 1e30f) || !(std::fabs(b.nodes[i].aabb_max[a]) <= 1e30f))
+					return fail(c, RT_E_UNSUPPORTED, "rt_upload_scene: blas %u node %u has a non-finite bound or one beyond 1e30", k, i);
+		}
 		const uint pairOff = (uint)(pairs.size() / 16), primOff = (uint)(prims.size() / 16);
 		std::vector<char> last(b.n_prims, 0);
 		auto link_of = [&](uint i) -> uint {
@@ -354,9 +365,13 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	if (d->use_tlas) {
 		for (uint i = 0; i < d->tlas_nodes_used; i++) {
 			const rt_tlas_node& nd = d->tlas_nodes[i];
-			if (nd.left_right == 0) { if (nd.blas >= d->n_instances && i != 0) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u instance %u out of range", i, nd.blas); }
+			if (nd.left_right == 0) { if (nd.blas >= d->n_instances && (i != 0 || d->tlas_nodes_used == 1)) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u instance %u out of range", i, nd.blas); }
 			else if ((nd.left_right & 0xFFFF) >= d->tlas_nodes_used || (nd.left_right >> 16) >= d->tlas_nodes_used) return fail(c, RT_E_ARG, "rt_upload_scene: tlas node %u child out of range", i);
 		}
+		for (uint i = 0; i < d->tlas_nodes_used; i++)
+			for (int a = 0; a < 3; a++)
+				if (!(std::fabs(d->tlas_nodes[i].aabb_min[a]) <= 1e30f) || !(std::fabs(d->tlas_nodes[i].aabb_max[a]) <= 1e30f))
+					return fail(c, RT_E_UNSUPPORTED, "rt_upload_scene: tlas node %u has a non-finite bound or one beyond 1e30", i);
 		const uint nT = d->tlas_nodes_used;
 		std::vector<uint> slotOf(nT, 0);
 		uint next = (uint)(pairs.size() / 16);
@@ -1004,6 +1019,7 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 	float *dO = nullptr, *dD = nullptr;
 	float4* dOut = nullptr;
 	std::vector<void*> tmp;
+	struct Guard { rt_ctx* c; std::vector<void*>& v; ~Guard() { (void)hipStreamSynchronize(c->stream); free_pool(v); } } guard{ c, tmp }; // every return path frees
 	HIPCHK(c, dalloc(tmp, &dO, (size_t)3 * n));
 	HIPCHK(c, dalloc(tmp, &dD, (size_t)3 * n));
 	HIPCHK(c, dalloc(tmp, &dOut, (size_t)n));
@@ -1032,8 +1048,6 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 		if (e != hipSuccess) rc = fail(c, RT_E_HIP, "rt_trace_batch: copy back failed: %s", hipGetErrorString(e));
 		else for (int i = 0; i < n; i++) { rgb_out[3 * i] = out4[4 * i], rgb_out[3 * i + 1] = out4[4 * i + 1], rgb_out[3 * i + 2] = out4[4 * i + 2]; }
 	}
-	(void)hipStreamSynchronize(c->stream);
-	free_pool(tmp);
 	return rc;
 }
 

@@ -50,7 +50,8 @@ namespace rtd {
 
 #define RT_BLOCK 256
 #define RT_STACK_LDS 16   // stack entries per lane held in LDS
-#define RT_STACK_MAX 64   // the reference's stack[64] (bvh.cpp:608, tlas.cpp:67)
+#define RT_STACK_MAX 130  // tlas::Intersect's stack[64] (tlas.cpp:67) + the instance sentinel + bvh::BIntersect's own stack[64]
+                          // (bvh.cpp:608) live on ONE stack here; whatever the reference can traverse fits
 
 struct DLight {
 	int kind, objIdx;
@@ -108,7 +109,7 @@ struct Stack {
 	{
 		if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v;
 		else if (sp < RT_STACK_MAX) spill[(size_t)(sp - RT_STACK_LDS) * spillStride] = v;
-		else { *overflow = 1; return; }
+		else { *overflow = 1; sp = 0; return; } // reported as RT_E_OVERFLOW by the host; the ray ends at its next pop instead of walking a wrong stack
 		sp++;
 	}
 	__device__ __forceinline__ uint pop()

@@ -237,6 +237,7 @@ void rth_renderer_get_camera(void* h, float* out12)
 }
 int rth_renderer_sync_camera(void* h) { RthRenderer* r = (RthRenderer*)h; GUARD(r, r->r->SyncCamera()); return 0; }
 void rth_renderer_set_download(void* h, int on) { ((RthRenderer*)h)->r->downloadEachTick = on != 0; }
+int rth_renderer_iteration(void* h) { return ((RthRenderer*)h)->r->scene.GetIterationNumber(); }
 int rth_renderer_tick(void* h) { RthRenderer* r = (RthRenderer*)h; GUARD(r, r->r->Tick(0.0f)); return 0; }
 const float* rth_renderer_accumulator(void* h) { return &((RthRenderer*)h)->r->accumulator[0].x; }
 const unsigned* rth_renderer_pixels(void* h) { return ((RthRenderer*)h)->r->screenPixels; }

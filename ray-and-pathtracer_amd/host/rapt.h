@@ -253,7 +253,7 @@ public:
 		topLeft = float3(-aspect, 2, 0);
 		topRight = float3(aspect, 2, 0);
 		bottomLeft = float3(-aspect, 0, 0);
-		changed = true;
+		changed = false; // camera.h:52: the constructor does not mark a change; the mutators do
 	}
 	void ToogleFisheye() { changed = true; fishEye = !fishEye; }
 	void SetChange(bool s) { changed = s; }

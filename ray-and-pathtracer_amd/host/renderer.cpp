@@ -46,17 +46,18 @@ void Renderer::SyncCamera()
 	check(ctx, rt_set_camera(ctx, &c));
 }
 
-// renderer.cpp:240-305 without the animation, input and printf parts
+// renderer.cpp:240-305 without the animation, input and printf parts.  As in the reference, 'it' is read before a
+// camera change resets the iteration number (:247 vs :253-255): the frame on which the camera changed is resolved
+// with the stale count and does not advance it (:293-294).
 void Renderer::Tick(float /*deltaTime*/)
 {
 	if (!ctx) Init();
 	scene.totIterationNumber++;
-	int it = scene.GetIterationNumber();
-	const bool camChanged = camera.GetChange() && frame > 0;
-	if (camChanged && !scene.raytracer) { // :253-255, :273-275
+	const int it = scene.GetIterationNumber();
+	const bool camChanged = camera.GetChange();
+	if (camChanged && !scene.raytracer) {
 		scene.SetIterationNumber(1);
-		it = 1;
-		check(ctx, rt_clear(ctx));
+		check(ctx, rt_clear(ctx)); // accumulator[...] = float3(0) for every pixel (:273-275)
 	}
 	SyncCamera();
 	const int mode = scene.raytracer ? RT_MODE_WHITTED : RT_MODE_PATH;
@@ -64,7 +65,7 @@ void Renderer::Tick(float /*deltaTime*/)
 	if (!scene.raytracer) frame++;
 	check(ctx, rt_resolve(ctx, it, 0, height, screenPixels));
 	if (downloadEachTick) check(ctx, rt_download_accumulator(ctx, 0, height, &accumulator[0].x));
-	if (!scene.raytracer && !camChanged) scene.SetIterationNumber(it + 1); // :293-294
+	if (!scene.raytracer && !camChanged) scene.SetIterationNumber(it + 1);
 	camera.SetChange(false);
 }
 

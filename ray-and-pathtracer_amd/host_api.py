@@ -316,6 +316,10 @@ class HostRenderer:
     def tick(self):
         self._chk(self.L.rth_renderer_tick(self.h))
 
+    def iteration(self):
+        """Scene::GetIterationNumber()"""
+        return int(self.L.rth_renderer_iteration(self.h))
+
     def tick_accumulator(self):
         p = C.cast(self.L.rth_renderer_accumulator(self.h), C.POINTER(C.c_float))
         return np.ctypeslib.as_array(p, shape=(self.hgt, self.w, 4)).copy()

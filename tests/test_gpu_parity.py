@@ -236,6 +236,35 @@ def test_trace_batch_and_renderer_surface(scenes, oracle_api, host_api):
     r.close()
 
 
+def test_tick_with_camera_change(scenes, oracle_api, host_api):
+    """Renderer::Tick across a camera change in path mode (renderer.cpp:247-255, :273-275, :287-294): the frame on
+    which the camera changed clears the accumulator, is resolved with the iteration count read BEFORE the reset and
+    does not advance the count -- the displayed pixels and the count must follow the reference's bookkeeping."""
+    o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 48, 32)
+    r.scene.set_raytracer(False)
+    o.set_raytracer(False)
+    cam = orr.camera()
+    moved = cam.copy()
+    moved[0] += np.float32(0.25)  # camPos
+    frame = 0
+    for step, change in enumerate([False, False, False, True, False, False, True, True, False]):
+        if change:
+            c = moved if (step % 2) else cam
+            r.set_camera(c[0], c[1], c[2], c[3])
+            orr.set_camera(c[0], c[1], c[2], c[3])
+        px_ref, it_ref = orr.tick(change, frame)
+        r.tick()
+        frame += 1
+        assert r.iteration() == it_ref, step
+        got, ref = r.tick_accumulator(), orr.accumulator()
+        err, cls_ok = rel_err(got[..., :3], ref[..., :3])
+        assert cls_ok and err.max() <= RADIANCE_TOL, step
+        same = (got == ref).all(-1)
+        assert same.mean() > 0.5
+        assert np.array_equal(r.tick_pixels()[same], px_ref[same]), step
+    r.close()
+
+
 def test_edge_cases(scenes, oracle_api, host_api):
     r = host_api.HostRenderer(16, 8)
     # calls before a scene is uploaded fail loudly
