@@ -875,6 +875,7 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 				const int* hc = c->hostCounts + 16 * k;
 				if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 				else if (hc[3] == 2) rc = fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
+				else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
 				if (hc[3] != 0) (void)hipMemsetAsync(c->pools[k].Q.counts + 3, 0, sizeof(int), c->pools[k].stream);
 				if (hc[0] == 0 || knownRounds > 0) live[k] = false;
 				any = any || live[k];
@@ -1099,6 +1100,7 @@ static int check_overflow(rt_ctx* c)
 {
 	int f = 0;
 	HIPCHK(c, hipMemcpy(&f, c->flags + 1, sizeof(int), hipMemcpyDeviceToHost));
+	if (f >= 100) { (void)hipMemset(c->flags, 0, 2 * sizeof(int)); return fail(c, RT_E_STATE, "debug check %d failed in a query kernel (RT_DEBUG_CHECKS build)", f - 100); }
 	if (f) { (void)hipMemset(c->flags, 0, 2 * sizeof(int)); return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX); }
 	return RT_OK;
 }

@@ -398,9 +398,11 @@ struct ExtendPolicy {
 	PathState& P;
 	const uint* queue;
 	int parity;
+	int* flag;
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
 	{
 		const int slot = DENSE ? work : (int)queue[work];
+		RT_CHECK(slot >= 0 && slot < P.nSlots, 10, flag);
 		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
 		O = xyz(o4), D = xyz(d4), tmax = o4.w; // o4.w: ray.t after the head tests made when the ray was created
 		unpack_head(__float_as_uint(d4.w), head);
@@ -426,7 +428,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, 
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	ExtendPolicy<DENSE> pol{ S, P, Q.active, parity };
+	ExtendPolicy<DENSE> pol{ S, P, Q.active, parity, &Q.counts[3] };
 	trace_persistent<false, COUNT, false>(S, pol, Q.counts[0], Q.heads, t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) {
 		// the head tests ran where the rays were created: per ray, every light and every brute-force primitive
@@ -444,6 +446,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R,
 	const int nActive = Q.counts[0];
 	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nActive; e += gridDim.x * blockDim.x) {
 		const int slot = fresh ? e : (int)Q.active[e]; // the slots extend just traced, in slot order (fresh: all of them, no queue)
+		RT_CHECK(slot >= 0 && slot < P.nSlots, 12, &Q.counts[3]);
 		bool keep = false, wantShadow = false, ended = false;
 		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
@@ -568,9 +571,11 @@ struct ConnectPolicy {
 	PathState& P;
 	const uint* queue;
 	int parity, nLights;
+	int* flag;
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef&) const
 	{
 		const int slot = (int)queue[work / nLights], li = work % nLights;
+		RT_CHECK(slot >= 0 && slot < P.nSlots && li >= 0 && li < nLights, 11, flag);
 		const f3 I = xyz(P.hitP[slot]); // O + t * D, as shade computed it
 		const f3 pickedPos = xyz(P.sh[(size_t)li * P.nSlots + slot]);
 		f3 lightRayDirection = pickedPos - I;
@@ -595,7 +600,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights };
+	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights, &Q.counts[3] };
 	trace_persistent<true, COUNT, false>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
@@ -608,6 +613,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 	const int nShadow = Q.counts[2];
 	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nShadow; e += gridDim.x * blockDim.x) {
 		const int slot = (int)Q.shadow[e]; // the slots connect just tested, in slot order
+		RT_CHECK(slot >= 0 && slot < P.nSlots, 13, &Q.counts[3]);
 		const unsigned char stBits = P.status[slot];
 		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
@@ -686,6 +692,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_finish(DScene S, DCamera C, Render
 	for (int e0 = first; e0 < last; e0 += 64) {
 		const int e = e0 + (int)lane;
 		const int slot = e < last ? (int)queue[e] : -1;
+		RT_CHECK(slot < P.nSlots, 14, &Q.counts[3]);
 		unsigned char stBits = slot >= 0 ? P.status[slot] : 0;
 		bool completes = false;
 		if (slot >= 0) {

@@ -53,6 +53,16 @@ namespace rtd {
 #define RT_STACK_MAX 130  // tlas::Intersect's stack[64] (tlas.cpp:67) + the instance sentinel + bvh::BIntersect's own stack[64]
                           // (bvh.cpp:608) live on ONE stack here; whatever the reference can traverse fits
 
+// Debug build (make EXTRA=-DRT_DEBUG_CHECKS, profiles/debug_checks.sh): index checks on the structures the traversal
+// and shading kernels share -- stack pointer and spill index, queue positions, slot numbers, pending-branch slots.
+// A failed check stores 100 + its number in the launch's flag word (reported as RT_E_STATE by the host) instead
+// of touching memory out of bounds.  Off in the product build: the checks cost registers in the hottest loop.
+#ifdef RT_DEBUG_CHECKS
+#define RT_CHECK(cond, code, flagptr) do { if (!(cond)) *(flagptr) = 100 + (code); } while (0)
+#else
+#define RT_CHECK(cond, code, flagptr) do { } while (0)
+#endif
+
 struct DLight {
 	int kind, objIdx;
 	float pos[3], strength, col[3], normal[3], radius, sinAngle;
@@ -107,6 +117,7 @@ struct Stack {
 	int* overflow;
 	__device__ __forceinline__ void push(uint v)
 	{
+		RT_CHECK(sp <= RT_STACK_MAX, 1, overflow);
 		if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v;
 		else if (sp < RT_STACK_MAX) spill[(size_t)(sp - RT_STACK_LDS) * spillStride] = v;
 		else { *overflow = 1; sp = 0; return; } // reported as RT_E_OVERFLOW by the host; the ray ends at its next pop instead of walking a wrong stack
@@ -114,6 +125,7 @@ struct Stack {
 	}
 	__device__ __forceinline__ uint pop()
 	{
+		RT_CHECK(sp >= 1 && sp <= RT_STACK_MAX, 2, overflow);
 		sp--;
 		return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : spill[(size_t)(sp - RT_STACK_LDS) * spillStride];
 	}
@@ -275,6 +287,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			const int cnt = __popcll(freeMask);
 			if (cnt >= refillMin || freeMask == ~0ull) {
 				if (doneLane) {
+					RT_CHECK(work >= 0 && work < n && st.sp <= RT_STACK_MAX, 4, overflow);
 					// results are written here, many lanes at a time, not one lane per iteration
 					if constexpr (ANY) pol.store(work, hit.kind == 1);
 					else { hit.t = rayT; pol.store(work, hit, O, D); }
@@ -306,6 +319,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 						const int avail = chunkEnd - chunkNext;
 						float tmax = 0;
 						const bool take = mine < chunkEnd && ((freeMask >> lane) & 1);
+						RT_CHECK(!take || (mine >= 0 && mine < n), 3, overflow);
 						if (take) hit.kind = -1, hit.prim = 0, hit.inst = -1;
 						// a work item may turn out to be nothing to trace: the lane stays idle
 						if (take && pol.load(mine, O, D, tmax, hit)) {
@@ -433,6 +447,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			// with invTransform (direction not renormalised: t is shared by both spaces); the BLAS is
 			// walked above a sentinel on the same stack
 			inst = (int)(lk & ~RT_INST_BIT);
+			RT_CHECK(S.useTLAS && inst >= 0 && inst < 256, 5, overflow);
 			if (COUNT) lc.inst++;
 			const DInstance* I = S.inst + inst;
 			const f3 Oo = xform_pos(I->invT, O);

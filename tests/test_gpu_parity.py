@@ -597,6 +597,82 @@ def test_tlas_reach_culling_keeps_results(name, kw, scenes, oracle_api, host_api
     assert cnt2["instance_visits"] < cnt["instance_visits"] and cnt2["inner_visits"] < cnt["inner_visits"] and cnt2["tlas_inner"] <= cnt["tlas_inner"]
 
 
+def _fuzz_rays(o, n_inst, rng, n, center, extent):
+    """A chunk of n rays, a quarter each of: random rays through the scene's volume; rays aimed at instance-box
+    silhouette vertices from 0.5 .. 1e5 units away with +-3 ulp nudges; rays from far origins (up to the reach
+    tables' origin limit and beyond) towards the scene; near-degenerate directions (one or two components tiny or
+    exactly zero, non-unit lengths)."""
+    q = n // 4
+    O = np.empty((n, 3), np.float32)
+    D = np.empty((n, 3), np.float32)
+    # random
+    O[:q] = (rng.uniform(-1, 1, (q, 3)) * extent + center).astype(np.float32)
+    D[:q] = rng.normal(size=(q, 3)).astype(np.float32)
+    # silhouette
+    sO, sD = _silhouette_rays(o, n_inst, rng, per_inst=max(8, q // n_inst))
+    k = min(q, len(sO))
+    O[q:q + k], D[q:q + k] = sO[:k], sD[:k]
+    if k < q:
+        O[q + k:2 * q] = (rng.uniform(-1, 1, (q - k, 3)) * extent + center).astype(np.float32)
+        D[q + k:2 * q] = rng.normal(size=(q - k, 3)).astype(np.float32)
+    # far origins aimed at the scene
+    dist = np.exp(rng.uniform(np.log(10.0), np.log(1e6), q))[:, None]
+    dirs = rng.normal(size=(q, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    tgt = rng.uniform(-1, 1, (q, 3)) * extent * 0.6 + center
+    O[2 * q:3 * q] = (tgt - dirs * dist).astype(np.float32)
+    D[2 * q:3 * q] = (tgt - O[2 * q:3 * q].astype(np.float64)).astype(np.float32)
+    # near-degenerate directions
+    O[3 * q:] = (rng.uniform(-1, 1, (n - 3 * q, 3)) * extent + center).astype(np.float32)
+    dd = rng.normal(size=(n - 3 * q, 3))
+    kill = rng.integers(0, 3, len(dd))
+    dd[np.arange(len(dd)), kill] *= rng.choice([0.0, 1e-30, 1e-12, 1e-7, 1e-4], len(dd))
+    two = rng.uniform(size=len(dd)) < 0.3
+    dd[two, (kill[two] + 1) % 3] *= rng.choice([0.0, 1e-20, 1e-6], int(two.sum()))
+    dd *= rng.choice([1.0, 1.0, 1e-3, 250.0], len(dd))[:, None]
+    D[3 * q:] = dd.astype(np.float32)
+    return O, D
+
+
+@pytest.mark.parametrize("name,kw,total", [("pretty_tlas", {"n_instances": 8}, 100_000_000), ("bigb_instanced", {"n": 16, "mesh": "BigB"}, 12_000_000),
+                                           ("tlas_test2", {"mesh": "BigB"}, 12_000_000)])
+def test_reach_cull_fuzz_gpu_vs_gpu(name, kw, total, scenes, oracle_api, host_api):
+    """1e8 rays on the bench scene (1.2e7 on two more): the timed traversal (TLAS children whose reach box the ray
+    misses are dropped, DESIGN.md section 4 finding 8) against the same kernels walking like the reference
+    (RT_COUNT_REFERENCE: no culling) -- GPU against GPU, because this one equivalence needs volume, not an oracle.
+    Hit ids, t, materials and normals of Scene::FindNearest and the flags of Scene::IsOccluded must be bit-identical."""
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 16, 8, **kw)
+    rng = np.random.default_rng(20260)
+    n_inst = o.n_instances
+    boxes = np.stack([o.instance_dump(i)["bounds"] for i in range(n_inst)])
+    lo, hi = boxes[:, :3].min(0), boxes[:, 3:].max(0)
+    hi = np.minimum(hi, 50.0)  # a .tri mesh's sentinel triangles stretch the reference's boxes to 999 (Q10)
+    center, extent = (lo + hi) / 2, (hi - lo) / 2 + 1.0
+    chunk = 4_000_000
+    done, hits, diff_near, diff_occ = 0, 0, 0, 0
+    while done < total:
+        n = min(chunk, total - done)
+        O, D = _fuzz_rays(o, n_inst, rng, n, center, extent)
+        tmax = np.where(rng.uniform(size=n) < 0.5, np.float32(1e34), rng.uniform(0.1, 40.0, n)).astype(np.float32)
+        r.set_counting(False)
+        a = r.find_nearest(O, D, tmax, t_min=0.001)
+        oa_ = r.is_occluded(O, D, tmax)
+        r.set_counting(host_api.RT_COUNT_REFERENCE)
+        b = r.find_nearest(O, D, tmax, t_min=0.001)
+        ob = r.is_occluded(O, D, tmax)
+        r.set_counting(False)
+        same = (a["obj"] == b["obj"]) & (a["t"].view(np.uint32) == b["t"].view(np.uint32)) & (a["mat"] == b["mat"]) & \
+               (a["normal"].view(np.uint32) == b["normal"].view(np.uint32)).all(1)
+        diff_near += int((~same).sum())
+        diff_occ += int((oa_ != ob).sum())
+        hits += int((b["obj"] >= 100).sum())
+        done += n
+    r.counters()
+    assert diff_near == 0 and diff_occ == 0, (diff_near, diff_occ)
+    assert hits > total // 50  # the rays do reach instanced triangles
+    r.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1023, 1025, 4097, 70001])
 def test_batch_sizes_cover_the_work_heads(n, scenes, oracle_api, host_api):
     """The traversal kernels cut a queue into 16 sub-queues of a multiple of 64 entries and hand them out
