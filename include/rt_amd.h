@@ -173,6 +173,13 @@ int rt_resolve(rt_ctx* ctx, int iteration, int y0, int y1, uint32_t* rgb8_out);
  * memory (e.g. a torch tensor handed to an RCCL gather).  The caller keeps that memory alive. */
 void* rt_accumulator_device_ptr(rt_ctx* ctx);
 int rt_bind_accumulator(rt_ctx* ctx, void* device_ptr);
+/* Multi-GPU from one process (one host thread + one rt_ctx per GPU): copy the accumulator rows
+ * row_first + k*row_stride, k < row_count, that context src rendered into the same rows of context dst's
+ * accumulator -- device to device over xGMI (peer access is enabled on first use; without it the rows are
+ * copied one by one through hipMemcpyPeerAsync).  Waits for src's pending work, then runs on dst's stream.
+ * Both contexts must have the same width and height.  rt_device_of: the HIP device a context lives on. */
+int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int row_count);
+int rt_device_of(const rt_ctx* ctx);
 
 /* ---- batch queries ---------------------------------------------------------------------------- */
 /* Scene::FindNearest(ray, t_min) (template/scene.h:1248-1267) for n rays. O, D: n*3 floats;

@@ -1095,6 +1095,39 @@ int rt_bind_accumulator(rt_ctx* c, void* p)
 	return RT_OK;
 }
 
+int rt_device_of(const rt_ctx* c) { return c ? c->device : -1; }
+
+int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int row_count)
+{
+	if (!dst || !src) return fail(dst, RT_E_ARG, "rt_gather_rows: null context");
+	if (dst->width != src->width || dst->height != src->height) return fail(dst, RT_E_ARG, "rt_gather_rows: contexts differ in size (%dx%d vs %dx%d)", dst->width, dst->height, src->width, src->height);
+	if (row_first < 0 || row_stride < 1 || row_count < 1 || row_first + (row_count - 1) * row_stride >= dst->height)
+		return fail(dst, RT_E_ARG, "rt_gather_rows: rows %d + k*%d (k < %d) outside 0..%d", row_first, row_stride, row_count, dst->height);
+	if (dst == src) return RT_OK;
+	// the rows must be complete before they are copied
+	HIPCHK(dst, hipSetDevice(src->device));
+	HIPCHK(dst, hipStreamSynchronize(src->stream));
+	HIPCHK(dst, hipSetDevice(dst->device));
+	const size_t rowBytes = (size_t)dst->width * sizeof(float4), pitch = rowBytes * (size_t)row_stride;
+	const float4* from = src->accum + (size_t)row_first * src->width;
+	float4* to = dst->accum + (size_t)row_first * dst->width;
+	bool direct = dst->device == src->device;
+	if (!direct) {
+		// peer access dst <- src: one strided copy engine transfer over the link between the two GPUs
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
+			const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+			direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+			(void)hipGetLastError();
+		}
+	}
+	if (direct) HIPCHK(dst, hipMemcpy2DAsync(to, pitch, from, pitch, rowBytes, (size_t)row_count, hipMemcpyDeviceToDevice, dst->stream));
+	else
+		for (int k = 0; k < row_count; k++)
+			HIPCHK(dst, hipMemcpyPeerAsync((char*)to + (size_t)k * pitch, dst->device, (const char*)from + (size_t)k * pitch, src->device, rowBytes, dst->stream));
+	return RT_OK;
+}
+
 // ---- batch queries -------------------------------------------------------------------------------
 static int check_overflow(rt_ctx* c)
 {

@@ -217,12 +217,20 @@ void* rth_renderer_new(int w, int hgt, int device)
 	r->scene.owned = false;
 	return r;
 }
+// one context per entry of devices[] (an entry may repeat: two contexts on one GPU)
+void* rth_renderer_new_multi(int w, int hgt, int n, const int* devices)
+{
+	RthRenderer* r = (RthRenderer*)rth_renderer_new(w, hgt, n > 0 ? devices[0] : 0);
+	if (n > 0) r->r->UseDevices(std::vector<int>(devices, devices + n));
+	return r;
+}
+int rth_renderer_contexts(void* h) { return (int)((RthRenderer*)h)->r->ctxs.size(); }
 void rth_renderer_free(void* h) { RthRenderer* r = (RthRenderer*)h; if (r) { delete r->r; delete r; } }
 const char* rth_renderer_error(void* h) { return ((RthRenderer*)h)->err.c_str(); }
 void* rth_renderer_scene(void* h) { return &((RthRenderer*)h)->scene; }
 int rth_renderer_init(void* h) { RthRenderer* r = (RthRenderer*)h; GUARD(r, r->r->Init()); return 0; }
 void* rth_renderer_ctx(void* h) { return ((RthRenderer*)h)->r->ctx; }
-int rth_renderer_commit(void* h) { RthRenderer* r = (RthRenderer*)h; GUARD(r, r->r->scene.Commit(r->r->ctx)); return 0; }
+int rth_renderer_commit(void* h) { RthRenderer* r = (RthRenderer*)h; GUARD(r, r->r->Commit()); return 0; }
 void rth_renderer_set_camera(void* h, const float* camPos, const float* TL, const float* TR, const float* BL, int fisheye, float viewAngle, float yAngle)
 {
 	Camera& c = ((RthRenderer*)h)->r->camera;

@@ -284,6 +284,7 @@ public:
 	bool LoadSkyHDR(const char* path, std::string* why = nullptr);
 	// flatten + upload to the device context (must be called before queries / rendering)
 	void Commit(rt_ctx* ctx);
+	void CommitAlso(rt_ctx* other) const; // the same flattened scene to one more context (multi-GPU: every GPU holds a copy)
 
 	// template/scene.h:1210: mesh wobble + bvh::Refit, executed on the device (rt_set_time); the
 	// reference runs it only when animOn (raytracer && defaultAnim && !useTLAS)
@@ -327,11 +328,19 @@ private:
 };
 
 // renderer.h / renderer.cpp
+// One GPU: exactly the reference's shape.  Several GPUs: UseDevices() before Init() makes Init create
+// one rt_ctx per device; Commit() uploads the scene to each; Tick() renders the interleaved rows k, k + n, ... on
+// context k from one host thread per context, gathers the rows into context 0's accumulator device to device
+// (rt_gather_rows) and resolves there.  Pixels are independent (per-pixel RNG streams), so the frame is the
+// one-GPU frame bit for bit.
 class Renderer {
 public:
 	Renderer(int width, int height, int device = 0);
 	~Renderer();
+	void UseDevices(const std::vector<int>& devs);         // before Init(); a device may be named twice (two contexts on it)
+	void UseAllDevices();                                  // every device rt_device_count() reports
 	void Init();                                           // renderer.cpp:5-11
+	void Commit();                                         // scene.Commit() on every context
 	float3 Trace(Ray& ray, int depth, float3 energy);      // renderer.cpp:21 (energy must be float3(1), as at its only call site :269)
 	float3 Sample(Ray& ray, int depth, float3 energy);     // renderer.cpp:128
 	void Tick(float deltaTime);                            // renderer.cpp:240
@@ -341,7 +350,9 @@ public:
 	Scene scene;
 	Camera camera;
 	int width, height, device;
-	rt_ctx* ctx = nullptr;
+	rt_ctx* ctx = nullptr;            // context 0: holds the gathered accumulator, resolves the pixels
+	std::vector<rt_ctx*> ctxs;        // all contexts, ctxs[0] == ctx
+	std::vector<int> devices;
 	uint32_t seedBase = 0x12345678; // template/template.cpp:671
 	uint32_t frame = 0;
 	bool downloadEachTick = true;

@@ -2,7 +2,9 @@
 // reference's signatures.  The pixel loop of Tick (renderer.cpp:259-291) is one rt_render() +
 // rt_resolve() pair on the device; Trace and Sample evaluate a caller-supplied ray there too.
 #include "rapt.h"
+#include <exception>
 #include <stdexcept>
+#include <thread>
 
 namespace rapt {
 
@@ -11,14 +13,33 @@ static void check(rt_ctx* ctx, int rc)
 	if (rc != RT_OK) throw std::runtime_error(std::string("rt_amd: ") + rt_last_error(ctx));
 }
 
-Renderer::Renderer(int w, int h, int dev) : width(w), height(h), device(dev) { camera.Reset(w, h); }
+Renderer::Renderer(int w, int h, int dev) : width(w), height(h), device(dev) { camera.Reset(w, h); devices.assign(1, dev); }
+
+void Renderer::UseDevices(const std::vector<int>& devs)
+{
+	if (ctx) throw std::runtime_error("Renderer::UseDevices: call before Init()");
+	if (devs.empty()) throw std::runtime_error("Renderer::UseDevices: no device");
+	devices = devs;
+	device = devs[0];
+}
+void Renderer::UseAllDevices()
+{
+	std::vector<int> d;
+	for (int i = 0; i < rt_device_count(); i++) d.push_back(i);
+	if (d.empty()) throw std::runtime_error("rt_amd: no HIP device");
+	UseDevices(d);
+}
 Renderer::~Renderer() { Shutdown(); }
 
 void Renderer::Init() // renderer.cpp:5-11: allocate and zero the float4 accumulator
 {
 	if (ctx) return;
-	ctx = rt_create(device, width, height);
-	if (!ctx) throw std::runtime_error(std::string("rt_amd: ") + rt_last_error(nullptr));
+	for (int d : devices) {
+		rt_ctx* c = rt_create(d, width, height);
+		if (!c) { const std::string why = rt_last_error(nullptr); for (rt_ctx* o : ctxs) rt_destroy(o); ctxs.clear(); throw std::runtime_error("rt_amd: " + why); }
+		ctxs.push_back(c);
+	}
+	ctx = ctxs[0];
 	accumulator = new float4[(size_t)width * height]();
 	screenPixels = new uint32_t[(size_t)width * height];
 	memset(screenPixels, 0, 4 * (size_t)width * height);
@@ -27,11 +48,19 @@ void Renderer::Init() // renderer.cpp:5-11: allocate and zero the float4 accumul
 
 void Renderer::Shutdown()
 {
-	if (ctx) rt_destroy(ctx);
+	for (rt_ctx* c : ctxs) rt_destroy(c);
+	ctxs.clear();
 	ctx = nullptr;
 	delete[] accumulator;
 	delete[] screenPixels;
 	accumulator = nullptr, screenPixels = nullptr;
+}
+
+void Renderer::Commit()
+{
+	if (!ctx) Init();
+	scene.Commit(ctx);
+	for (size_t k = 1; k < ctxs.size(); k++) scene.CommitAlso(ctxs[k]);
 }
 
 void Renderer::SyncCamera()
@@ -43,7 +72,7 @@ void Renderer::SyncCamera()
 	c.top_right[0] = camera.topRight.x, c.top_right[1] = camera.topRight.y, c.top_right[2] = camera.topRight.z;
 	c.bottom_left[0] = camera.bottomLeft.x, c.bottom_left[1] = camera.bottomLeft.y, c.bottom_left[2] = camera.bottomLeft.z;
 	c.fisheye = camera.fishEye ? 1 : 0, c.view_angle = camera.viewAngle, c.y_angle = camera.yAngle;
-	check(ctx, rt_set_camera(ctx, &c));
+	for (rt_ctx* k : ctxs) check(k, rt_set_camera(k, &c));
 }
 
 // renderer.cpp:240-305 without the animation, input and printf parts.  As in the reference, 'it' is read before a
@@ -57,11 +86,34 @@ void Renderer::Tick(float /*deltaTime*/)
 	const bool camChanged = camera.GetChange();
 	if (camChanged && !scene.raytracer) {
 		scene.SetIterationNumber(1);
-		check(ctx, rt_clear(ctx)); // accumulator[...] = float3(0) for every pixel (:273-275)
+		for (rt_ctx* k : ctxs) check(k, rt_clear(k)); // accumulator[...] = float3(0) for every pixel (:273-275)
 	}
 	SyncCamera();
 	const int mode = scene.raytracer ? RT_MODE_WHITTED : RT_MODE_PATH;
-	check(ctx, rt_render(ctx, mode, frame, 1, seedBase, 0, height, 4));
+	const int n = (int)ctxs.size();
+	if (n == 1) check(ctx, rt_render(ctx, mode, frame, 1, seedBase, 0, height, 4));
+	else {
+		// the scanline loop of renderer.cpp:259, one interleaved share of the rows per GPU: one host thread per context
+		// (a context is not thread safe, and each thread binds its context's device)
+		std::vector<std::exception_ptr> errs((size_t)n);
+		std::vector<std::thread> pool;
+		for (int k = 0; k < n; k++)
+			pool.emplace_back([&, k]() {
+				try {
+					const int count = (height - k + n - 1) / n;
+					if (count > 0) {
+						check(ctxs[k], rt_render_rows(ctxs[k], mode, frame, 1, seedBase, k, n, count, 4));
+						check(ctxs[k], rt_synchronize(ctxs[k]));
+					}
+				} catch (...) { errs[(size_t)k] = std::current_exception(); }
+			});
+		for (auto& t : pool) t.join();
+		for (auto& e : errs) if (e) std::rethrow_exception(e);
+		for (int k = 1; k < n; k++) {
+			const int count = (height - k + n - 1) / n;
+			if (count > 0) check(ctx, rt_gather_rows(ctx, ctxs[k], k, n, count));
+		}
+	}
 	if (!scene.raytracer) frame++;
 	check(ctx, rt_resolve(ctx, it, 0, height, screenPixels));
 	if (downloadEachTick) check(ctx, rt_download_accumulator(ctx, 0, height, &accumulator[0].x));

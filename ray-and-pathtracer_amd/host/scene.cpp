@@ -380,6 +380,12 @@ void Scene::Commit(rt_ctx* c)
 	check(ctx, rt_upload_scene(ctx, &Describe()));
 }
 
+void Scene::CommitAlso(rt_ctx* other) const
+{
+	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");
+	check(other, rt_upload_scene(other, &const_cast<Scene*>(this)->Describe()));
+}
+
 void Scene::SetTime(float t)
 {
 	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");

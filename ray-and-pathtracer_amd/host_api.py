@@ -24,7 +24,7 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_render", "rt_render_rows", "rt_clear", "rt_download_accumulator", "rt_resolve", "rt_accumulator_device_ptr",
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
-              "rt_build_bvh"]
+              "rt_build_bvh", "rt_gather_rows", "rt_device_of"]
 
 
 class RtCamera(C.Structure):
@@ -105,7 +105,7 @@ def host_lib():
         if not os.path.exists(HOST_SO):
             raise RuntimeError("librapt_host.so is not built (run __graft_entry__.build())")
         L = C.CDLL(HOST_SO)
-        for name in ["rth_scene_new", "rth_renderer_new", "rth_renderer_scene", "rth_renderer_ctx", "rth_describe",
+        for name in ["rth_scene_new", "rth_renderer_new", "rth_renderer_new_multi", "rth_renderer_scene", "rth_renderer_ctx", "rth_describe",
                      "rth_renderer_accumulator", "rth_renderer_pixels", "rth_get_sky"]:
             getattr(L, name).restype = C.c_void_p
         L.rth_last_error.restype = C.c_char_p
@@ -275,11 +275,17 @@ class HostRenderer:
     """rapt::Renderer (Init / Tick / Trace / Sample) plus direct access to its device context through
     the C ABI of include/rt_amd.h."""
 
-    def __init__(self, width, height, device=0):
+    def __init__(self, width, height, device=0, devices=None):
+        """devices: list of HIP devices for rapt::Renderer::UseDevices (one context each; Tick shards the rows over
+        them and gathers into context 0).  A device may repeat: [0, 0] runs the multi-context path on one GPU."""
         self.L = host_lib()
         self.rt = rt_lib()
         self.w, self.hgt = width, height
-        self.h = C.c_void_p(self.L.rth_renderer_new(width, height, device))
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            self.h = C.c_void_p(self.L.rth_renderer_new_multi(width, height, len(devices), arr))
+        else:
+            self.h = C.c_void_p(self.L.rth_renderer_new(width, height, device))
         self.scene = HostScene(self.L.rth_renderer_scene(self.h))
         self._chk(self.L.rth_renderer_init(self.h))
         self.ctx = C.c_void_p(self.L.rth_renderer_ctx(self.h))

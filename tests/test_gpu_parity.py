@@ -265,6 +265,62 @@ def test_tick_with_camera_change(scenes, oracle_api, host_api):
     r.close()
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0, 1], "all"])
+def test_multi_context_renderer(devices, scenes, oracle_api, host_api):
+    """rapt::Renderer over several contexts (SURVEY.md 8e: one host thread + one rt_ctx per GPU, rows interleaved,
+    device-to-device gather into context 0): Whitted and path Ticks must give the one-context frame bit for bit.
+    [0, 0] / [0, 0, 0] run the whole multi-context path on one GPU; [0, 1] and "all" need more than one."""
+    ndev = host_api.rt_lib().rt_device_count()
+    if devices == "all":
+        devices = list(range(ndev))
+    if max(devices) >= ndev or (len(set(devices)) > 1 and ndev < 2) or len(devices) < 2:
+        pytest.skip("needs %d HIP devices, %d visible" % (max(devices) + 1, ndev))
+    w, h = 96, 61  # an odd height: the shares differ in size
+    frames = {}
+    for key, devs in (("one", None), ("many", devices)):
+        r = host_api.HostRenderer(w, h, devices=devs)
+        d = scenes.pretty_tlas(r.scene, n_instances=4)
+        r.commit()
+        c = d["camera"]
+        r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+        r.tick()
+        out = [r.tick_accumulator().copy(), r.tick_pixels().copy()]
+        r.scene.set_raytracer(False)
+        for _ in range(3):
+            r.tick()
+        out += [r.tick_accumulator().copy(), r.tick_pixels().copy(), r.iteration()]
+        frames[key] = out
+        r.close()
+    a, b = frames["one"], frames["many"]
+    assert np.isfinite(a[2][..., :3]).mean() > 0.5 and (a[2][..., :3] > 0).mean() > 0.5
+    for k in range(4):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert a[4] == b[4]
+
+
+def test_bench_two_ranks_equal_one(host_api):
+    """bench.py --gpus 2 through torch.distributed.run (one process per rank, rows interleaved, accumulator gather to
+    rank 0) must report the frame checksum of the one-rank run.  With two GPUs visible the ranks use the RCCL
+    ("nccl") backend on a GPU each, exactly like the driver's scaling runs; on a one-GPU box the gloo rehearsal
+    mode lets both ranks share the device."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    ndev = host_api.rt_lib().rt_device_count()
+    common = ["--steps", "1", "--warmup", "0", "--width", "320", "--height", "181", "--spp", "4", "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if ndev < 2:
+        env["RAPT_DIST_BACKEND"] = "gloo"
+    def last_json(out):
+        return json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
+    one = last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env, cwd=ROOT, timeout=600))
+    two = last_json(subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                             "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, cwd=ROOT, timeout=600))
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["metric"] == two["metric"] == "Mrays/s at 320×181×4spp"
+    assert one["frame_checksum"] == two["frame_checksum"]
+    assert two["rays_per_step"] == one["rays_per_step"]  # the two shards trace exactly the rays of the whole frame
+
+
 def test_edge_cases(scenes, oracle_api, host_api):
     r = host_api.HostRenderer(16, 8)
     # calls before a scene is uploaded fail loudly
