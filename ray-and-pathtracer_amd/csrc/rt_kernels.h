@@ -38,8 +38,8 @@ struct DCamera {
 struct PathState {
 	float4* O[2];    // ray origin xyz, w = ray.t on entry (tmax); double buffered by round parity
 	float4* D[2];    // ray direction xyz
-	float4* hitN;    // hit normal xyz, w = t
-	int2* hitId;     // objIdx, material
+	float4* hitN[2]; // hit normal xyz, w = t; double buffered by round parity like the rays: light of round r still reads
+	int2* hitId[2];  // objIdx, material           its hit while extend of round r + 1 (overlapped with connect of round r) writes the next
 	float4* W;       // path weight xyz, w = depth (int bits)
 	float4* E;       // energy xyz, w = RNG state (uint bits)
 	float4* L;       // radiance of the current sample xyz, w = sample id in the pool (uint bits)
@@ -383,11 +383,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DScene S, DCamera C, Rend
 }
 
 // round bookkeeping between kernels: reset the work heads and the queue counts
-__global__ void k_round_begin(Queues Q, int poolFollowsEnded, int allActive)
+// which = 1: the extend side (active / ended counts, extend's work heads); 2: the connect side (shadow count, connect's
+// work heads); 3: both.  They are reset apart when connect of round r runs beside extend of round r + 1.
+__global__ void k_round_begin(Queues Q, int poolFollowsEnded, int allActive, int which)
 {
-	if (poolFollowsEnded) Q.counts[7] += Q.counts[1]; // k_finish handed out one pool sample per ended slot
-	Q.counts[0] = allActive, Q.counts[1] = 0, Q.counts[2] = 0; // allActive: the number of slots when all are ACTIVE and no queue is built (0 otherwise)
-	for (int h = 0; h < 2 * RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
+	if (which & 1) {
+		if (poolFollowsEnded) Q.counts[7] += Q.counts[1]; // k_finish handed out one pool sample per ended slot
+		Q.counts[0] = allActive, Q.counts[1] = 0; // allActive: the number of slots when all are ACTIVE and no queue is built (0 otherwise)
+		for (int h = 0; h < RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
+	}
+	if (which & 2) {
+		Q.counts[2] = 0;
+		for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
+	}
 }
 
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
@@ -417,8 +425,8 @@ struct ExtendPolicy {
 		const PathState& Pc = P;
 		const int par = parity;
 		resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = xyz(Pc.O[par][slot]), d = xyz(Pc.D[par][slot]); }, objIdx, mat, normal);
-		P.hitN[slot] = mk4(normal, hit.t);
-		P.hitId[slot] = make_int2(objIdx, mat);
+		P.hitN[parity][slot] = mk4(normal, hit.t);
+		P.hitId[parity][slot] = make_int2(objIdx, mat);
 	}
 };
 template <bool COUNT, bool DENSE>
@@ -449,8 +457,8 @@ __global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R,
 		RT_CHECK(slot >= 0 && slot < P.nSlots, 12, &Q.counts[3]);
 		bool keep = false, wantShadow = false, ended = false;
 		{
-			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
-			const int2 id = P.hitId[slot];
+			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[parity][slot];
+			const int2 id = P.hitId[parity][slot];
 			// fresh: first segment of a sample whose slot index is its sample (k_generate did not write W and L)
 			const float4 e4 = P.E[slot];
 			const float4 w4 = fresh ? make_float4(1, 1, 1, __int_as_float(start_depth(R))) : P.W[slot];
@@ -616,8 +624,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, Pa
 		RT_CHECK(slot >= 0 && slot < P.nSlots, 13, &Q.counts[3]);
 		const unsigned char stBits = P.status[slot];
 		{
-			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[slot];
-			const int2 id = P.hitId[slot];
+			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[parity][slot];
+			const int2 id = P.hitId[parity][slot];
 			const float4 e4 = P.E[slot], l4 = P.L[slot];
 			const float4 w4 = P.sh[(size_t)S.nLights * P.nSlots + slot];
 			const f3 D = xyz(d4), normal = xyz(hn);

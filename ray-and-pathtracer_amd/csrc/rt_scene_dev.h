@@ -239,6 +239,11 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
                          // same-address atomic per wave at the end of a launch: 16 -> 3 took a 2 M-ray frame from 5.1 to
                          // 4.7 ms, but 3 costs balance on the full frame)
 #endif
+#ifdef RT_TAIL_PROBE
+// measurement build: when does a traversal launch run out of queue entries, and when does its last wave leave?
+// [0] first wave in, [1] first wave that finds every sub-queue empty, [2] last wave out (s_memrealtime, 100 MHz)
+__device__ unsigned long long g_tailProbe[4];
+#endif
 template <bool ANY, bool COUNT, bool HEAD, class Policy>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
@@ -257,6 +262,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	int chunk = subLen / (wavesPerHead * 2); // size of the next reservation
 	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= 64 ? 64 : (chunk & ~63));
 	Stack st = make_stack(ldsStack, spill, overflow);
+#ifdef RT_TAIL_PROBE
+	if ((threadIdx.x & 63) == 0) atomicMin(&g_tailProbe[0], __builtin_amdgcn_s_memrealtime());
+	bool probed = false;
+#endif
 	int work = -1;           // queue entry this lane is tracing, -1 = idle
 	int chunkNext = 0, chunkEnd = 0; // wave-uniform: reserved, not yet handed out
 	bool exhausted = n <= 0; // wave-uniform: the queue has no more entries
@@ -338,9 +347,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				}
 			}
 		}
+#ifdef RT_TAIL_PROBE
+		if (exhausted && !probed) { probed = true; if (lane == 0) atomicMin(&g_tailProbe[1], __builtin_amdgcn_s_memrealtime()); }
+#endif
 		const bool stepping = work >= 0 && link != RT_LINK_DONE;
 		if (__ballot(stepping) == 0) {
 			if (exhausted && __ballot(work >= 0) == 0) {
+#ifdef RT_TAIL_PROBE
+				if (lane == 0) atomicMax(&g_tailProbe[2], __builtin_amdgcn_s_memrealtime());
+#endif
 #ifdef RT_EXPERIMENT_EXTRA_LOADS
 				if (xdummy == 0x7fc12345u && n < 0) *overflow = 3; // keeps the register allocated to the loads
 #endif
