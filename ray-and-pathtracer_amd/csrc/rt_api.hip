@@ -53,21 +53,15 @@ struct rt_ctx {
 		hipStream_t stream = nullptr; // pool 0 runs on the context's stream
 		uint* spill = nullptr;
 		hipEvent_t done = nullptr;
-		// connect of round r beside extend of round r + 1 (run_rounds_overlapped): its own stream and stack spill area
-		hipStream_t stream2 = nullptr;
-		uint* spill2 = nullptr;
-		hipEvent_t shaded = nullptr, connected = nullptr;
 	};
 	Pool pools[RT_MAX_POOLS];
-	int overlapConnect = -1; // connect of a round beside extend of the next (run_rounds_overlapped): -1 for batches under
-	                         // RT_OVERLAP_MAX samples, where the launches' drains are a real share of the frame (a 1080p x 8 batch:
-	                         // 11.3 -> 10.6 ms; the full 1080p x 64 batch: 60.7 -> 62.2, the two kernels only disturb each other); RT_OVERLAP=0 / 1 forces
+	int fuseTraversal = -1;  // one traversal launch per round (run_rounds_fused): -1 for batches under RT_FUSE_MAX samples, RT_FUSE=0 / 1 forces
 	int nPoolsWanted = 1; // RT_POOLS; measured: 2 pools overlap their kernels but do not shorten the frame
 	hipEvent_t fork = nullptr;
 	// traversal stack spill of pool 0 and of the batch queries + flags
 	uint* spill = nullptr;
 	int gridBlocks = 0;
-	int gridExtend = 0, gridConnect = 0, gridQuery = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
+	int gridExtend = 0, gridConnect = 0, gridQuery = 0, gridTraverse = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
 	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
 	int refillAny = 32; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int pairAgain = 16; // lanes that must still want a pair step for an iteration to repeat it (RT_PAIRAGAIN); tuning bits 20-26
@@ -147,7 +141,7 @@ static void prof_collect(rt_ctx* c)
 }
 
 #ifdef RT_TAIL_PROBE
-// measurement build only: print, per traversal launch of the overlapped round loop, how long it ran with work left in
+// measurement build only: print, per traversal launch of the plain round loop (RT_FUSE=0), how long it ran with work left in
 // its queue and how long its drain was
 static void tail_probe_reset(hipStream_t st)
 {
@@ -189,7 +183,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	memset(&c->S, 0, sizeof(c->S));
 	for (int k = 0; k < RT_MAX_POOLS; k++) memset(&c->pools[k].P, 0, sizeof(PathState)), memset(&c->pools[k].Q, 0, sizeof(Queues));
 	if (getenv("RT_POOLS")) c->nPoolsWanted = atoi(getenv("RT_POOLS"));
-	if (getenv("RT_OVERLAP")) c->overlapConnect = atoi(getenv("RT_OVERLAP")) != 0 ? 1 : 0;
+	if (getenv("RT_FUSE")) c->fuseTraversal = atoi(getenv("RT_FUSE")) != 0 ? 1 : 0;
 	if (c->nPoolsWanted < 1) c->nPoolsWanted = 1;
 	if (c->nPoolsWanted > RT_MAX_POOLS) c->nPoolsWanted = RT_MAX_POOLS;
 	memset(&c->prof, 0, sizeof(c->prof));
@@ -207,6 +201,7 @@ rt_ctx* rt_create(int device, int width, int height)
 		const int e0 = std::min(resident((const void*)k_extend<false, false>), resident((const void*)k_extend<false, true>)), e1 = std::min(resident((const void*)k_extend<true, false>), resident((const void*)k_extend<true, true>));
 		const int c0 = resident((const void*)k_connect<false>), c1 = resident((const void*)k_connect<true>);
 		c->gridExtend = e0 < e1 ? e0 : e1, c->gridConnect = c0 < c1 ? c0 : c1;
+		c->gridTraverse = resident((const void*)k_traverse);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
 		const void* qk[6] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true> };
 		for (int i = 0; i < 6; i++) { const int r = resident(qk[i]); if (r < q) q = r; }
@@ -252,10 +247,6 @@ void rt_destroy(rt_ctx* c)
 		if (k > 0 && pl.stream) { (void)hipStreamSynchronize(pl.stream); (void)hipStreamDestroy(pl.stream); }
 		if (k > 0 && pl.spill) (void)hipFree(pl.spill);
 		if (pl.done) (void)hipEventDestroy(pl.done);
-		if (pl.stream2) { (void)hipStreamSynchronize(pl.stream2); (void)hipStreamDestroy(pl.stream2); }
-		if (pl.spill2) (void)hipFree(pl.spill2);
-		if (pl.shaded) (void)hipEventDestroy(pl.shaded);
-		if (pl.connected) (void)hipEventDestroy(pl.connected);
 		free_pool(pl.allocs);
 	}
 	if (c->fork) (void)hipEventDestroy(c->fork);
@@ -938,44 +929,50 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 }
 
 // Path mode with a slot per sample and one pool: exactly 'rounds' rounds, nothing to resume, no finish pass.  The
-// only consumer of connect(r) is light(r), and extend(r + 1) needs neither, so connect(r) runs on a second stream
-// beside extend(r + 1): each of the two persistent traversal launches ends in a drain (the last rays finish alone),
-// and this way one launch's drain is filled by the other's bulk.  light(r) runs after both, before shade(r + 1).
-//   stream : generate | begin(0) extend(0) shade(0) cs(0) | begin(1) ca(1) extend(1)         | light(0) shade(1) cs(1) | ...
-//   stream2:                                               | connect(0)                       |                         | connect(1) ...
-// (cs / ca: compaction of the shadow / active queue).  light(r) still needs the hit of round r while extend(r + 1)
-// writes the next one: hitN / hitId are double buffered by round parity like the rays.
-static int run_rounds_overlapped(rt_ctx* c, const RenderParams& R, int rounds)
+// only consumer of connect(r) is light(r), and extend(r + 1) needs neither, so the two share ONE traversal launch per
+// round: one work list for k_traverse (rt_kernels.h), one drain per round instead of two (a persistent traversal
+// launch ends several hundred microseconds after its queue ran dry, whatever the queue held).  light(r) runs after
+// it and still needs the hit of round r while the launch writes the hits of round r + 1: hitN / hitId are double
+// buffered by round parity like the rays.  Measured (1080p): 8 spp batch 11.3 -> 10.2 ms, 64 spp batch 60.1 -> 60.7
+// (in full waves the mixed nearest / any-hit lanes cost more than the drains), so it is used for batches under
+// RT_FUSE_MAX samples -- the per-GPU share of a multi-GPU frame.  Not used by counting launches (their tallies are
+// kept per kind of query).
+//   generate | begin extend(0) shade(0) cs(0) | begin ca(1) traverse{extend(1), connect(0)} light(0) shade(1) cs(1) | ...
+//   ... | connect(R-1) light(R-1)
+static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 {
 	rt_ctx::Pool& pl = c->pools[0];
-	if (!pl.stream2) HIPCHK(c, hipStreamCreate(&pl.stream2));
-	if (!pl.spill2) HIPCHK(c, hipMalloc((void**)&pl.spill2, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
-	if (!pl.shaded) HIPCHK(c, hipEventCreateWithFlags(&pl.shaded, hipEventDisableTiming));
-	if (!pl.connected) HIPCHK(c, hipEventCreateWithFlags(&pl.connected, hipEventDisableTiming));
 	const float t_min = 0.001f; // renderer.cpp:131
 	const int grid = c->gridBlocks;
 	PathState P = pl.P;
 	P.pend = nullptr, P.pendCount = nullptr;
 	const Queues Q = pl.Q;
-	hipStream_t st = pl.stream, st2 = pl.stream2;
+	hipStream_t st = pl.stream;
 	prof_begin(c, K_GENERATE, st);
 	hipLaunchKernelGGL(k_generate, dim3((P.nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q);
 	prof_end(c, st);
 	const int connectTuning = tuning(c, (c->refillMin & ~0xFF) | c->refillAny);
 	for (int round = 0; round <= rounds; round++) {
 		const int parity = round & 1;
-		if (round < rounds) {
-			const int allActive = round == 0 ? P.nSlots : 0;
-			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, allActive, 1);
-			if (!allActive) hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
+		if (round == 0) {
+			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, P.nSlots, 3);
 			prof_begin(c, K_EXTEND, st);
-			auto extendKernel = c->counting ? (allActive ? k_extend<true, true> : k_extend<true, false>) : (allActive ? k_extend<false, true> : k_extend<false, false>);
-			hipLaunchKernelGGL(extendKernel, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
+			hipLaunchKernelGGL((k_extend<false, true>), dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
+			prof_end(c, st);
+		} else if (round < rounds) {
+			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
+			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
+			prof_begin(c, K_EXTEND, st);
+			hipLaunchKernelGGL(k_traverse, dim3(c->gridTraverse), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill);
+			prof_end(c, st);
+		} else {
+			// the shadow rays of the last round have no extend to share a launch with
+			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
+			prof_begin(c, K_CONNECT, st);
+			hipLaunchKernelGGL(k_connect<false>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, 1 - parity, connectTuning, pl.spill, c->counters + 1);
 			prof_end(c, st);
 		}
 		if (round > 0) {
-			// light of the previous round: after its connect (other stream) and, in stream order, after this round's extend
-			HIPCHK(c, hipStreamWaitEvent(st, pl.connected, 0));
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, R, P, Q, 1 - parity);
 			prof_end(c, st);
@@ -986,16 +983,8 @@ static int run_rounds_overlapped(rt_ctx* c, const RenderParams& R, int rounds)
 			prof_end(c, st);
 			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 0, 0, 2);
 			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
-			HIPCHK(c, hipEventRecord(pl.shaded, st));
-			HIPCHK(c, hipStreamWaitEvent(st2, pl.shaded, 0));
-			prof_begin(c, K_CONNECT, st2);
-			if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st2, c->S, P, Q, parity, connectTuning, pl.spill2, c->counters + 1);
-			else hipLaunchKernelGGL(k_connect<false>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st2, c->S, P, Q, parity, connectTuning, pl.spill2, c->counters + 1);
-			prof_end(c, st2);
-			HIPCHK(c, hipEventRecord(pl.connected, st2));
 		}
 	}
-	// overflow flags, once at the end
 	HIPCHK(c, hipMemcpyAsync(c->hostCounts, Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
 	HIPCHK(c, hipStreamSynchronize(st));
 	const int* hc = c->hostCounts;
@@ -1008,8 +997,8 @@ static int run_rounds_overlapped(rt_ctx* c, const RenderParams& R, int rounds)
 	return RT_OK;
 }
 
-#define RT_OVERLAP_MAX ((size_t)48 << 20)
-static bool use_overlap(const rt_ctx* c, size_t samples) { return c->overlapConnect < 0 ? samples < RT_OVERLAP_MAX : c->overlapConnect != 0; }
+#define RT_FUSE_MAX ((size_t)48 << 20)
+static bool use_fused(const rt_ctx* c, size_t samples) { return !c->counting && (c->fuseTraversal < 0 ? samples < RT_FUSE_MAX : c->fuseTraversal != 0); }
 
 // Split 'total' samples over the pools and size their slots.
 static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& base, RenderParams* Rs, int& nPools, int& maxSlots, bool& slotPerSample)
@@ -1104,7 +1093,7 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		const int maxRounds = (int)((total / nPools + slots) / slots) * seg + seg + 4;
 		const bool direct = mode == RT_MODE_PATH && slotPerSample;
 		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
-		rc = direct && nPools == 1 && use_overlap(c, total) ? run_rounds_overlapped(c, Rs[0], seg) : run_rounds(c, Rs, nPools, maxRounds, direct ? seg : 0);
+		rc = direct && nPools == 1 && use_fused(c, total) ? run_rounds_fused(c, Rs[0], seg) : run_rounds(c, Rs, nPools, maxRounds, direct ? seg : 0);
 		if (rc != RT_OK) return rc;
 		hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 	}
@@ -1155,7 +1144,7 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 		const int seg = segments_per_sample(mode, depth, c->S.nLights);
 		const bool direct = mode == RT_MODE_PATH && slotPerSample;
 		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
-		if (rc == RT_OK) rc = direct && nPools == 1 && use_overlap(c, (size_t)n) ? run_rounds_overlapped(c, Rs[0], seg) : run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, direct ? seg : 0);
+		if (rc == RT_OK) rc = direct && nPools == 1 && use_fused(c, (size_t)n) ? run_rounds_fused(c, Rs[0], seg) : run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, direct ? seg : 0);
 	}
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);

@@ -39,7 +39,7 @@ struct PathState {
 	float4* O[2];    // ray origin xyz, w = ray.t on entry (tmax); double buffered by round parity
 	float4* D[2];    // ray direction xyz
 	float4* hitN[2]; // hit normal xyz, w = t; double buffered by round parity like the rays: light of round r still reads
-	int2* hitId[2];  // objIdx, material           its hit while extend of round r + 1 (overlapped with connect of round r) writes the next
+	int2* hitId[2];  // objIdx, material           its hit after k_traverse wrote the hits of round r + 1 (run_rounds_fused)
 	float4* W;       // path weight xyz, w = depth (int bits)
 	float4* E;       // energy xyz, w = RNG state (uint bits)
 	float4* L;       // radiance of the current sample xyz, w = sample id in the pool (uint bits)
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(DScene S, DCamera C, Rend
 
 // round bookkeeping between kernels: reset the work heads and the queue counts
 // which = 1: the extend side (active / ended counts, extend's work heads); 2: the connect side (shadow count, connect's
-// work heads); 3: both.  They are reset apart when connect of round r runs beside extend of round r + 1.
+// work heads); 3: both.  They are reset apart when connect of round r shares a launch with extend of round r + 1.
 __global__ void k_round_begin(Queues Q, int poolFollowsEnded, int allActive, int which)
 {
 	if (which & 1) {
@@ -611,6 +611,36 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S
 	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights, &Q.counts[3] };
 	trace_persistent<true, COUNT, false>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
+}
+
+// traverse: extend of round r + 1 and connect of round r in ONE persistent launch (path mode with a slot per sample:
+// both only need shade(r), and neither needs the other).  Work items [0, nActive) are the active queue's rays
+// (nearest hit, the long ones: they start first), [nActive, nActive + nShadow * nLights) the shadow rays.
+struct TraversePolicy {
+	ExtendPolicy<false> ext;
+	ConnectPolicy con;
+	int nActive;
+	__device__ __forceinline__ bool any_of(int work) const { return work >= nActive; }
+	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
+	{
+		if (work < nActive) return ext.load(work, O, D, tmax, head);
+		return con.load(work - nActive, O, D, tmax, head);
+	}
+	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& O, const f3& D) const { ext.store(work, hit, O, D); }
+	__device__ __forceinline__ void store(int work, bool occluded) const { con.store(work - nActive, occluded); }
+};
+#ifndef RT_TRAVERSE_WAVES
+#define RT_TRAVERSE_WAVES 7
+#endif
+__global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse(DScene S, PathState P, Queues Q, int parityExtend, float t_min, int refillMin, uint* spill)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	const int nActive = Q.counts[0];
+	TraversePolicy pol{ { S, P, Q.active, parityExtend, &Q.counts[3] }, { P, Q.shadow, 1 - parityExtend, S.nLights, &Q.counts[3] }, nActive };
+	trace_persistent<false, false, false, TraversePolicy, true>(S, pol, nActive + Q.counts[2] * S.nLights, Q.heads, t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 }
 
 // light: the direct-light terms of a diffuse hit, in light order.

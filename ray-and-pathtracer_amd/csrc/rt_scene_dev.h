@@ -217,6 +217,10 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 //                                                     candidate hit of head tests already made); false = nothing to trace
 //   void store(int work, const HitRef&, O, D)         nearest-hit result      (ANY == false)
 //   void store(int work, bool occluded)               occlusion result        (ANY == true)
+// MIXED == true: one launch serves nearest-hit and any-hit work items side by side (the policy says which a work
+// item is: bool any_of(int work)); ANY is then ignored.  One persistent launch per round instead of two means one
+// drain per round instead of two (a launch ends when its longest ray does, several hundred microseconds after the
+// queue ran dry, whatever the queue held).
 #define RT_INST_BIT 0x40000000u // link names an instance (TLAS leaf)
 #define RT_LINK_EXIT 0xFFFFFFFCu // leave the current instance (the sentinel was popped)
 #define RT_LINK_DONE 0xFFFFFFFBu // this ray is finished; its result is written at the next refill
@@ -244,7 +248,7 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // [0] first wave in, [1] first wave that finds every sub-queue empty, [2] last wave out (s_memrealtime, 100 MHz)
 __device__ unsigned long long g_tailProbe[4];
 #endif
-template <bool ANY, bool COUNT, bool HEAD, class Policy>
+template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
@@ -275,6 +279,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	HitRef hit;
 	hit.kind = -1, hit.inst = -1, hit.prim = 0, hit.t = 0;
 	int inst = -1;
+	bool laneAny = ANY;  // MIXED: this lane's work item is an occlusion query
 	bool clean = false; // the current (world or object space) ray cannot produce a NaN slab product
 #ifdef RT_EXPERIMENT_EXTRA_LOADS
 	uint xdummy = 0;
@@ -298,7 +303,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				if (doneLane) {
 					RT_CHECK(work >= 0 && work < n && st.sp <= RT_STACK_MAX, 4, overflow);
 					// results are written here, many lanes at a time, not one lane per iteration
-					if constexpr (ANY) pol.store(work, hit.kind == 1);
+					if constexpr (MIXED) {
+						if (laneAny) pol.store(work, hit.kind == 1);
+						else { hit.t = rayT; pol.store(work, hit, O, D); }
+					} else if constexpr (ANY) pol.store(work, hit.kind == 1);
 					else { hit.t = rayT; pol.store(work, hit, O, D); }
 					work = -1;
 				}
@@ -333,6 +341,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 						// a work item may turn out to be nothing to trace: the lane stays idle
 						if (take && pol.load(mine, O, D, tmax, hit)) {
 							work = mine;
+							if constexpr (MIXED) laneAny = pol.any_of(mine);
 							rayT = tmax;
 							st.sp = 0, inst = -1;
 							if (!ANY && HEAD) find_nearest_head<COUNT>(S, O, D, t_min, rayT, hit, lc);
@@ -447,10 +456,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			bool h;
 			if (kind == RT_KIND_TRI) h = tri_hit(O, D, rayT, bvh_t_min, xyz(r0), xyz(r1), xyz(r2), f3(r0.w, r1.w, r2.w), r3.x, t);
 			else if (kind == RT_KIND_SPHERE) {
-				if (ANY) h = sphere_occludes(O, D, rayT, bvh_t_min, xyz(r0), r0.w);
+				if (MIXED ? laneAny : ANY) h = sphere_occludes(O, D, rayT, bvh_t_min, xyz(r0), r0.w);
 				else h = sphere_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
 			} else h = plane_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
-			if (h && ANY) hit.kind = 1, link = RT_LINK_DONE; // first occluder ends the query
+			if (h && (MIXED ? laneAny : ANY)) hit.kind = 1, link = RT_LINK_DONE; // first occluder ends the query
 			else {
 				if (h) rayT = t, hit.prim = slot, hit.inst = inst, hit.kind = 0;
 				if (kl & RT_LAST_BIT) pop_next();
