@@ -34,6 +34,7 @@ struct rt_ctx {
 	// animation (rt_set_time): original leaf records of the scene BVH and its pair records by level
 	float4* primsOrig = nullptr;
 	float4* pairsMut = nullptr; float4* primsMut = nullptr;
+	float4* wideMut = nullptr; int wideNodes = 0; // 4-wide nodes: their boxes follow the pair records after a refit
 	uint* refitOrder = nullptr; int* refitLevelStart = nullptr;
 	int refitLevels = 0, animSlots = 0;
 	// camera
@@ -61,7 +62,7 @@ struct rt_ctx {
 	// traversal stack spill of pool 0 and of the batch queries + flags
 	uint* spill = nullptr;
 	int gridBlocks = 0;
-	int gridExtend = 0, gridConnect = 0, gridQuery = 0, gridTraverse = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
+	int gridExtend = 0, gridConnect = 0, gridQuery = 0, gridTraverse = 0, gridConnectWide = 0, gridLeftover = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
 	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
 	int refillAny = 32; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int pairAgain = 16; // lanes that must still want a pair step for an iteration to repeat it (RT_PAIRAGAIN); tuning bits 20-26
@@ -202,9 +203,12 @@ rt_ctx* rt_create(int device, int width, int height)
 		const int c0 = resident((const void*)k_connect<false>), c1 = resident((const void*)k_connect<true>);
 		c->gridExtend = e0 < e1 ? e0 : e1, c->gridConnect = c0 < c1 ? c0 : c1;
 		c->gridTraverse = resident((const void*)k_traverse);
+		c->gridConnectWide = resident((const void*)k_connect<false, true>);
+		c->gridLeftover = std::min(resident((const void*)k_connect<false, false, true>), prop.multiProcessorCount); // a short list: one block per CU is plenty
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
-		const void* qk[6] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true> };
-		for (int i = 0; i < 6; i++) { const int r = resident(qk[i]); if (r < q) q = r; }
+		const void* qk[8] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true>,
+		                      (const void*)k_query_occluded<false, true>, (const void*)k_query_occluded<false, false, true> };
+		for (int i = 0; i < 8; i++) { const int r = resident(qk[i]); if (r < q) q = r; }
 		c->gridQuery = q;
 	}
 	if (getenv("RT_REFILL")) c->refillMin = atoi(getenv("RT_REFILL"));
@@ -326,7 +330,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 
 	// pairs + prims of every BLAS, concatenated
 	std::vector<float> pairs, prims;
-	std::vector<uint> rootLink(d->n_blas);
+	std::vector<uint> rootLink(d->n_blas), pairOffOf(d->n_blas);
 	for (uint k = 0; k < d->n_blas; k++) {
 		const rt_blas& b = d->blas[k];
 		if (b.nodes_used < 1 || (b.nodes_used & 1) || !b.nodes) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u has %u nodes (expected an even count >= 2)", k, b.nodes_used);
@@ -343,6 +347,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 					return fail(c, RT_E_UNSUPPORTED, "rt_upload_scene: blas %u node %u has a non-finite bound or one beyond 1e30", k, i);
 		}
 		const uint pairOff = (uint)(pairs.size() / 16), primOff = (uint)(prims.size() / 16);
+		pairOffOf[k] = pairOff;
 		std::vector<char> last(b.n_prims, 0);
 		auto link_of = [&](uint i) -> uint {
 			const rt_bvh_node& nd = b.nodes[i];
@@ -376,6 +381,71 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			if (p >= b.n_prims) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u prim_idx[%u] = %u out of range", k, j, p);
 			pack_prim(&prims[(size_t)(primOff + j) * 16], b, p, last[j] != 0);
 		}
+	}
+	// 4-wide nodes (rt_scene_dev.h, wide[]): collapse every BLAS; all or nothing (one flag for the kernels)
+	std::vector<float> wide;
+	std::vector<uint> rootWide(d->n_blas);
+	// Off unless RT_WIDE=1: exact (tests/test_gpu_parity.py::test_wide_walk_*), but measured 6 % SLOWER than the binary
+	// walk on the bench scene (connect 11.2 -> 11.9 ms per step; 12.9 without the distance sort): four slab tests, a
+	// sorting network and up to three pushes per step cost more issue slots than the halved fetch chain returns.
+	bool wideOK = getenv("RT_WIDE") ? atoi(getenv("RT_WIDE")) != 0 : false;
+	{
+		size_t primBase = 0;
+		for (uint k = 0; k < d->n_blas && wideOK; k++) {
+			const rt_blas& b = d->blas[k];
+			const uint primOff = (uint)primBase;
+			primBase += b.n_prims;
+			rootWide[k] = rootLink[k];
+			if (b.n_prims == 0 || b.nodes[0].prim_count > 0) continue; // empty, or the root is a leaf
+			// nested?  (parents are unions of their children after bvh::Refit, bvh.cpp:556-594)
+			for (uint i = 0; i < b.nodes_used && wideOK; i++) {
+				if (i == 1 || b.nodes[i].prim_count > 0) continue;
+				for (uint ci = b.nodes[i].left_first; ci < b.nodes[i].left_first + 2; ci++)
+					for (int a = 0; a < 3; a++)
+						if (!(b.nodes[ci].aabb_min[a] >= b.nodes[i].aabb_min[a]) || !(b.nodes[ci].aabb_max[a] <= b.nodes[i].aabb_max[a])) wideOK = false;
+			}
+			if (!wideOK) break;
+			auto area = [&](uint i) { const rt_bvh_node& n = b.nodes[i]; const double ex = (double)n.aabb_max[0] - n.aabb_min[0], ey = (double)n.aabb_max[1] - n.aabb_min[1], ez = (double)n.aabb_max[2] - n.aabb_min[2]; return ex * ey + ey * ez + ez * ex; };
+			// depth-first emission; a record is reserved when its binary node is first reached
+			std::vector<std::pair<uint, uint>> todo; // (binary inner node, wide record)
+			auto reserve = [&]() { const uint w = (uint)(wide.size() / 32); wide.resize(wide.size() + 32, 0.0f); return w; };
+			const uint rootRec = reserve();
+			rootWide[k] = rootRec;
+			todo.push_back({ 0u, rootRec });
+			while (!todo.empty()) {
+				const uint node = todo.back().first, rec = todo.back().second;
+				todo.pop_back();
+				uint ch[4];
+				int n = 2;
+				ch[0] = b.nodes[node].left_first, ch[1] = ch[0] + 1;
+				while (n < 4) {
+					int best = -1;
+					double bestA = -1;
+					for (int j = 0; j < n; j++)
+						if (b.nodes[ch[j]].prim_count == 0 && area(ch[j]) > bestA) best = j, bestA = area(ch[j]);
+					if (best < 0) break;
+					const uint lf = b.nodes[ch[best]].left_first;
+					for (int j = n; j > best + 1; j--) ch[j] = ch[j - 1];
+					ch[best] = lf, ch[best + 1] = lf + 1;
+					n++;
+				}
+				float* r = &wide[(size_t)rec * 32];
+				for (int j = 0; j < 4; j++) {
+					uint link = RT_EMPTY, src = 0xFFFFFFFFu;
+					float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f }; // inverted: never hit
+					if (j < n) {
+						const rt_bvh_node& c2 = b.nodes[ch[j]];
+						memcpy(lo, c2.aabb_min, 12), memcpy(hi, c2.aabb_max, 12);
+						src = pairOffOf[k] * 2 + ch[j]; // global binary node number: pair record (src / 2), side (src & 1)
+						if (c2.prim_count > 0) link = RT_LEAF_BIT | (primOff + c2.left_first);
+						else { link = reserve(); r = &wide[(size_t)rec * 32]; todo.push_back({ ch[j], link }); }
+					}
+					for (int a = 0; a < 3; a++) r[4 * a + j] = lo[a], r[12 + 4 * a + j] = hi[a];
+					memcpy(&r[24 + j], &link, 4), memcpy(&r[28 + j], &src, 4);
+				}
+			}
+		}
+		if (!wideOK) wide.clear();
 	}
 	// TLAS inner nodes -> pair records appended to the BLAS pairs (children boxes inside the parent's
 	// record; child A = leftRight & 0xFFFF, the one tlas::Intersect tests first)
@@ -423,6 +493,13 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	HIPCHK(c, hipMemcpy(dp, prims.data(), prims.size() * 4, hipMemcpyHostToDevice));
 	S.prims = (const float4*)dp;
 	S.rootLink = d->use_tlas ? tlasRoot : rootLink[0];
+	if (!wide.empty() || wideOK) {
+		HIPCHK(c, dalloc(c->sceneAllocs, &dp, wide.size() + 32));
+		if (!wide.empty()) HIPCHK(c, hipMemcpy(dp, wide.data(), wide.size() * 4, hipMemcpyHostToDevice));
+		S.wide = wideOK ? (const float4*)dp : nullptr;
+		S.rootWide = rootWide[0];
+		c->wideMut = (float4*)dp, c->wideNodes = (int)(wide.size() / 32);
+	} else c->wideMut = nullptr, c->wideNodes = 0;
 	c->pairsMut = (float4*)S.pairs, c->primsMut = (float4*)S.prims;
 	c->primsOrig = nullptr, c->refitLevels = 0, c->animSlots = 0;
 	if (!d->use_tlas && d->blas[0].n_prims > 0) {
@@ -461,6 +538,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			memset(&inst[i], 0, sizeof(DInstance));
 			memcpy(inst[i].invT, in.inv_transform, 48), memcpy(inst[i].T, in.transform, 48);
 			inst[i].rootLink = rootLink[in.blas];
+			inst[i].rootWide = rootWide[in.blas];
 		}
 		DInstance* di = nullptr;
 		HIPCHK(c, dalloc(c->sceneAllocs, &di, inst.size()));
@@ -762,6 +840,7 @@ int rt_set_time(rt_ctx* c, float t)
 	const float a = (float)sin((double)r) * 0.5f;
 	hipLaunchKernelGGL(k_animate, dim3((c->animSlots + 255) / 256), dim3(256), 0, c->stream, c->primsOrig, c->primsMut, c->animSlots, a);
 	if (c->refitLevels > 0) hipLaunchKernelGGL(k_refit, dim3(1), dim3(1024), 0, c->stream, c->pairsMut, c->primsMut, c->refitOrder, c->refitLevelStart, c->refitLevels);
+	if (c->S.wide && c->wideNodes > 0) hipLaunchKernelGGL(k_wide_sync, dim3((c->wideNodes * 4 + 255) / 256), dim3(256), 0, c->stream, c->wideMut, c->pairsMut, c->wideNodes);
 	HIPCHK(c, hipGetLastError());
 	return RT_OK;
 }
@@ -801,6 +880,7 @@ static int ensure_state(rt_ctx* c, int k, int nSlots, bool pend)
 	HIPCHK(c, dalloc(pl.allocs, &Q.active, n));
 	HIPCHK(c, dalloc(pl.allocs, &Q.shadow, n));
 	HIPCHK(c, dalloc(pl.allocs, &Q.ended, n));
+	HIPCHK(c, dalloc(pl.allocs, &Q.leftover, n * (size_t)(c->S.nLights > 0 ? c->S.nLights : 1)));
 	HIPCHK(c, dalloc(pl.allocs, &Q.counts, 16));
 	HIPCHK(c, dalloc(pl.allocs, &Q.heads, (size_t)2 * RT_HEADS * RT_HEAD_STRIDE));
 	HIPCHK(c, hipMemset(Q.counts, 0, 16 * sizeof(int)));
@@ -821,6 +901,20 @@ static int ensure_samples(rt_ctx* c, size_t count)
 }
 
 static int slot_budget();
+// Scene::IsOccluded for the shadow queue.  Counting launches walk like the reference; timed launches take the 4-wide
+// walk when the scene has wide nodes, followed by the binary walk over the (normally empty) list of rays the wide
+// walk handed back because they are not clean.
+static void launch_connect(rt_ctx* c, hipStream_t st, const PathState& P, const Queues& Q, int parity, uint* spill)
+{
+	const int tun = tuning(c, (c->refillMin & ~0xFF) | c->refillAny);
+	if (c->counting) hipLaunchKernelGGL((k_connect<true>), dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
+	else if (!c->S.wide) hipLaunchKernelGGL((k_connect<false>), dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
+	else {
+		hipLaunchKernelGGL((k_connect<false, true>), dim3(c->gridConnectWide), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
+		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 0, 0, 4);
+		hipLaunchKernelGGL((k_connect<false, false, true>), dim3(c->gridLeftover), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
+	}
+}
 // The round loop shared by rt_render_rows and rt_trace_batch.  The batch's samples are split over
 // nPools pools (R[k].sampleFirst / nSamples); every pool runs the same sequence of kernels on its own
 // stream, so while one pool's traversal launch drains (its longest rays finish alone, at memory latency
@@ -880,8 +974,7 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 			tail_probe_reset(st);
 #endif
 			prof_begin(c, K_CONNECT, st);
-			if (c->counting) hipLaunchKernelGGL(k_connect<true>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, tuning(c, (c->refillMin & ~0xFF) | c->refillAny), pl.spill, c->counters + 1);
-			else hipLaunchKernelGGL(k_connect<false>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, tuning(c, (c->refillMin & ~0xFF) | c->refillAny), pl.spill, c->counters + 1);
+			launch_connect(c, st, P[k], Q, parity, pl.spill);
 			prof_end(c, st);
 #ifdef RT_TAIL_PROBE
 			tail_probe_print(st, "connect", round);
@@ -906,7 +999,8 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 				const int* hc = c->hostCounts + 16 * k;
 				if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 				else if (hc[3] == 2) rc = fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
-				else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
+				else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
+	else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
 				if (hc[3] != 0) (void)hipMemsetAsync(c->pools[k].Q.counts + 3, 0, sizeof(int), c->pools[k].stream);
 				if (hc[0] == 0 || knownRounds > 0) live[k] = false;
 				any = any || live[k];
@@ -951,7 +1045,6 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 	prof_begin(c, K_GENERATE, st);
 	hipLaunchKernelGGL(k_generate, dim3((P.nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q);
 	prof_end(c, st);
-	const int connectTuning = tuning(c, (c->refillMin & ~0xFF) | c->refillAny);
 	for (int round = 0; round <= rounds; round++) {
 		const int parity = round & 1;
 		if (round == 0) {
@@ -969,7 +1062,7 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 			// the shadow rays of the last round have no extend to share a launch with
 			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
 			prof_begin(c, K_CONNECT, st);
-			hipLaunchKernelGGL(k_connect<false>, dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, 1 - parity, connectTuning, pl.spill, c->counters + 1);
+			launch_connect(c, st, P, Q, 1 - parity, pl.spill);
 			prof_end(c, st);
 		}
 		if (round > 0) {
@@ -990,6 +1083,7 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 	const int* hc = c->hostCounts;
 	int rc = RT_OK;
 	if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+	else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
 	else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
 	if (hc[3] != 0) (void)hipMemsetAsync(Q.counts + 3, 0, sizeof(int), st);
 	if (rc != RT_OK) return rc;
@@ -1236,6 +1330,7 @@ static int check_overflow(rt_ctx* c)
 {
 	int f = 0;
 	HIPCHK(c, hipMemcpy(&f, c->flags + 1, sizeof(int), hipMemcpyDeviceToHost));
+	if (f == 199) { (void)hipMemset(c->flags, 0, 2 * sizeof(int)); return fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays"); }
 	if (f >= 100) { (void)hipMemset(c->flags, 0, 2 * sizeof(int)); return fail(c, RT_E_STATE, "debug check %d failed in a query kernel (RT_DEBUG_CHECKS build)", f - 100); }
 	if (f) { (void)hipMemset(c->flags, 0, 2 * sizeof(int)); return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX); }
 	return RT_OK;
@@ -1284,19 +1379,29 @@ int rt_occluded_batch(rt_ctx* c, int n, const float* O, const float* D, const fl
 	std::vector<void*> tmp;
 	float *dO = nullptr, *dD = nullptr, *dT = nullptr;
 	unsigned char* dR = nullptr;
+	uint* dL = nullptr;
 	int rc = RT_OK;
+	const bool wideWalk = !c->counting && c->S.wide;
 	hipError_t e = dalloc(tmp, &dO, (size_t)3 * n);
 	if (e == hipSuccess) e = dalloc(tmp, &dD, (size_t)3 * n);
 	if (e == hipSuccess && tmax) e = dalloc(tmp, &dT, (size_t)n);
 	if (e == hipSuccess) e = dalloc(tmp, &dR, (size_t)n);
+	if (e == hipSuccess && wideWalk) e = dalloc(tmp, &dL, (size_t)n);
 	if (e == hipSuccess) e = hipMemcpyAsync(dO, O, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_query_occluded<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1);
-		else hipLaunchKernelGGL(k_query_occluded<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1);
+		if (c->counting) hipLaunchKernelGGL((k_query_occluded<true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+		else if (!wideWalk) hipLaunchKernelGGL((k_query_occluded<false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+		else {
+			// the 4-wide walk, then the binary walk over the rays it handed back (not clean: normally none)
+			(void)hipMemsetAsync(c->flags + 2, 0, sizeof(int), c->stream);
+			hipLaunchKernelGGL((k_query_occluded<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+			(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream);
+			hipLaunchKernelGGL((k_query_occluded<false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+		}
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}

@@ -79,7 +79,9 @@ struct Queues {
 	uint* shadow; // compacted SHADOW slots
 	uint* ended;  // compacted ENDED slots (built after light)
 	int* heads;   // work heads of extend ([0, RT_HEADS)) and connect ([RT_HEADS, 2 RT_HEADS)), RT_HEAD_STRIDE ints apart
-	int* counts;  // [0] active count, [1] ended count, [2] shadow count, [3] overflow flag, [4] extend head, [6] connect head, [7] next sample in the pool
+	int* counts;  // [0] active count, [1] ended count, [2] shadow count, [3] overflow flag, [4] extend head, [6] connect head, [7] next sample in the pool,
+	              // [8] shadow rays the wide walk handed back
+	uint* leftover; // connect work items of rays that are not clean (the 4-wide walk is exact for clean rays only): redone by the binary walk
 };
 
 // ---- camera (camera.h:24-41) ---------------------------------------------------------------
@@ -393,9 +395,11 @@ __global__ void k_round_begin(Queues Q, int poolFollowsEnded, int allActive, int
 		for (int h = 0; h < RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
 	}
 	if (which & 2) {
-		Q.counts[2] = 0;
+		Q.counts[2] = 0, Q.counts[8] = 0;
 		for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
 	}
+	if (which & 4) // connect's work heads only: the leftover launch walks its own list with them
+		for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
 }
 
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
@@ -597,19 +601,34 @@ struct ConnectPolicy {
 		const int slot = (int)queue[work / nLights], li = work % nLights;
 		P.vis[(size_t)li * P.nSlots + slot] = occluded ? 1 : 0;
 	}
+	uint* leftoverList; int* leftoverCount;
+	__device__ __forceinline__ void leftover(int work) const { leftoverList[atomicAdd(leftoverCount, 1)] = (uint)work; }
 };
-template <bool COUNT>
+// a list of work items of another policy (the rays a wide walk handed back)
+template <class Base>
+struct ListedPolicy {
+	Base base;
+	const uint* list;
+	__device__ __forceinline__ bool load(int i, f3& O, f3& D, float& tmax, HitRef& head) const { return base.load((int)list[i], O, D, tmax, head); }
+	__device__ __forceinline__ void store(int i, bool occluded) const { base.store((int)list[i], occluded); }
+};
 #ifndef RT_CONNECT_WAVES
 #define RT_CONNECT_WAVES 6
 #endif
+// WIDE: the 4-wide walk (needs S.wide); LISTED: the work items are Q.leftover[0 .. Q.counts[8])
+template <bool COUNT, bool WIDE = false, bool LISTED = false>
 __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S, PathState P, Queues Q, int parity, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights, &Q.counts[3] };
-	trace_persistent<true, COUNT, false>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights, &Q.counts[3], Q.leftover, &Q.counts[8] };
+	if constexpr (LISTED) {
+		ListedPolicy<ConnectPolicy> lp{ pol, Q.leftover };
+		trace_persistent<true, COUNT, false>(S, lp, Q.counts[8], Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	} else
+		trace_persistent<true, COUNT, false, ConnectPolicy, false, WIDE>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -639,7 +658,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse(DScene
 	lc.clear();
 	uint rays = 0;
 	const int nActive = Q.counts[0];
-	TraversePolicy pol{ { S, P, Q.active, parityExtend, &Q.counts[3] }, { P, Q.shadow, 1 - parityExtend, S.nLights, &Q.counts[3] }, nActive };
+	TraversePolicy pol{ { S, P, Q.active, parityExtend, &Q.counts[3] }, { P, Q.shadow, 1 - parityExtend, S.nLights, &Q.counts[3], Q.leftover, &Q.counts[8] }, nActive };
 	trace_persistent<false, false, false, TraversePolicy, true>(S, pol, nActive + Q.counts[2] * S.nLights, Q.heads, t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 }
 
@@ -938,8 +957,10 @@ struct NearestQueryPolicy : ArrayRays {
 };
 struct OccludedQueryPolicy : ArrayRays {
 	unsigned char* out;
-	__device__ __forceinline__ OccludedQueryPolicy(const float* o, const float* d, const float* t, unsigned char* q) : ArrayRays{ o, d, t }, out(q) {}
+	uint* leftoverList; int* leftoverCount;
+	__device__ __forceinline__ OccludedQueryPolicy(const float* o, const float* d, const float* t, unsigned char* q, uint* ll, int* lc) : ArrayRays{ o, d, t }, out(q), leftoverList(ll), leftoverCount(lc) {}
 	__device__ __forceinline__ void store(int i, bool occluded) const { out[i] = occluded ? 1 : 0; }
+	__device__ __forceinline__ void leftover(int i) const { leftoverList[atomicAdd(leftoverCount, 1)] = (uint)i; }
 };
 // Camera::GetPrimaryRay + Scene::FindNearest for every pixel
 struct PrimaryPolicy {
@@ -972,16 +993,21 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, con
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
-template <bool COUNT>
+// work[0] unused, work[1] overflow flag, work[2] rays handed back by the wide walk; LISTED: the items are leftover[0 .. work[2])
+template <bool COUNT, bool WIDE = false, bool LISTED = false>
 __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax, int refillMin,
-                                                             unsigned char* out, uint* spill, int* work, DCounters* counters)
+                                                             unsigned char* out, uint* spill, int* work, DCounters* counters, uint* leftover)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	OccludedQueryPolicy pol(O3, D3, tmax, out);
-	trace_persistent<true, COUNT, false>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	OccludedQueryPolicy pol(O3, D3, tmax, out, leftover, &work[2]);
+	if constexpr (LISTED) {
+		ListedPolicy<OccludedQueryPolicy> lp{ pol, leftover };
+		trace_persistent<true, COUNT, false>(S, lp, work[2], work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	} else
+		trace_persistent<true, COUNT, false, OccludedQueryPolicy, false, WIDE>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -1070,6 +1096,20 @@ __global__ void __launch_bounds__(1024) k_refit(float4* pairs, const float4* pri
 		__threadfence_block();
 		__syncthreads();
 	}
+}
+
+// after k_refit: the 4-wide nodes' child boxes are copies of binary node boxes (record src / 2, side src & 1)
+__global__ void k_wide_sync(float4* wide, const float4* pairs, int nWide)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nWide * 4) return;
+	const int node = i >> 2, j = i & 3;
+	float* w = (float*)(wide + 8 * (size_t)node);
+	const uint src = __float_as_uint(w[28 + j]);
+	if (src == 0xFFFFFFFFu) return;
+	const float4* rec = pairs + 4 * (size_t)(src >> 1);
+	const float4 lo = rec[2 * (src & 1)], hi = rec[2 * (src & 1) + 1];
+	w[0 + j] = lo.x, w[4 + j] = lo.y, w[8 + j] = lo.z, w[12 + j] = hi.x, w[16 + j] = hi.y, w[20 + j] = hi.z;
 }
 
 // RGBF32_to_RGB8(accumulator / it) (renderer.cpp:287-290, template/precomp.h:445-448)

@@ -33,6 +33,18 @@
 //            rule for equal t is untouched and results are identical.  Counting launches either walk like
 //            the reference (no culling: the counters are the reference's tallies) or like the timed
 //            kernels (RT_TUNE_CULL_COUNTED: the counters are the work actually done).
+//   wide[]   4-wide nodes for occlusion queries (the reference's own 4-wide variant is bvh.cpp:335-512,
+//            :658-761).  One 128-byte record = one cache line: {min.x[4]}{min.y[4]}{min.z[4]}{max.x[4]}{max.y[4]}{max.z[4]}
+//            {link[4]}{source[4]}; built at upload by collapsing the reference's binary tree (a node's children are
+//            expanded, largest surface first, until there are four); a child entry carries the binary node's OWN box,
+//            an unused entry an inverted box.  Why this is exact for Scene::IsOccluded: the answer is "some primitive of
+//            some visited leaf occludes", a leaf is visited by the reference iff every binary ancestor's box passes
+//            the slab test, and for a ray that cannot produce a NaN slab product (ray_is_clean) a box that passes
+//            implies every box CONTAINING it passes (rounding is monotone: (b - O) * rD keeps the order of the b's), so
+//            with nested boxes -- checked at upload, parents are unions of their children after bvh::Refit -- the
+//            visited leaves are exactly those whose own box passes, whichever ancestors a walk tests on the way.  Order
+//            is free (a boolean).  Rays that are not clean, in world or in an instance's object space, are handed to the
+//            binary walk (leftover list).  Half as many dependent fetches per ray, and each fetch is one L1 line.
 // All of it is read-only and a few MB at most: every XCD's 4 MiB L2 ends up holding its own copy.
 #pragma once
 #include "rt_dmath.h"
@@ -77,7 +89,8 @@ struct DInstance {
 	float invT[12];
 	float T[12];
 	uint rootLink;
-	uint pad[7];
+	uint rootWide; // the same BLAS entered through its 4-wide nodes (== rootLink when the root is a leaf)
+	uint pad[6];
 };
 struct DScene {
 	const float4* pairs;
@@ -85,6 +98,8 @@ struct DScene {
 	const DInstance* inst;
 	const float4* brute; // TLAS mode: spheres then planes, prim-record format
 	const float4* reach; // TLAS mode: per TLAS pair, the boxes its children's geometry can actually occupy (see below)
+	const float4* wide;  // 4-wide nodes of every BLAS (any-hit queries of clean rays), 128-byte records; null when a tree is not nested
+	uint rootWide;       // scene BVH root through the wide nodes (unused in TLAS mode: instances carry theirs)
 	const DLight* lights;
 	const DMaterial* mats;
 	const unsigned char* sky;
@@ -248,10 +263,14 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // [0] first wave in, [1] first wave that finds every sub-queue empty, [2] last wave out (s_memrealtime, 100 MHz)
 __device__ unsigned long long g_tailProbe[4];
 #endif
-template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false>
+// WIDE == true (occlusion queries only, never counting launches): inside a BLAS / the scene BVH the walk uses the
+// 4-wide nodes (wide[], see the layout notes above); a ray that is not clean is given back through
+// pol.leftover(work) for the binary walk.  The TLAS level keeps its pair records and reach test.
+template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false, bool WIDE = false>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
+	static_assert(!WIDE || (ANY && !COUNT && !MIXED), "the wide walk is exact for any-hit queries only");
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
 	const int refillMin = tuning & 0xFF, stepMin = (tuning >> 8) & 0xFF, pairAgain = (tuning >> 20) & 0x7F;
 	const uint lane = threadIdx.x & 63;
@@ -347,9 +366,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 							if (!ANY && HEAD) find_nearest_head<COUNT>(S, O, D, t_min, rayT, hit, lc);
 							rD = rcp3(D);
 							clean = ray_is_clean(O, D, rD);
-							link = S.rootLink;
+							link = WIDE && !S.useTLAS ? S.rootWide : S.rootLink;
 							if (link == RT_EMPTY) link = RT_LINK_DONE;
 							rays++;
+							if constexpr (WIDE) { if (!clean) { pol.leftover(mine); work = -1; } } // the binary walk answers this one
 						}
 						chunkNext += cnt < avail ? cnt : avail;
 					}
@@ -402,6 +422,32 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				// mode, of the TLAS (tlas.cpp:77-91 / :106-120) -- same test, same ordering rule
 				if (COUNT) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
 				const bool atTlas = S.useTLAS && inst < 0;
+				if (WIDE && !atTlas) {
+					// one 4-wide node: every child whose box the ray passes is visited, in any order (a boolean query)
+					const float4* w = S.wide + 8 * (size_t)lk;
+					const float4 mnx = w[0], mny = w[1], mnz = w[2], mxx = w[3], mxy = w[4], mxz = w[5], lkf = w[6];
+					const float bx0[4] = { mnx.x, mnx.y, mnx.z, mnx.w }, by0[4] = { mny.x, mny.y, mny.z, mny.w }, bz0[4] = { mnz.x, mnz.y, mnz.z, mnz.w };
+					const float bx1[4] = { mxx.x, mxx.y, mxx.z, mxx.w }, by1[4] = { mxy.x, mxy.y, mxy.z, mxy.w }, bz1[4] = { mxz.x, mxz.y, mxz.z, mxz.w };
+					const uint cl[4] = { __float_as_uint(lkf.x), __float_as_uint(lkf.y), __float_as_uint(lkf.z), __float_as_uint(lkf.w) };
+					// entry distances (1e30f: missed, or an unused entry -- its inverted box reads as a huge one in a min / max slab test)
+					float td[4];
+					uint tl[4];
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const float dj = intersect_aabb_clean(O, rD, rayT, f3(bx0[j], by0[j], bz0[j]), f3(bx1[j], by1[j], bz1[j]));
+						td[j] = cl[j] != RT_EMPTY ? dj : 1e30f, tl[j] = cl[j];
+					}
+					// nearest first (an occluder is usually found in the first leaf reached): 5-exchange sorting network
+					auto cswap = [&](int a, int b) { const bool sw = td[b] < td[a]; const float ta = td[a]; const uint la = tl[a]; td[a] = sw ? td[b] : ta, tl[a] = sw ? tl[b] : la, td[b] = sw ? ta : td[b], tl[b] = sw ? la : tl[b]; };
+					cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+					if (td[3] != 1e30f) st.push(tl[3]);
+					if (td[2] != 1e30f) st.push(tl[2]);
+					if (td[1] != 1e30f) st.push(tl[1]);
+					const bool have = td[0] != 1e30f;
+					const uint next = tl[0];
+					if (have) link = next; else pop_next();
+					continue;
+				}
 				const float4* p = S.pairs + 4 * (size_t)lk;
 				const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
 #ifdef RT_EXPERIMENT_EXTRA_LOADS
@@ -442,6 +488,13 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		const bool runLeaf = nL > 0 && (nL >= stepMin || nL == most);
 		const bool runEnter = nN > 0 && (nN >= stepMin || nN == most);
 		const bool runExit = nE > 0 && (nE >= stepMin || nE == most);
+		if (most == 0 && __ballot(live) != 0) {
+			// live lanes whose link no step kind understands (a corrupt tree): nothing would ever change again.  Every
+			// wave must reach its exit, so the rays are dropped and the launch reports RT_E_STATE.
+			*overflow = 199;
+			if (live) link = RT_LINK_DONE;
+			continue;
+		}
 
 		if (runLeaf && wantLeaf) {
 			// one primitive of a leaf (bvh.cpp:616-629 / :770-783); all four vectors of the record in
@@ -478,9 +531,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			const f3 Do = xform_vec(I->invT, D);
 			O = Oo, D = Do, rD = rcp3(Do);
 			clean = ray_is_clean(O, D, rD);
-			link = I->rootLink;
+			link = WIDE ? I->rootWide : I->rootLink;
 			if (link == RT_EMPTY) link = RT_LINK_EXIT;
 			else st.push(RT_SENTINEL);
+			if constexpr (WIDE) { if (!clean) { pol.leftover(work); work = -1; link = RT_LINK_DONE; } } // not clean in object space: the binary walk redoes this ray
 		}
 		if (runExit && wantExit) {
 			// back to world space (the backup ray of bvhInstance.cpp:6, :20), then the next TLAS entry

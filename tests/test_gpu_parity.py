@@ -70,11 +70,64 @@ def test_find_nearest_and_occlusion(name, kw, scenes, oracle_api, host_api):
     assert np.array_equal(got, ref["occluded"])
     for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits", "rays_occluded"):
         assert cnt[k] == ref["counters"][k], k
+    # the timed kernels (counting off): the 4-wide walk for clean rays, the binary walk for the rest (the axis-aligned
+    # directions among these rays are not clean) -- same flags
+    r.set_counting(False)
+    assert np.array_equal(r.is_occluded(O, D, tmax), ref["occluded"])
+    assert np.array_equal(r.is_occluded(O, D), o.is_occluded(O, D)["occluded"])
     # tmax on the nearest-hit query too
     ref = o.find_nearest(O, D, tmax=tmax, t_min=1e-6)
     got = r.find_nearest(O, D, tmax=tmax, t_min=1e-6)
     assert np.array_equal(got["obj"], ref["obj"])
     assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    r.close()
+
+
+@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("scene3", {"force_diffuse": False}), ("tlas_test2", {"mesh": "BigB"}), ("pretty_tlas", {"n_instances": 8})])
+def test_wide_walk_equals_binary_walk(name, kw, scenes, oracle_api, host_api, monkeypatch):
+    """the 4-wide nodes (csrc/rt_scene_dev.h wide[], built at upload by collapsing the reference's
+    binary tree; the reference's own 4-wide variant is bvh.cpp:335-512, :658-761).  Scene::IsOccluded through them
+    (RT_WIDE=1; off by default because it measured slower) must give the oracle's flags for every ray -- clean rays
+    take the wide walk, the others (axis-aligned directions here) are handed back to the binary walk -- and a path
+    frame whose shadow rays took it must equal the default frame bit for bit."""
+    frames = {}
+    for wide in ("0", "1"):
+        monkeypatch.setenv("RT_WIDE", wide)
+        o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 96, 54, **kw)
+        if wide == "1":
+            O, D = random_rays(40000, 9, center=(0.0, 1.0, 3.0), spread=6.0)
+            pO, pD = orr.primary_rays()
+            O, D = np.concatenate([O, pO]), np.concatenate([D, pD])
+            rng = np.random.default_rng(5)
+            for tmax in (None, rng.uniform(0.1, 12.0, len(O)).astype(np.float32), np.full(len(O), 2.5, np.float32)):
+                ref = o.is_occluded(O, D, tmax)["occluded"]
+                assert 0.003 < ref.mean() < 0.98
+                r.set_counting(False)
+                assert np.array_equal(r.is_occluded(O, D, tmax), ref)            # wide walk + leftover list
+                r.set_counting(True)
+                assert np.array_equal(r.is_occluded(O, D, tmax), ref)            # the reference's walk
+                r.set_counting(False)
+        r.clear()
+        r.render(host_api.RT_MODE_PATH, 0, 5)
+        frames[wide] = r.accumulator().copy()
+        r.clear()
+        r.render(host_api.RT_MODE_WHITTED, 0, 1)
+        frames[wide + "w"] = r.accumulator().copy()
+        r.close()
+    assert np.array_equal(frames["0"].view(np.uint32), frames["1"].view(np.uint32))
+    assert np.array_equal(frames["0w"].view(np.uint32), frames["1w"].view(np.uint32))
+
+
+def test_wide_walk_after_refit(scenes, oracle_api, host_api, monkeypatch):
+    """rt_set_time deforms and refits the scene BVH; the wide nodes' boxes must follow (k_wide_sync)."""
+    monkeypatch.setenv("RT_WIDE", "1")
+    o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 48, 32)
+    O, D = random_rays(20000, 3)
+    for t in (0.7, 3.1, 0.0):
+        o.set_time(t)
+        r.scene.set_time(t)
+        for tmax in (None, np.full(len(O), 5.0, np.float32)):
+            assert np.array_equal(r.is_occluded(O, D, tmax), o.is_occluded(O, D, tmax)["occluded"])
     r.close()
 
 
@@ -692,11 +745,13 @@ def _fuzz_rays(o, n_inst, rng, n, center, extent):
 
 @pytest.mark.parametrize("name,kw,total", [("pretty_tlas", {"n_instances": 8}, 100_000_000), ("bigb_instanced", {"n": 16, "mesh": "BigB"}, 12_000_000),
                                            ("tlas_test2", {"mesh": "BigB"}, 12_000_000)])
-def test_reach_cull_fuzz_gpu_vs_gpu(name, kw, total, scenes, oracle_api, host_api):
+def test_reach_cull_fuzz_gpu_vs_gpu(name, kw, total, scenes, oracle_api, host_api, monkeypatch):
     """1e8 rays on the bench scene (1.2e7 on two more): the timed traversal (TLAS children whose reach box the ray
     misses are dropped, DESIGN.md section 4 finding 8) against the same kernels walking like the reference
     (RT_COUNT_REFERENCE: no culling) -- GPU against GPU, because this one equivalence needs volume, not an oracle.
     Hit ids, t, materials and normals of Scene::FindNearest and the flags of Scene::IsOccluded must be bit-identical."""
+    if name != "pretty_tlas":
+        monkeypatch.setenv("RT_WIDE", "1")  # the two smaller runs also put the 4-wide occlusion walk against the binary one
     o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 16, 8, **kw)
     rng = np.random.default_rng(20260)
     n_inst = o.n_instances
