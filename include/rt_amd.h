@@ -201,6 +201,15 @@ int rt_trace_batch(rt_ctx* ctx, int mode, int n, const float* O, const float* D,
  * no triangle or sphere, or with a non-finite vertex / centre / radius. */
 int rt_build_bvh(rt_ctx* ctx, const rt_triangle* tris, uint32_t n_tri, const rt_sphere* spheres, uint32_t n_sph, const rt_plane* planes, uint32_t n_pla,
                  rt_bvh_node* nodes_out, uint32_t* prim_idx_out, uint32_t* nodes_used_out);
+/* The same with bvh.h:38-43's splitMethod: 0 BINNEDSAH (what rt_build_bvh builds), 1 SAMESIZE (median of the longest
+ * axis, bvh.cpp:233-252), 2 LONGESTAXIS (spatial middle, :226-232), 3 SAH (every centroid tried as the plane, :275-293
+ * with EvaluateSAH :514-554 -- quadratic in the node size like the reference). */
+int rt_build_bvh_split(rt_ctx* ctx, int split_method, const rt_triangle* tris, uint32_t n_tri, const rt_sphere* spheres, uint32_t n_sph,
+                       const rt_plane* planes, uint32_t n_pla, rt_bvh_node* nodes_out, uint32_t* prim_idx_out, uint32_t* nodes_used_out);
+/* tlas::build (tlas.cpp:13-48: agglomerative clustering by smallest union surface area, FindBestMatch :50-63) on the
+ * device.  bounds6: per instance the world box its bvhInstance holds (min.xyz, max.xyz, template bvhInstance.cpp:37-44);
+ * 1 <= n <= 256; nodes_out has room for 2 n + 1 nodes.  Same node order and boxes as the host builder. */
+int rt_build_tlas(rt_ctx* ctx, const float* bounds6, uint32_t n, rt_tlas_node* nodes_out, uint32_t* nodes_used_out);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernels tally rt_counters (slower; keep off when timing).

@@ -716,6 +716,13 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 int rt_build_bvh(rt_ctx* c, const rt_triangle* tris, uint32_t n_tri, const rt_sphere* spheres, uint32_t n_sph, const rt_plane* planes, uint32_t n_pla,
                  rt_bvh_node* nodes_out, uint32_t* prim_idx_out, uint32_t* nodes_used_out)
 {
+	return rt_build_bvh_split(c, RT_SPLIT_BINNEDSAH, tris, n_tri, spheres, n_sph, planes, n_pla, nodes_out, prim_idx_out, nodes_used_out);
+}
+
+int rt_build_bvh_split(rt_ctx* c, int split_method, const rt_triangle* tris, uint32_t n_tri, const rt_sphere* spheres, uint32_t n_sph, const rt_plane* planes, uint32_t n_pla,
+                       rt_bvh_node* nodes_out, uint32_t* prim_idx_out, uint32_t* nodes_used_out)
+{
+	if (split_method < 0 || split_method > 3) return fail(c, RT_E_ARG, "rt_build_bvh: split method %d (bvh.h:38-43 knows 0..3)", split_method);
 	if (!c || !nodes_out || !prim_idx_out || !nodes_used_out) return fail(c, RT_E_ARG, "rt_build_bvh: null argument");
 	if ((n_tri && !tris) || (n_sph && !spheres) || (n_pla && !planes)) return fail(c, RT_E_ARG, "rt_build_bvh: null primitive array");
 	const uint M = n_tri + n_sph, N = M + n_pla;
@@ -760,7 +767,7 @@ int rt_build_bvh(rt_ctx* c, const rt_triangle* tris, uint32_t n_tri, const rt_sp
 	for (bool done = false; !done;) {
 		for (int g = 0; g < 16 && (uint)level <= M + 2; g++, level++) { // a tree over M primitives has at most M levels
 			const unsigned cap = level < 31 && (1u << level) < M ? (1u << level) : M;
-			hipLaunchKernelGGL(k_build_level, dim3(cap), dim3(RT_BUILD_THREADS), 0, c->stream, B, open, next, level);
+			hipLaunchKernelGGL(k_build_level, dim3(cap), dim3(RT_BUILD_THREADS), 0, c->stream, B, open, next, level, split_method);
 			hipLaunchKernelGGL(k_build_advance, dim3(1), dim3(1), 0, c->stream, B, level);
 			std::swap(open, next);
 		}
@@ -825,6 +832,37 @@ int rt_build_bvh(rt_ctx* c, const rt_triangle* tris, uint32_t n_tri, const rt_sp
 		r.left_first = 2, r.prim_count = 0;
 	}
 	*nodes_used_out = nodesUsed;
+	return RT_OK;
+}
+
+// tlas::build on the device (rt_build.h k_build_tlas): bounds6 = per instance the world box bvhInstance::SetTransform
+// left in 'bounds' (min.xyz, max.xyz); nodes_out has room for 2 n + 1 nodes.
+int rt_build_tlas(rt_ctx* c, const float* bounds6, uint32_t n, rt_tlas_node* nodes_out, uint32_t* nodes_used_out)
+{
+	if (!c || !bounds6 || !nodes_out || !nodes_used_out) return fail(c, RT_E_ARG, "rt_build_tlas: null argument");
+	if (n < 1 || n > RT_TLAS_MAX) return fail(c, RT_E_UNSUPPORTED, "rt_build_tlas: %u instances (the reference's nodeIdx[256] holds 1..256, tlas.cpp:16)", n);
+	for (uint32_t i = 0; i < 6 * n; i++)
+		if (!(std::fabs(bounds6[i]) <= 1e30f)) return fail(c, RT_E_UNSUPPORTED, "rt_build_tlas: instance %u has a non-finite bound", i / 6);
+	HIPCHK(c, hipSetDevice(c->device));
+	std::vector<void*> tmp;
+	struct Guard { std::vector<void*>& v; ~Guard() { free_pool(v); } } guard{ tmp };
+	float* dB = nullptr;
+	TlasNodeDev* dN = nullptr;
+	int* dU = nullptr;
+	static_assert(sizeof(TlasNodeDev) == sizeof(rt_tlas_node), "TLAS node layout");
+	HIPCHK(c, dalloc(tmp, &dB, (size_t)6 * n));
+	HIPCHK(c, dalloc(tmp, &dN, (size_t)2 * n + 1));
+	HIPCHK(c, dalloc(tmp, &dU, 1));
+	HIPCHK(c, hipMemsetAsync(dN, 0, ((size_t)2 * n + 1) * sizeof(TlasNodeDev), c->stream));
+	HIPCHK(c, hipMemcpyAsync(dB, bounds6, (size_t)24 * n, hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(k_build_tlas, dim3(1), dim3(64), 0, c->stream, dB, (int)n, dN, dU);
+	int used = 0;
+	HIPCHK(c, hipMemcpyAsync(&used, dU, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(nodes_out, dN, ((size_t)2 * n + 1) * sizeof(rt_tlas_node), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipGetLastError());
+	if (used < 0) return fail(c, RT_E_UNSUPPORTED, "rt_build_tlas: no finite union area left (degenerate instance bounds)");
+	*nodes_used_out = (uint32_t)used;
 	return RT_OK;
 }
 

@@ -1,4 +1,6 @@
-// bvh::Build with splitMethod BINNEDSAH (bvh.cpp:18-56, 67-114, 116-200, 223-333) on the device: the step
+// bvh::Build (bvh.cpp:18-56, 67-114, 116-200, 223-333, 514-554) on the device, all four split methods of bvh.h:38-43
+// (BINNEDSAH: 8-bin SAH, the default; SAMESIZE: median of the longest axis; LONGESTAXIS: spatial middle of the
+// longest axis; SAH: every centroid of every axis tried as the plane, EvaluateSAH, O(n^2) like the reference): the step
 // immediately before the trace loop.  The tree must come out IDENTICAL to the
 // reference's -- node numbering, boxes, primitiveIdx order -- because the stored boxes and the leaf order
 // decide which primitive a ray reports, so this is a restatement of the same arithmetic, reorganised:
@@ -119,8 +121,9 @@ __global__ void k_build_prep(const float* tris, int triStride, int nTri, const f
 		}
 	}
 	if (!ok) B.counters[2] = 1;
-	B.cen[i] = make_float4(c[0], c[1], c[2], 0);
-	B.nlo[i] = make_float4(lo[0], lo[1], lo[2], 0), B.nhi[i] = make_float4(hi[0], hi[1], hi[2], 0);
+	// w: the sphere's radius / the sphere flag (EvaluateSAH grows a side by pos[axis] -+ r broadcast to all three axes, bvh.cpp:533-544)
+	B.cen[i] = make_float4(c[0], c[1], c[2], i < nTri ? 0.0f : sph[(size_t)(i - nTri) * sphStride + 5]);
+	B.nlo[i] = make_float4(lo[0], lo[1], lo[2], i < nTri ? 0.0f : 1.0f), B.nhi[i] = make_float4(hi[0], hi[1], hi[2], 0);
 	B.blo[i] = make_float4(l2[0], l2[1], l2[2], 0), B.bhi[i] = make_float4(h2[0], h2[1], h2[2], 0);
 	B.idx[i] = (uint)i;
 }
@@ -165,7 +168,29 @@ struct SweepBox { // aabb of template/precomp.h as FindBestSplitPlane uses it
 };
 
 // Subdivide (bvh.cpp:223-333) for every open node of one level: one block per node
-__global__ void __launch_bounds__(RT_BUILD_THREADS) k_build_level(BuildArrays B, const int* open, int* next, int level)
+#define RT_SPLIT_BINNEDSAH 0
+#define RT_SPLIT_SAMESIZE 1
+#define RT_SPLIT_LONGESTAXIS 2
+#define RT_SPLIT_SAH 3
+// block-wide "first minimum": the smallest key wins, equal keys by the smaller index (the reference's loops keep the
+// first candidate under a strict '<'); a NaN key never wins
+__device__ __forceinline__ void block_argmin(float& key, int& idx, float* shk, int* shi2)
+{
+	if (!(key == key)) key = __builtin_inff(), idx = 0x7fffffff;
+	for (int o = 32; o > 0; o >>= 1) {
+		const float k2 = __shfl_xor(key, o);
+		const int i2 = __shfl_xor(idx, o);
+		if (k2 < key || (k2 == key && i2 < idx)) key = k2, idx = i2;
+	}
+	if ((threadIdx.x & 63) == 0) shk[threadIdx.x >> 6] = key, shi2[threadIdx.x >> 6] = idx;
+	__syncthreads();
+	key = shk[0], idx = shi2[0];
+	for (int w = 1; w < RT_BUILD_WAVES; w++) if (shk[w] < key || (shk[w] == key && shi2[w] < idx)) key = shk[w], idx = shi2[w];
+	__syncthreads();
+}
+__device__ __forceinline__ float comp3(const float4& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+__global__ void __launch_bounds__(RT_BUILD_THREADS) k_build_level(BuildArrays B, const int* open, int* next, int level, int method)
 {
 	__shared__ float binLo[RT_BUILD_BINS * 3][RT_BUILD_THREADS], binHi[RT_BUILD_BINS * 3][RT_BUILD_THREADS]; // [bin * 3 + axis of the box][thread]: private columns
 	__shared__ int binCnt[RT_BUILD_BINS][RT_BUILD_THREADS];
@@ -182,9 +207,66 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) k_build_level(BuildArrays B,
 	const TNode node = B.nodes[id];
 	const uint first = node.first, count = node.count;
 
+	if (method != RT_SPLIT_BINNEDSAH) {
+		// ---- the other three split methods (bvh.cpp:226-293) ----
+		const float ext[3] = { node.hi[0] - node.lo[0], node.hi[1] - node.lo[1], node.hi[2] - node.lo[2] };
+		int la = 0; // the longest axis as the reference picks it (:228-231, :236-239)
+		if (ext[1] > ext[0]) la = 1;
+		if (ext[2] > ext[la]) la = 2;
+		if (method == RT_SPLIT_LONGESTAXIS) {
+			if (tid == 0) axisS = la, bestS[1] = node.lo[la] + ext[la] * 0.5f, bestS[0] = -1.0f;
+		} else if (method == RT_SPLIT_SAMESIZE) {
+			// std::sort of (key, primIdx) tuples, splitPos = key of element count / 2 (:240-252): the key k with
+			// #{keys < k} <= m < #{keys <= k}
+			const int m = (int)(count / 2);
+			if (tid == 0) axisS = la, bestS[0] = -1.0f, bestS[1] = 0;
+			__syncthreads();
+			for (uint i = tid; i < count; i += RT_BUILD_THREADS) {
+				const float k = comp3(B.cen[B.idx[first + i]], la);
+				int less = 0, leq = 0;
+				for (uint j = 0; j < count; j++) { const float kj = comp3(B.cen[B.idx[first + j]], la); less += kj < k ? 1 : 0, leq += kj <= k ? 1 : 0; }
+				if (less <= m && m < leq) bestS[1] = k; // every thread that gets here writes the same value
+			}
+		} else {
+			// SAH (:275-293) with EvaluateSAH (:514-554): candidate q = axis * count + i, first minimum wins
+			float bestC = 1e30f;
+			int bestQ = 0x7fffffff;
+			for (uint q = tid; q < 3 * count; q += RT_BUILD_THREADS) {
+				const int a = (int)(q / count);
+				const float pos = comp3(B.cen[B.idx[first + q % count]], a);
+				SweepBox lb, rb;
+				lb.reset(), rb.reset();
+				int lc = 0, rc = 0;
+				for (uint j = 0; j < count; j++) {
+					const uint p = B.idx[first + j];
+					const float4 c4 = B.cen[p], lo4 = B.nlo[p], hi4 = B.nhi[p];
+					const bool left = comp3(c4, a) < pos;
+					float glo[3] = { lo4.x, lo4.y, lo4.z }, ghi[3] = { hi4.x, hi4.y, hi4.z };
+					if (lo4.w != 0.0f) { // sphere: the scalar pos[axis] -+ r on all three axes
+						const float s0 = comp3(c4, a) - c4.w, s1 = comp3(c4, a) + c4.w;
+						glo[0] = glo[1] = glo[2] = s0, ghi[0] = ghi[1] = ghi[2] = s1;
+					}
+					SweepBox& bx = left ? lb : rb;
+					for (int k = 0; k < 3; k++) { bx.lo[k] = t_fminf(bx.lo[k], glo[k]); bx.hi[k] = t_fmaxf(bx.hi[k], glo[k]); }
+					for (int k = 0; k < 3; k++) { bx.lo[k] = t_fminf(bx.lo[k], ghi[k]); bx.hi[k] = t_fmaxf(bx.hi[k], ghi[k]); }
+					lc += left ? 1 : 0, rc += left ? 0 : 1;
+				}
+				float cost = lc * lb.area() + rc * rb.area();
+				cost = cost > 0 ? cost : 1e30f;
+				if (cost < bestC) bestC = cost, bestQ = (int)q; // q ascends within a thread: its first minimum
+			}
+			block_argmin(bestC, bestQ, shf, shi);
+			if (tid == 0) {
+				const bool found = bestC < 1e30f && bestQ != 0x7fffffff; // the reference would index centroid[-1] otherwise: "no split"
+				bestS[0] = found ? -1.0f : 1e30f;
+				if (found) axisS = bestQ / (int)count, bestS[1] = comp3(B.cen[B.idx[first + (uint)bestQ % count]], bestQ / (int)count);
+			}
+		}
+		__syncthreads();
+	}
 	// ---- FindBestSplitPlane (bvh.cpp:116-193) ----
-	if (tid == 0) bestS[0] = 1e30f, bestS[1] = 0, axisS = 0;
-	for (int a = 0; a < 3; a++) {
+	if (method == RT_SPLIT_BINNEDSAH && tid == 0) bestS[0] = 1e30f, bestS[1] = 0, axisS = 0;
+	for (int a = 0; a < 3 && method == RT_SPLIT_BINNEDSAH; a++) {
 		float mn = 1e30f, mx = -1e30f;
 		for (uint i = tid; i < count; i += RT_BUILD_THREADS) {
 			const float4 c4 = B.cen[B.idx[first + i]];
@@ -259,7 +341,7 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) k_build_level(BuildArrays B,
 	// CalculateNodeCost (bvh.cpp:196-200)
 	const float ex = node.hi[0] - node.lo[0], ey = node.hi[1] - node.lo[1], ez = node.hi[2] - node.lo[2];
 	const float nosplitCost = count * (ex * ey + ey * ez + ez * ex);
-	if (bestCost >= nosplitCost) return; // stays a leaf, primitiveIdx untouched
+	if (method == RT_SPLIT_BINNEDSAH ? bestCost >= nosplitCost : bestCost > 0.0f) return; // stays a leaf, primitiveIdx untouched (the other methods split unconditionally, or found no plane)
 
 	// ---- the partition loop (bvh.cpp:296-313) in closed form ----
 	auto isLeft = [&](uint p) { const float4 c4 = B.cen[p]; return (axis == 0 ? c4.x : (axis == 1 ? c4.y : c4.z)) < splitPos; };
@@ -333,6 +415,78 @@ __global__ void __launch_bounds__(RT_BUILD_THREADS) k_build_level(BuildArrays B,
 		B.nodes[id].left = c, B.nodes[id].right = c + 1;
 		const int o = atomicAdd(&B.counters[4 + ((level + 1) & 1)], 2);
 		next[o] = c, next[o + 1] = c + 1;
+	}
+}
+
+// ---- tlas::build (tlas.cpp:13-48) with tlas::FindBestMatch (:50-63): agglomerative clustering ------------------------
+// At most 256 instances (the reference's nodeIdx[256]), and every step depends on the one before: ONE wave runs the
+// reference's loop as it stands -- the scalar bookkeeping (A, B, C, nodeIdx[], nodesUsed) uniformly in every lane,
+// FindBestMatch as a wave-wide "first minimum" over the up to 256 candidates (four per lane) -- so the nodes come
+// out in the reference's order with the reference's boxes.
+#define RT_TLAS_MAX 256
+struct TlasNodeDev { float lo[3]; uint leftRight; float hi[3]; uint blas; };
+__device__ __forceinline__ int tlas_best_match(const TlasNodeDev* node, const int* list, int n, int A)
+{
+	const uint lane = threadIdx.x & 63;
+	const TlasNodeDev a = node[list[A]];
+	float best = 1e30f;
+	int bestB = 0x7fffffff; // "no candidate": smallest < 1e30f never held (the reference returns -1)
+	for (int Bc = (int)lane; Bc < n; Bc += 64) {
+		if (Bc == A) continue;
+		const TlasNodeDev b = node[list[Bc]];
+		const float ex = t_fmaxf(a.hi[0], b.hi[0]) - t_fminf(a.lo[0], b.lo[0]);
+		const float ey = t_fmaxf(a.hi[1], b.hi[1]) - t_fminf(a.lo[1], b.lo[1]);
+		const float ez = t_fmaxf(a.hi[2], b.hi[2]) - t_fminf(a.lo[2], b.lo[2]);
+		const float area = ex * ey + ey * ez + ez * ex;
+		if (area < best) best = area, bestB = Bc; // ascending within a lane: its first minimum
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		const float k2 = __shfl_xor(best, o);
+		const int i2 = __shfl_xor(bestB, o);
+		if (k2 < best || (k2 == best && i2 < bestB)) best = k2, bestB = i2;
+	}
+	return bestB == 0x7fffffff ? -1 : bestB;
+}
+__global__ void __launch_bounds__(64) k_build_tlas(const float* bounds6, int n, TlasNodeDev* node, int* nodesUsedOut)
+{
+	__shared__ int nodeIdx[RT_TLAS_MAX];
+	const uint lane = threadIdx.x;
+	int nodesUsed = 1;
+	for (int i = (int)lane; i < n; i += 64) {
+		TlasNodeDev leaf;
+		for (int k = 0; k < 3; k++) leaf.lo[k] = bounds6[6 * i + k], leaf.hi[k] = bounds6[6 * i + 3 + k];
+		leaf.blas = (uint)i, leaf.leftRight = 0;
+		node[1 + i] = leaf;
+		nodeIdx[i] = 1 + i;
+	}
+	nodesUsed += n;
+	__threadfence_block();
+	__builtin_amdgcn_wave_barrier();
+	int live = n, A = 0, Bi = tlas_best_match(node, nodeIdx, live, A);
+	int guard = 0;
+	while (live > 1 && Bi >= 0 && guard++ < 4 * RT_TLAS_MAX * RT_TLAS_MAX) {
+		const int C = tlas_best_match(node, nodeIdx, live, Bi);
+		if (C < 0) break;
+		if (A != C) { A = Bi, Bi = C; continue; }
+		const int ia = nodeIdx[A], ib = nodeIdx[Bi];
+		if (lane == 0) {
+			const TlasNodeDev na = node[ia], nb = node[ib];
+			TlasNodeDev p;
+			p.leftRight = (uint)ia + ((uint)ib << 16);
+			p.blas = 0;
+			for (int k = 0; k < 3; k++) p.lo[k] = t_fminf(na.lo[k], nb.lo[k]), p.hi[k] = t_fmaxf(na.hi[k], nb.hi[k]);
+			node[nodesUsed] = p;
+			nodeIdx[A] = nodesUsed;
+			nodeIdx[Bi] = nodeIdx[live - 1];
+		}
+		nodesUsed++, live--;
+		__threadfence_block();
+		__builtin_amdgcn_wave_barrier();
+		Bi = tlas_best_match(node, nodeIdx, live, A);
+	}
+	if (lane == 0) {
+		node[0] = node[nodeIdx[A]];
+		*nodesUsedOut = live == 1 ? nodesUsed : -1; // -1: no finite union area left to pick (the reference would index nodeIdx[-1])
 	}
 }
 

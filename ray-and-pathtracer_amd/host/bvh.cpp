@@ -332,7 +332,6 @@ void bvh::Build(bool isQ)
 
 void bvh::BuildOnDevice(rt_ctx* ctx)
 {
-	if (splitMethod != BINNEDSAH) throw std::runtime_error("bvh::BuildOnDevice: the device builder is the binned SAH only");
 	Builder bl(*this);
 	NTri = bl.nTri, NSph = bl.nSph, NPla = bl.nPla, N = bl.nAll;
 	std::vector<rt_triangle> T(NTri);
@@ -351,7 +350,7 @@ void bvh::BuildOnDevice(rt_ctx* ctx)
 	bvhNode = new BVHNode[2 * (N + 1)]();
 	static_assert(sizeof(BVHNode) == sizeof(rt_bvh_node), "BVHNode must match rt_bvh_node");
 	uint32_t used = 0;
-	if (rt_build_bvh(ctx, T.data(), NTri, S.data(), NSph, P.data(), NPla, (rt_bvh_node*)bvhNode, primitiveIdx, &used) != RT_OK)
+	if (rt_build_bvh_split(ctx, splitMethod, T.data(), NTri, S.data(), NSph, P.data(), NPla, (rt_bvh_node*)bvhNode, primitiveIdx, &used) != RT_OK)
 		throw std::runtime_error(std::string("bvh::BuildOnDevice: ") + rt_last_error(ctx));
 	nodesUsed = used;
 	// DataCollector::maxTreeDepth analogue: deepest leaf, counted in nodes from the root
@@ -420,6 +419,21 @@ int tlas::FindBestMatch(int* list, int Ncount, int A) // tlas.cpp:50-63
 		if (surfaceArea < smallest) smallest = surfaceArea, bestB = B;
 	}
 	return bestB;
+}
+
+void tlas::BuildOnDevice(rt_ctx* ctx) // the same nodes from rt_build_tlas
+{
+	if (blasCount == 0 || blasCount > 256) throw std::runtime_error("tlas::build supports 1..256 instances (nodeIdx[256] in the reference)");
+	std::vector<float> b6((size_t)6 * blasCount);
+	for (uint i = 0; i < blasCount; i++) {
+		const aabb& bb = blas[i].bounds;
+		b6[6 * i] = bb.bmin.x, b6[6 * i + 1] = bb.bmin.y, b6[6 * i + 2] = bb.bmin.z, b6[6 * i + 3] = bb.bmax.x, b6[6 * i + 4] = bb.bmax.y, b6[6 * i + 5] = bb.bmax.z;
+	}
+	static_assert(sizeof(TLASNode) == sizeof(rt_tlas_node), "TLASNode must match rt_tlas_node");
+	uint32_t used = 0;
+	if (rt_build_tlas(ctx, b6.data(), blasCount, (rt_tlas_node*)tlasNode, &used) != RT_OK)
+		throw std::runtime_error(std::string("tlas::BuildOnDevice: ") + rt_last_error(ctx));
+	nodesUsed = used;
 }
 
 void tlas::build() // tlas.cpp:13-48: agglomerative clustering by smallest union area

@@ -235,6 +235,7 @@ public:
 	tlas(bvhInstance* bvhList, int N);
 	~tlas();
 	void build();
+	void BuildOnDevice(rt_ctx* ctx); // tlas::build through rt_build_tlas
 	int FindBestMatch(int* list, int N, int A);
 	TLASNode* tlasNode = nullptr;
 	uint nodesUsed = 0;
@@ -272,7 +273,8 @@ public:
 	~Scene();
 	// the default construction path of the reference (template/scene.h:688-716): after filling the
 	// containers call BuildBVH() (new bvh(this); Build) or BuildTLAS() (tlas(bvhList, bvhCount); build)
-	// deviceBuild != nullptr: BuildBVH / BuildTLAS make their BINNEDSAH trees with bvh::BuildOnDevice(deviceBuild)
+	// deviceBuild != nullptr: BuildBVH / BuildTLAS make their trees (any split method) and the TLAS on that context's GPU
+	// (bvh::BuildOnDevice -> rt_build_bvh_split, tlas::BuildOnDevice -> rt_build_tlas)
 	rt_ctx* deviceBuild = nullptr;
 	void BuildBVH(int splitMethod = BINNEDSAH);
 	// instances reference meshes by index; one bvh per distinct mesh (TLASSceneTest2 shares one)

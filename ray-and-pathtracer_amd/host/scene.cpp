@@ -231,7 +231,7 @@ void Scene::BuildBVH(int splitMethod)
 	useTLAS = false;
 	b = new bvh(this);
 	b->splitMethod = splitMethod;
-	if (deviceBuild && splitMethod == BINNEDSAH) b->BuildOnDevice(deviceBuild);
+	if (deviceBuild) b->BuildOnDevice(deviceBuild);
 	else b->Build(false);
 }
 
@@ -252,7 +252,7 @@ void Scene::BuildTLAS(const std::vector<int>& meshOfInstance, const std::vector<
 		if (!bl) {
 			bl = new bvh(&meshes[mi]);
 			bl->splitMethod = splitMethod;
-			if (deviceBuild && splitMethod == BINNEDSAH) bl->BuildOnDevice(deviceBuild);
+			if (deviceBuild) bl->BuildOnDevice(deviceBuild);
 			else bl->Build();
 			blasOwned.push_back(bl);
 		}
@@ -262,7 +262,8 @@ void Scene::BuildTLAS(const std::vector<int>& meshOfInstance, const std::vector<
 	}
 	delete tl;
 	tl = new tlas(bvhList, (int)bvhCount);
-	tl->build();
+	if (deviceBuild) tl->BuildOnDevice(deviceBuild);
+	else tl->build();
 }
 
 int Scene::materialIndex(const material* m) const

@@ -24,7 +24,7 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_render", "rt_render_rows", "rt_clear", "rt_download_accumulator", "rt_resolve", "rt_accumulator_device_ptr",
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
-              "rt_build_bvh", "rt_gather_rows", "rt_device_of"]
+              "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_device_of"]
 
 
 class RtCamera(C.Structure):
@@ -91,6 +91,8 @@ def rt_lib():
         L.rt_trace_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
         L.rt_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_build_bvh_split.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_build_tlas.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.rt_get_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -390,8 +392,16 @@ class HostRenderer:
         self._rt(self.rt.rt_occluded_batch(self.ctx, len(O), _p(O), _p(D), tm, _p(out)))
         return out
 
-    def build_bvh(self, tri_v9=None, spheres=None, planes=None):
-        """rt_build_bvh: the reference's binned-SAH bvh::Build on the device.  tri_v9: (n, 9) vertices,
+    def build_tlas(self, bounds6):
+        """rt_build_tlas: tlas::build on the device; bounds6 (n, 6) instance world boxes.  Returns the nodes as (k, 8) uint32."""
+        b = np.ascontiguousarray(bounds6, dtype=np.float32).reshape(-1, 6)
+        nodes = np.zeros((2 * len(b) + 1, 8), dtype=np.uint32)
+        used = C.c_uint32(0)
+        self._rt(self.rt.rt_build_tlas(self.ctx, _p(b), len(b), _p(nodes), C.byref(used)))
+        return nodes[:used.value].copy()
+
+    def build_bvh(self, tri_v9=None, spheres=None, planes=None, split=0):
+        """rt_build_bvh_split: the reference's bvh::Build on the device (split: bvh.h:38-43, 0 = binned SAH).  tri_v9: (n, 9) vertices,
         spheres: (n, 4) pos + r, planes: (n, 4) N + d.  Returns (nodes[:nodes_used] as an (n, 8) uint32 view
         like the oracle's dump, prim_idx)."""
         tv = np.zeros((0, 9), np.float32) if tri_v9 is None else np.ascontiguousarray(tri_v9, dtype=np.float32).reshape(-1, 9)
@@ -407,7 +417,7 @@ class HostRenderer:
         nodes = np.zeros(2 * (n + 1), dtype=RT_BVH_NODE_DTYPE)
         prim = np.zeros(max(n, 1), dtype=np.uint32)
         used = C.c_uint32(0)
-        self._rt(self.rt.rt_build_bvh(self.ctx, _p(T) if len(T) else None, len(T), _p(S) if len(S) else None, len(S),
+        self._rt(self.rt.rt_build_bvh_split(self.ctx, int(split), _p(T) if len(T) else None, len(T), _p(S) if len(S) else None, len(S),
                                       _p(P) if len(P) else None, len(P), _p(nodes), _p(prim), C.byref(used)))
         return nodes[:used.value].view(np.uint32).reshape(-1, 8).copy(), prim[:n].copy()
 

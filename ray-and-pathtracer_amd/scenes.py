@@ -33,7 +33,7 @@ def _f32(x):
     return float(np.float32(x))
 
 
-def background_scene(b, rt=True, sky=True):
+def background_scene(b, rt=True, sky=True, split=BINNEDSAH):
     """instantiateBackgroundScene (template/scene.h:791-813): the reference's default scene.
     hdr.hdr is missing from the snapshot, so a synthetic sky stands in."""
     if sky:
@@ -50,7 +50,7 @@ def background_scene(b, rt=True, sky=True):
     b.mesh_obj(4, assets.obj_path("ico"), blue_glass, (1.5, 0.5, 0.0), 0.5)
     b.sphere(3, green_glass, (0.0, 0.5, 0), 0.5)
     b.plane(0, floor, (0, 1, 0), 0)
-    b.build(BINNEDSAH)
+    b.build(split)
     return dict(name="background", tlas=False)
 
 

@@ -913,7 +913,10 @@ def _same_tree(got, ref):
     assert np.array_equal(nodes[keep], ref["nodes"][:ref["nodes_used"]][keep])
 
 
-@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("scene3", {"force_diffuse": False, "split": 0}), ("background", {}), ("tower", {})])
+@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("scene3", {"force_diffuse": False, "split": 0}), ("background", {}), ("tower", {}),
+                                     ("mixed_small", {"split": 1}), ("mixed_small", {"split": 2}), ("mixed_small", {"split": 3}),
+                                     ("scene3", {"force_diffuse": True, "split": 3}),  # BASELINE config 2's tree: full-sweep SAH
+                                     ("scene3", {"force_diffuse": False, "split": 1}), ("background", {"split": 2})])
 def test_device_build_equals_reference_build_scene(name, kw, scenes, oracle_api, host_api):
     """Scene bvh over triangles + spheres + planes: the device builder must return the tree the oracle's
     restatement of bvh::Build returns, bit for bit (numbering, boxes, primitiveIdx)."""
@@ -925,23 +928,88 @@ def test_device_build_equals_reference_build_scene(name, kw, scenes, oracle_api,
     tv = np.concatenate(tris) if tris else np.zeros((0, 9), np.float32)
     assert len(tv) == ref["NTri"] and len(rec.spheres) == ref["NSph"] and len(rec.planes) == ref["NPla"]
     r = host_api.HostRenderer(8, 8)
-    _same_tree(r.build_bvh(tv, rec.spheres or None, rec.planes or None), ref)
+    _same_tree(r.build_bvh(tv, rec.spheres or None, rec.planes or None, split=kw.get("split", 0)), ref)
     r.close()
 
 
-@pytest.mark.parametrize("mesh", ["unity", "BigB", "lowBigB"])
-def test_device_build_equals_reference_build_mesh(mesh, scenes, oracle_api, host_api):
-    """The BLAS of a mesh (bvh(Mesh*)): 12,584 / 11,830 triangles, ~24 levels."""
+@pytest.mark.parametrize("mesh,split", [("unity", 0), ("BigB", 0), ("lowBigB", 0), ("BigB", 1), ("BigB", 2), ("lowBigB", 3), ("three", 3), ("stellatedDode", 3)])
+def test_device_build_equals_reference_build_mesh(mesh, split, scenes, oracle_api, host_api):
+    """The BLAS of a mesh (bvh(Mesh*)): 12,584 / 11,830 triangles, ~24 levels; the four split methods of bvh.h:38-43
+    (the quadratic full-sweep SAH on the small meshes)."""
+    from conftest import pkg
     o = oracle_api.OracleScene()
-    scenes.REGISTRY["tlas_test2"](o, mesh=mesh) if mesh != "unity" else scenes.REGISTRY["pretty_tlas"](o, n_instances=2)
+    if mesh == "unity":
+        scenes.REGISTRY["pretty_tlas"](o, n_instances=2, split=split)
+    else:
+        m = o.mesh_obj(1, pkg("assets").obj_path(mesh), o.diffuse(0.8, (1, 1, 1)), (0, 0.5, 0), 1)
+        o.build_tlas(split, [(m, o.trs((0, 0, 3), 4, 0.0, 0.5, 0.0))])
     ref = o.bvh_dump(0)
     tv = o.mesh_tris(0)[0][:, :9]
     r = host_api.HostRenderer(8, 8)
     if not np.isfinite(tv).all():
         with pytest.raises(RuntimeError):
-            r.build_bvh(tv)
+            r.build_bvh(tv, split=split)
     else:
-        _same_tree(r.build_bvh(tv), ref)
+        _same_tree(r.build_bvh(tv, split=split), ref)
+    r.close()
+
+
+@pytest.mark.parametrize("name,kw", [("tlas_test2", {}), ("pretty_tlas", {"n_instances": 8}), ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}), ("bigb_instanced", {"n": 1, "mesh": "lowBigB"})])
+def test_device_tlas_build_equals_reference(name, kw, scenes, oracle_api, host_api):
+    """tlas::build (tlas.cpp:13-48) on the device: same node order, child packing and boxes as the oracle's restatement."""
+    o = oracle_api.OracleScene()
+    scenes.REGISTRY[name](o, **kw)
+    b6 = np.stack([o.instance_dump(i)["bounds"] for i in range(o.n_instances)])
+    r = host_api.HostRenderer(8, 8)
+    assert np.array_equal(r.build_tlas(b6), o.tlas_dump())
+    r.close()
+
+
+def test_device_tlas_build_sizes(host_api):
+    """1, 2, 3, 100 and 256 instances with random boxes against a plain restatement of the clustering loop; > 256 is refused."""
+    r = host_api.HostRenderer(8, 8)
+    rng = np.random.default_rng(12)
+    def reference(b6):
+        n = len(b6)
+        node = np.zeros((2 * n + 1, 8), np.uint32)
+        nf = node.view(np.float32)
+        idx = list(range(1, n + 1))
+        for i in range(n):
+            nf[1 + i, 0:3], nf[1 + i, 4:7] = b6[i, :3], b6[i, 3:]
+            node[1 + i, 7] = i
+        used = n + 1
+        live = n
+        def best(A):
+            ids = np.array(idx[:live])
+            e = np.maximum(nf[idx[A], 4:7][None], nf[ids, 4:7]) - np.minimum(nf[idx[A], 0:3][None], nf[ids, 0:3])  # float32 throughout
+            area = (e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2]) + e[:, 2] * e[:, 0]
+            if A < live:
+                area[A] = np.inf
+            B = int(np.argmin(area))  # the first minimum, like the strict '<' of FindBestMatch
+            return B if area[B] < np.float32(1e30) else -1
+        A, B = 0, best(0) if n > 1 else 0
+        while live > 1:
+            Cc = best(B)
+            if A != Cc:
+                A, B = B, Cc
+                continue
+            ia, ib = idx[A], idx[B]
+            node[used, 3] = ia + (ib << 16)
+            nf[used, 0:3] = np.minimum(nf[ia, 0:3], nf[ib, 0:3])
+            nf[used, 4:7] = np.maximum(nf[ia, 4:7], nf[ib, 4:7])
+            idx[A] = used
+            used += 1
+            idx[B] = idx[live - 1]  # the list only shrinks logically: A may now sit past its end, as in the reference
+            live -= 1
+            B = best(A)
+        node[0] = node[idx[A]]
+        return node[:used]
+    for n in (1, 2, 3, 100, 256):
+        lo = rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+        b6 = np.concatenate([lo, lo + rng.uniform(0.1, 5, (n, 3)).astype(np.float32)], 1)
+        assert np.array_equal(r.build_tlas(b6), reference(b6)), n
+    with pytest.raises(RuntimeError):
+        r.build_tlas(np.zeros((257, 6), np.float32))
     r.close()
 
 
@@ -967,7 +1035,8 @@ def test_device_build_degenerate_inputs(oracle_api, host_api):
     r.close()
 
 
-@pytest.mark.parametrize("name,kw,blas", [("mixed_small", {}, -1), ("tlas_test2", {}, 0), ("pretty_tlas", {"n_instances": 3}, 1)])
+@pytest.mark.parametrize("name,kw,blas", [("mixed_small", {}, -1), ("tlas_test2", {}, 0), ("pretty_tlas", {"n_instances": 3}, 1),
+                                          ("scene3", {"force_diffuse": True, "split": 3}, -1), ("mixed_small", {"split": 1}, -1), ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 0)])
 def test_host_mirror_builds_on_the_device(name, kw, blas, scenes, oracle_api, host_api):
     """rapt::Scene with deviceBuild set: BuildBVH / BuildTLAS go through bvh::BuildOnDevice -> rt_build_bvh.
     Same arrays as the oracle's builder, and the rendered frame is the host-built scene's frame."""
@@ -983,6 +1052,8 @@ def test_host_mirror_builds_on_the_device(name, kw, blas, scenes, oracle_api, ho
     keep[1] = False
     assert np.array_equal(got["nodes"][:ref["nodes_used"]][keep], ref["nodes"][:ref["nodes_used"]][keep])
     assert got["max_depth"] == ref["max_depth"]
+    if d["tlas"]:
+        assert np.array_equal(r2.scene.tlas_dump(), o.tlas_dump())  # tlas::BuildOnDevice
     r2.commit()
     if "camera" in d:
         c = d["camera"]
