@@ -37,6 +37,7 @@ struct rt_ctx {
 	float4* wideMut = nullptr; int wideNodes = 0; // 4-wide nodes: their boxes follow the pair records after a refit
 	uint* refitOrder = nullptr; int* refitLevelStart = nullptr;
 	int refitLevels = 0, animSlots = 0;
+	std::vector<int> refitLevelHost; // levelStart[] on the host: which levels are wide enough for a launch of their own
 	// camera
 	DCamera C;
 	bool cameraSet = false;
@@ -520,6 +521,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			level.swap(next);
 		}
 		c->refitLevels = (int)levelStart.size() - 1;
+		c->refitLevelHost = levelStart;
 		c->animSlots = (int)b.n_prims;
 		HIPCHK(c, dalloc(c->sceneAllocs, &c->primsOrig, (size_t)b.n_prims * 4));
 		HIPCHK(c, hipMemcpy(c->primsOrig, prims.data(), (size_t)b.n_prims * 64, hipMemcpyHostToDevice));
@@ -877,7 +879,23 @@ int rt_set_time(rt_ctx* c, float t)
 	const float r = fmodf(t, 2 * RT_PI);
 	const float a = (float)sin((double)r) * 0.5f;
 	hipLaunchKernelGGL(k_animate, dim3((c->animSlots + 255) / 256), dim3(256), 0, c->stream, c->primsOrig, c->primsMut, c->animSlots, a);
-	if (c->refitLevels > 0) hipLaunchKernelGGL(k_refit, dim3(1), dim3(1024), 0, c->stream, c->pairsMut, c->primsMut, c->refitOrder, c->refitLevelStart, c->refitLevels);
+	if (c->refitLevels > 0) {
+		// bottom up: a level with more records than one workgroup covers in two passes gets a launch of its own across the
+		// chip; the narrow levels above the last such level share one workgroup with barriers between them
+		int top = c->refitLevels; // levels [0, top) are left for the single-workgroup kernel
+		for (int l = c->refitLevels - 1; l >= 0; l--) {
+			const int count = c->refitLevelHost[l + 1] - c->refitLevelHost[l];
+			if (count < 2048) continue;
+			// everything deeper than l must be done first: the narrow levels between two wide ones go with the next wide launch's predecessor
+			for (int m = top - 1; m > l; m--) {
+				const int cm = c->refitLevelHost[m + 1] - c->refitLevelHost[m];
+				if (cm > 0) hipLaunchKernelGGL(k_refit_level, dim3((cm + 255) / 256), dim3(256), 0, c->stream, c->pairsMut, c->primsMut, c->refitOrder, c->refitLevelHost[m], cm);
+			}
+			hipLaunchKernelGGL(k_refit_level, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->pairsMut, c->primsMut, c->refitOrder, c->refitLevelHost[l], count);
+			top = l;
+		}
+		if (top > 0) hipLaunchKernelGGL(k_refit, dim3(1), dim3(1024), 0, c->stream, c->pairsMut, c->primsMut, c->refitOrder, c->refitLevelStart, top);
+	}
 	if (c->S.wide && c->wideNodes > 0) hipLaunchKernelGGL(k_wide_sync, dim3((c->wideNodes * 4 + 255) / 256), dim3(256), 0, c->stream, c->wideMut, c->pairsMut, c->wideNodes);
 	HIPCHK(c, hipGetLastError());
 	return RT_OK;

@@ -1075,27 +1075,36 @@ __device__ __forceinline__ void leaf_bounds(const float4* prims, uint first, f3&
 // k_refit: bvh::Refit (bvh.cpp:556-594).  A pair record holds the boxes of its two children, so the
 // records are processed deepest level first; 'order' lists them by level, levelStart[l] .. [l+1].
 // One workgroup walks all levels (a tree of 10^4..10^5 nodes has a few dozen), barrier between levels.
+__device__ __forceinline__ void refit_record(float4* pairs, const float4* prims, uint record)
+{
+	float4* rec = pairs + 4 * (size_t)record;
+	for (int s = 0; s < 2; s++) {
+		const uint lk = __float_as_uint(rec[2 * s].w);
+		f3 lo, hi;
+		if (lk & RT_LEAF_BIT) leaf_bounds(prims, lk & ~RT_LEAF_BIT, lo, hi);
+		else {
+			const float4* ch = pairs + 4 * (size_t)lk; // child pair: already refitted (deeper level)
+			lo = f3(t_fminf(ch[0].x, ch[2].x), t_fminf(ch[0].y, ch[2].y), t_fminf(ch[0].z, ch[2].z));
+			hi = f3(t_fmaxf(ch[1].x, ch[3].x), t_fmaxf(ch[1].y, ch[3].y), t_fmaxf(ch[1].z, ch[3].z));
+		}
+		rec[2 * s] = mk4(lo, rec[2 * s].w);
+		rec[2 * s + 1] = mk4(hi, 0.0f);
+	}
+}
+// the levels [0, nLevels) in one workgroup, deepest first, a barrier between levels (the narrow top of the tree)
 __global__ void __launch_bounds__(1024) k_refit(float4* pairs, const float4* prims, const uint* order, const int* levelStart, int nLevels)
 {
 	for (int l = nLevels - 1; l >= 0; l--) {
-		for (int i = levelStart[l] + (int)threadIdx.x; i < levelStart[l + 1]; i += (int)blockDim.x) {
-			float4* rec = pairs + 4 * (size_t)order[i];
-			for (int s = 0; s < 2; s++) {
-				const uint lk = __float_as_uint(rec[2 * s].w);
-				f3 lo, hi;
-				if (lk & RT_LEAF_BIT) leaf_bounds(prims, lk & ~RT_LEAF_BIT, lo, hi);
-				else {
-					const float4* ch = pairs + 4 * (size_t)lk; // child pair: already refitted (deeper level)
-					lo = f3(t_fminf(ch[0].x, ch[2].x), t_fminf(ch[0].y, ch[2].y), t_fminf(ch[0].z, ch[2].z));
-					hi = f3(t_fmaxf(ch[1].x, ch[3].x), t_fmaxf(ch[1].y, ch[3].y), t_fmaxf(ch[1].z, ch[3].z));
-				}
-				rec[2 * s] = mk4(lo, rec[2 * s].w);
-				rec[2 * s + 1] = mk4(hi, 0.0f);
-			}
-		}
+		for (int i = levelStart[l] + (int)threadIdx.x; i < levelStart[l + 1]; i += (int)blockDim.x) refit_record(pairs, prims, order[i]);
 		__threadfence_block();
 		__syncthreads();
 	}
+}
+// one wide level across the whole chip: records order[first .. first + count), one thread each
+__global__ void __launch_bounds__(256) k_refit_level(float4* pairs, const float4* prims, const uint* order, int first, int count)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < count) refit_record(pairs, prims, order[first + i]);
 }
 
 // after k_refit: the 4-wide nodes' child boxes are copies of binary node boxes (record src / 2, side src & 1)
