@@ -92,6 +92,23 @@ __global__ void __launch_bounds__(256, 7) walkAmask(const float4* __restrict__ t
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// A with a wave-uniform base in SGPRs and a 32-bit byte offset per lane (global_load ... v_off, s[base]): does the
+// address form matter to the vector-memory path?
+__global__ void __launch_bounds__(256, 7) walkAs(const float4* __restrict__ tab, int steps, unsigned mask, float* out)
+{
+	unsigned idx = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u & mask;
+	float acc = 0;
+	const char* base = (const char*)tab;
+	for (int s = 0; s < steps; s++) {
+		const unsigned off = idx << 6;
+		float4 a, b, c, d;
+		asm volatile("global_load_dwordx4 %0, %4, %5\n global_load_dwordx4 %1, %4, %5 offset:16\n global_load_dwordx4 %2, %4, %5 offset:32\n global_load_dwordx4 %3, %4, %5 offset:48\n s_waitcnt vmcnt(0)"
+		             : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(off), "s"(base) : "memory");
+		acc += a.x + b.y + c.z + d.x;
+		idx = __float_as_uint(a.w) & mask;
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
 // one lane per walker, ONE dwordx4 per step (16-byte records at a 64-byte stride)
 __global__ void __launch_bounds__(256, 7) walkA1(const float4* __restrict__ tab, int steps, unsigned mask, float* out)
 {
@@ -145,7 +162,7 @@ int main()
 		hipEvent_t a, b;
 		CHK(hipEventCreate(&a));
 		CHK(hipEventCreate(&b));
-		for (int variant = 0; variant < 9; variant++) {
+		for (int variant = 0; variant < 10; variant++) {
 			for (int rep = 0; rep < 2; rep++) {
 				CHK(hipEventRecord(a));
 				if (variant == 0) hipLaunchKernelGGL(walkA, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
@@ -156,13 +173,14 @@ int main()
 				if (variant == 5) hipLaunchKernelGGL(walkA1, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 7) hipLaunchKernelGGL(walkAmask<2>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 8) hipLaunchKernelGGL(walkAmask<4>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 9) hipLaunchKernelGGL(walkAs, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 6) hipLaunchKernelGGL(walkA8, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				CHK(hipEventRecord(b));
 				CHK(hipEventSynchronize(b));
 				float ms;
 				CHK(hipEventElapsedTime(&ms, a, b));
-				const double per[9] = { 1, 0.25, 0.5, 0.5, 1, 1, 1, 0.5, 0.25 };
-				const char* names[9] = { "A  lane, 4 loads/rec", "Q  quad, 1 load/lane", "P  pair, 2 loads/lane", "Q2 quad, 2 chains", "Q4 quad, 4 chains", "A1 lane, 1 load (16 B)", "A8 lane, 8 loads (128 B)", "A  every 2nd lane only", "A  every 4th lane only" };
+				const double per[10] = { 1, 0.25, 0.5, 0.5, 1, 1, 1, 0.5, 0.25, 1 };
+				const char* names[10] = { "A  lane, 4 loads/rec", "Q  quad, 1 load/lane", "P  pair, 2 loads/lane", "Q2 quad, 2 chains", "Q4 quad, 4 chains", "A1 lane, 1 load (16 B)", "A8 lane, 8 loads (128 B)", "A  every 2nd lane only", "A  every 4th lane only", "As lane, 4 loads, saddr+voffset" };
 				const double walkers = (double)blocks * threads * per[variant];
 				if (rep == 1) printf("table %5u KB  %-26s %8.3f ms  %8.2f G records/s  (%.0f walkers)\n", R * 64 / 1024, names[variant], ms, walkers * steps / ms / 1e6, walkers);
 			}
