@@ -187,11 +187,26 @@ int rt_device_of(const rt_ctx* ctx);
 int rt_intersect_batch(rt_ctx* ctx, int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out);
 /* Scene::IsOccluded(ray) (template/scene.h:1286-1291) for n rays; out[i] = 0 / 1 */
 int rt_occluded_batch(rt_ctx* ctx, int n, const float* O, const float* D, const float* tmax, uint8_t* out);
+/* The queries BELOW Scene level, with the reference's own names: scope
+ *   RT_SCOPE_SCENE     Scene::FindNearest / Scene::IsOccluded (what the two calls above do)
+ *   RT_SCOPE_ACCEL     the scene's accelerator alone: bvh::Intersect / IsOccluded of the scene bvh (bvh.cpp:596-604) or
+ *                      tlas::Intersect / IsOccluded (tlas.cpp:65-122): no lights, no brute-force primitives
+ *   RT_SCOPE_BLAS      bvh::Intersect / IsOccluded of BLAS 'index' in its own object space
+ *   RT_SCOPE_INSTANCE  bvhInstance::BIntersect / IsOccluded of instance 'index' (bvhInstance.cpp:3-35): ray to object
+ *                      space, normal back to world
+ * t_min matters for RT_SCOPE_SCENE only (the BVH uses 0.0001, bvh.cpp:607). */
+enum { RT_SCOPE_SCENE = 0, RT_SCOPE_ACCEL = 1, RT_SCOPE_BLAS = 2, RT_SCOPE_INSTANCE = 3 };
+int rt_intersect_scope(rt_ctx* ctx, int scope, int index, int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out);
+int rt_occluded_scope(rt_ctx* ctx, int scope, int index, int n, const float* O, const float* D, const float* tmax, uint8_t* out);
+/* Scene::GetSkyColor (template/scene.h:1312-1327) for n directions (D: n*3 floats, rgb_out: n*3 floats) */
+int rt_sky_color_batch(rt_ctx* ctx, int n, const float* D, float* rgb_out);
 /* Camera::GetPrimaryRay(x, y) + Scene::FindNearest(t_min) for every pixel ("primary rays only") */
 int rt_primary_hits(rt_ctx* ctx, float t_min, int32_t* obj_idx_out, float* t_out);
 /* Renderer::Trace / Renderer::Sample on caller-supplied rays: rgb_out[n*3].  Stream i starts at
  * InitSeed(seed_base + i). */
 int rt_trace_batch(rt_ctx* ctx, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, float* rgb_out);
+/* The same with Trace / Sample's third argument: energy[3] instead of float3(1) */
+int rt_trace_batch_energy(rt_ctx* ctx, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, const float* energy, float* rgb_out);
 
 /* ---- acceleration structure build ("next" row N1) ------------------------------------------------ */
 /* bvh::Build() with splitMethod BINNEDSAH (bvh.cpp:18-56; FindBestSplitPlane :116-193, Subdivide :223-333,

@@ -181,6 +181,30 @@ class OracleScene:
         self.L.orc_find_nearest_batch(self.h, n, _p(O), _p(D), tm, C.c_float(t_min), _p(t), _p(obj), _p(mat), _p(nrm), _p(cnt))
         return dict(t=t, obj=obj, mat=mat, normal=nrm, counters=dict(zip(ORACLE_COUNTER_NAMES, cnt.tolist())))
 
+    def scope_nearest(self, scope, index, O, D, tmax=None):
+        """bvh::Intersect / tlas::Intersect / bvhInstance::BIntersect: scope 1 accelerator alone, 2 BLAS index, 3 instance index"""
+        O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        n = len(O)
+        t, obj, mat, nrm = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros((n, 3), np.float32)
+        tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
+        self.L.orc_scope_nearest(self.h, scope, index, n, _p(O), _p(D), tm, _p(t), _p(obj), _p(mat), _p(nrm))
+        return dict(t=t, obj=obj, mat=mat, normal=nrm)
+
+    def scope_occluded(self, scope, index, O, D, tmax=None):
+        O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(len(O), dtype=np.uint8)
+        tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
+        self.L.orc_scope_occluded(self.h, scope, index, len(O), _p(O), _p(D), tm, _p(out))
+        return out
+
+    def sky_color(self, D):
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(D), 3), dtype=np.float32)
+        self.L.orc_sky_color(self.h, len(D), _p(D), _p(out))
+        return out
+
     def is_occluded(self, O, D, tmax=None):
         O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
         D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
@@ -230,6 +254,14 @@ class OracleRenderer:
         ch = C.c_int(int(cam_changed))
         it = self.L.orc_tick(self.h, C.byref(ch), C.c_uint(frame), C.c_uint(seed_base), nthreads, _p(px))
         return px, it
+
+    def trace_rays(self, mode, O, D, depth=4, energy=(1, 1, 1), seed_base=0x12345678):
+        """Renderer::Trace (mode 0) / Sample (mode 1) on caller rays with a caller energy."""
+        O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(O), 3), dtype=np.float32)
+        self.L.orc_trace_rays(self.h, mode, len(O), _p(O), _p(D), depth, _f3(energy), C.c_uint(seed_base), _p(out))
+        return out
 
     def accumulator(self):
         out = np.zeros((self.hgt, self.w, 4), dtype=np.float32)

@@ -236,6 +236,49 @@ int orc_find_nearest_batch(void* h, int n, const float* O, const float* D, const
 	counters_out(cnt, counters);
 	return 0;
 }
+// The queries below Scene level: scope 1 = the scene's accelerator alone (bvh::Intersect of the scene bvh / tlas::Intersect:
+// no lights, no brute-force primitives), 2 = bvh::Intersect of BLAS 'index' in its own object space, 3 =
+// bvhInstance::BIntersect of instance 'index' (bvh.cpp:596-604, tlas.cpp:65-122, bvhInstance.cpp:3-35).
+int orc_scope_nearest(void* h, int scope, int index, int n, const float* O, const float* D, const float* tmax,
+                      float* outT, int* outObj, int* outMat, float* outN)
+{
+	const Scene& sc = ((OrcScene*)h)->sc;
+	Counters cnt;
+	for (int i = 0; i < n; i++) {
+		Ray r(f3(O + 3 * i), f3(D + 3 * i), tmax ? tmax[i] : 1e34f);
+		r.objIdx = -1;
+		if (scope == 1) { if (sc.useTLAS) sc.tl->Intersect(r, cnt); else sc.b->Intersect(r, cnt); }
+		else if (scope == 2) (sc.useTLAS ? sc.blasList[index] : sc.b)->Intersect(r, cnt);
+		else sc.instances[index]->BIntersect(r, cnt);
+		outT[i] = r.t, outObj[i] = r.objIdx, outMat[i] = r.objIdx == -1 ? -1 : r.mat;
+		outN[3 * i] = r.hitNormal.x, outN[3 * i + 1] = r.hitNormal.y, outN[3 * i + 2] = r.hitNormal.z;
+	}
+	return 0;
+}
+int orc_scope_occluded(void* h, int scope, int index, int n, const float* O, const float* D, const float* tmax, unsigned char* out)
+{
+	const Scene& sc = ((OrcScene*)h)->sc;
+	Counters cnt;
+	for (int i = 0; i < n; i++) {
+		Ray r(f3(O + 3 * i), f3(D + 3 * i), tmax ? tmax[i] : 1e34f);
+		bool o;
+		if (scope == 1) o = sc.useTLAS ? sc.tl->IsOccluded(r, cnt) : sc.b->IsOccluded(r, cnt);
+		else if (scope == 2) o = (sc.useTLAS ? sc.blasList[index] : sc.b)->IsOccluded(r, cnt);
+		else o = sc.instances[index]->IsOccluded(r, cnt);
+		out[i] = o ? 1 : 0;
+	}
+	return 0;
+}
+// Scene::GetSkyColor (template/scene.h:1312-1327) for n directions
+void orc_sky_color(void* h, int n, const float* D, float* rgb)
+{
+	const Scene& sc = ((OrcScene*)h)->sc;
+	for (int i = 0; i < n; i++) {
+		Ray r(float3(0), f3(D + 3 * i));
+		const float3 c = sc.GetSkyColor(r);
+		rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+	}
+}
 int orc_is_occluded_batch(void* h, int n, const float* O, const float* D, const float* tmax, unsigned char* out, unsigned long long* counters)
 {
 	const Scene& sc = ((OrcScene*)h)->sc;
@@ -309,6 +352,19 @@ int orc_tick(void* h, int* camChanged, unsigned frame, unsigned seedBase, int nt
 	r.Tick(ch, frame, seedBase, pixels);
 	*camChanged = ch ? 1 : 0;
 	return r.iterationNumber;
+}
+// Renderer::Trace (mode 0) / Renderer::Sample (mode 1) on caller rays with a caller energy; ray i draws from the
+// stream StreamSeed(seedBase + i), as rt_trace_batch does
+void orc_trace_rays(void* h, int mode, int n, const float* O, const float* D, int depth, const float* energy, unsigned seedBase, float* rgb)
+{
+	Renderer& r = ((OrcRenderer*)h)->r;
+	Counters cnt;
+	for (int i = 0; i < n; i++) {
+		uint seed = StreamSeed(seedBase + (uint)i);
+		Ray ray(f3(O + 3 * i), f3(D + 3 * i));
+		const float3 c = mode == 0 ? r.Trace(ray, depth, f3(energy), seed, cnt) : r.Sample(ray, depth, f3(energy), seed, cnt);
+		rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+	}
 }
 void orc_get_accumulator(void* h, float* out) { const Renderer& r = ((OrcRenderer*)h)->r; memcpy(out, r.accumulator.data(), r.accumulator.size() * 16); }
 // screen->pixels for iteration count 'it' (renderer.cpp:287-290)

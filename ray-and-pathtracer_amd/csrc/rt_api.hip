@@ -34,6 +34,7 @@ struct rt_ctx {
 	// animation (rt_set_time): original leaf records of the scene BVH and its pair records by level
 	float4* primsOrig = nullptr;
 	float4* pairsMut = nullptr; float4* primsMut = nullptr;
+	std::vector<uint> blasRoot, blasRootWide; int nInstances = 0; // roots for the scoped queries (rt_intersect_scope)
 	float4* wideMut = nullptr; int wideNodes = 0; // 4-wide nodes: their boxes follow the pair records after a refit
 	uint* refitOrder = nullptr; int* refitLevelStart = nullptr;
 	int refitLevels = 0, animSlots = 0;
@@ -709,6 +710,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		S.sky = ds, S.skyW = d->sky_w, S.skyH = d->sky_h, S.skyN = d->sky_n;
 	}
 	c->S = S;
+	c->blasRoot = rootLink, c->blasRootWide = wideOK ? rootWide : rootLink, c->nInstances = d->use_tlas ? (int)d->n_instances : 0;
 	c->sceneLoaded = true;
 	return RT_OK;
 }
@@ -1260,6 +1262,13 @@ int rt_render(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t seed_b
 
 int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, float* rgb_out)
 {
+	const float one[3] = { 1, 1, 1 };
+	return rt_trace_batch_energy(c, mode, n, O, D, depth, seed_base, one, rgb_out);
+}
+
+int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, const float* energy, float* rgb_out)
+{
+	if (!energy) return fail(c, RT_E_ARG, "rt_trace_batch: null energy");
 	if (!c || !O || !D || !rgb_out || n < 0) return fail(c, RT_E_ARG, "rt_trace_batch: bad argument");
 	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_trace_batch: no scene uploaded");
 	if (n == 0) return RT_OK;
@@ -1283,6 +1292,7 @@ int rt_trace_batch(rt_ctx* c, int mode, int n, const float* O, const float* D, i
 	memset(&R, 0, sizeof(R));
 	R.mode = mode, R.nSamples = (uint)n, R.tilePixels = (uint)n, R.seedBase = seed_base, R.maxDepth = depth, R.accum = c->accum;
 	R.customO = dO, R.customD = dD, R.customOut = dOut, R.customDepth = depth;
+	R.customE[0] = energy[0], R.customE[1] = energy[1], R.customE[2] = energy[2];
 	if (mode == RT_MODE_PATH && c->pathUnsupported) {
 		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
 		rc = check_overflow(c);
@@ -1393,10 +1403,35 @@ static int check_overflow(rt_ctx* c)
 }
 static int query_grid(rt_ctx* c, int n) { int g = (n + RT_CHUNK - 1) / RT_CHUNK / 4 + 1; return g > c->gridQuery ? c->gridQuery : g; }
 
+// the scene as a query of the given scope sees it: rooted at the accelerator, one BLAS or one instance
+static int scoped_scene(rt_ctx* c, int scope, int index, DScene& S, const char* who)
+{
+	S = c->S;
+	if (scope == RT_SCOPE_SCENE || scope == RT_SCOPE_ACCEL) return RT_OK;
+	if (scope == RT_SCOPE_BLAS) {
+		if (index < 0 || index >= (int)c->blasRoot.size()) return fail(c, RT_E_ARG, "%s: blas %d of %d", who, index, (int)c->blasRoot.size());
+		S.useTLAS = 0, S.rootLink = c->blasRoot[(size_t)index], S.rootWide = c->blasRootWide[(size_t)index], S.nBruteSph = S.nBrutePla = 0;
+		return RT_OK;
+	}
+	if (scope == RT_SCOPE_INSTANCE) {
+		if (!c->S.useTLAS || index < 0 || index >= c->nInstances) return fail(c, RT_E_ARG, "%s: instance %d of %d", who, index, c->S.useTLAS ? c->nInstances : 0);
+		S.rootLink = RT_INST_BIT | (uint)index;
+		return RT_OK;
+	}
+	return fail(c, RT_E_ARG, "%s: scope %d", who, scope);
+}
+
 int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out)
+{
+	return rt_intersect_scope(c, RT_SCOPE_SCENE, 0, n, O, D, tmax, t_min, out);
+}
+
+int rt_intersect_scope(rt_ctx* c, int scope, int index, int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out)
 {
 	if (!c || !O || !D || !out || n < 0) return fail(c, RT_E_ARG, "rt_intersect_batch: bad argument");
 	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_intersect_batch: no scene uploaded");
+	DScene S;
+	{ const int src = scoped_scene(c, scope, index, S, "rt_intersect_scope"); if (src != RT_OK) return src; }
 	if (n == 0) return RT_OK;
 	HIPCHK(c, hipSetDevice(c->device));
 	std::vector<void*> tmp;
@@ -1413,8 +1448,14 @@ int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const f
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_query_nearest<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
-		else hipLaunchKernelGGL(k_query_nearest<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
+		const bool head = scope == RT_SCOPE_SCENE;
+		if (c->counting) {
+			if (head) hipLaunchKernelGGL((k_query_nearest<true, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
+			else hipLaunchKernelGGL((k_query_nearest<true, false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
+		} else {
+			if (head) hipLaunchKernelGGL((k_query_nearest<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
+			else hipLaunchKernelGGL((k_query_nearest<false, false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
+		}
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}
@@ -1428,8 +1469,34 @@ int rt_intersect_batch(rt_ctx* c, int n, const float* O, const float* D, const f
 
 int rt_occluded_batch(rt_ctx* c, int n, const float* O, const float* D, const float* tmax, uint8_t* out)
 {
+	return rt_occluded_scope(c, RT_SCOPE_SCENE, 0, n, O, D, tmax, out);
+}
+
+int rt_sky_color_batch(rt_ctx* c, int n, const float* D, float* rgb_out)
+{
+	if (!c || !D || !rgb_out || n < 0) return fail(c, RT_E_ARG, "rt_sky_color_batch: bad argument");
+	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_sky_color_batch: no scene uploaded");
+	if (n == 0) return RT_OK;
+	HIPCHK(c, hipSetDevice(c->device));
+	std::vector<void*> tmp;
+	struct Guard { std::vector<void*>& v; ~Guard() { free_pool(v); } } guard{ tmp };
+	float *dD = nullptr, *dC = nullptr;
+	HIPCHK(c, dalloc(tmp, &dD, (size_t)3 * n));
+	HIPCHK(c, dalloc(tmp, &dC, (size_t)3 * n));
+	HIPCHK(c, hipMemcpyAsync(dD, D, (size_t)12 * n, hipMemcpyHostToDevice, c->stream));
+	hipLaunchKernelGGL(k_sky_color, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, n, dD, dC);
+	HIPCHK(c, hipMemcpyAsync(rgb_out, dC, (size_t)12 * n, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipGetLastError());
+	return RT_OK;
+}
+
+int rt_occluded_scope(rt_ctx* c, int scope, int index, int n, const float* O, const float* D, const float* tmax, uint8_t* out)
+{
 	if (!c || !O || !D || !out || n < 0) return fail(c, RT_E_ARG, "rt_occluded_batch: bad argument");
 	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_occluded_batch: no scene uploaded");
+	DScene S;
+	{ const int src = scoped_scene(c, scope, index, S, "rt_occluded_scope"); if (src != RT_OK) return src; }
 	if (n == 0) return RT_OK;
 	HIPCHK(c, hipSetDevice(c->device));
 	std::vector<void*> tmp;
@@ -1449,14 +1516,14 @@ int rt_occluded_batch(rt_ctx* c, int n, const float* O, const float* D, const fl
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL((k_query_occluded<true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
-		else if (!wideWalk) hipLaunchKernelGGL((k_query_occluded<false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+		if (c->counting) hipLaunchKernelGGL((k_query_occluded<true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+		else if (!wideWalk) hipLaunchKernelGGL((k_query_occluded<false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
 		else {
 			// the 4-wide walk, then the binary walk over the rays it handed back (not clean: normally none)
 			(void)hipMemsetAsync(c->flags + 2, 0, sizeof(int), c->stream);
-			hipLaunchKernelGGL((k_query_occluded<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+			hipLaunchKernelGGL((k_query_occluded<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
 			(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream);
-			hipLaunchKernelGGL((k_query_occluded<false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+			hipLaunchKernelGGL((k_query_occluded<false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
 		}
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);

@@ -65,6 +65,7 @@ struct RenderParams {
 	float4* accum;     // accumulator, whole image
 	// rt_trace_batch: caller rays instead of camera rays, raw radiance out instead of accumulation
 	const float* customO; const float* customD; float4* customOut; int customDepth;
+	float customE[3];  // rt_trace_batch_energy: the 'energy' argument of Trace / Sample
 	int finishInline;  // path mode with a slot per sample: nothing to resume and no sample to pull when a segment ends,
 	                   // so shade / light store the finished sample themselves and the round has no finish pass
 };
@@ -345,7 +346,7 @@ __device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, 
 		}
 	}
 	emit_ray(S, P, parityOut, slot, O, D, mode_t_min(R.mode));
-	P.E[slot] = make_float4(1, 1, 1, __uint_as_float(seed));
+	P.E[slot] = R.customO ? make_float4(R.customE[0], R.customE[1], R.customE[2], __uint_as_float(seed)) : make_float4(1, 1, 1, __uint_as_float(seed));
 	if (writeWL) {
 		P.W[slot] = make_float4(1, 1, 1, __int_as_float(depth));
 		P.L[slot] = make_float4(0, 0, 0, __uint_as_float(sid));
@@ -817,6 +818,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_sample_general(DScene S, DCamera C
 			depth = 4;
 		}
 		f3 W(1.0f), E(1.0f), Lsum(0.0f);
+		if (R.customO) E = f3(R.customE[0], R.customE[1], R.customE[2]);
 		Suspended stack[6];
 		int sp = 0;
 		bool resume = false;
@@ -980,7 +982,9 @@ struct PrimaryPolicy {
 };
 
 // work[0] is the queue head (zeroed by the host before the launch), work[1] the overflow flag
-template <bool COUNT>
+// HEAD: Scene::FindNearest (lights and brute-force primitives first); !HEAD: the accelerator alone (bvh::Intersect,
+// tlas::Intersect, bvhInstance::BIntersect -- the host passes a DScene rooted at what is asked for)
+template <bool COUNT, bool HEAD = true>
 __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, const float* O3, const float* D3, const float* tmax, float t_min, int refillMin,
                                                             QueryHit* out, uint* spill, int* work, DCounters* counters)
 {
@@ -989,7 +993,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, con
 	lc.clear();
 	uint rays = 0;
 	NearestQueryPolicy pol(S, O3, D3, tmax, out);
-	trace_persistent<false, COUNT, true>(S, pol, n, work + 16, t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, COUNT, HEAD>(S, pol, n, work + 16, t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
@@ -1021,6 +1025,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, 
 	PrimaryPolicy pol{ S, C, objOut, tOut };
 	trace_persistent<false, COUNT, true>(S, pol, C.width * C.height, work + 16, t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
+}
+
+// Scene::GetSkyColor (template/scene.h:1312-1327) for n directions
+__global__ void k_sky_color(DScene S, int n, const float* D3, float* rgb)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const f3 c = sky_color(S, f3(D3[3 * i], D3[3 * i + 1], D3[3 * i + 2]));
+	rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
 }
 
 // ---- animation: Scene::SetTime + bvh::Refit on the device ------------------------------------------

@@ -249,12 +249,12 @@ int rth_renderer_iteration(void* h) { return ((RthRenderer*)h)->r->scene.GetIter
 int rth_renderer_tick(void* h) { RthRenderer* r = (RthRenderer*)h; GUARD(r, r->r->Tick(0.0f)); return 0; }
 const float* rth_renderer_accumulator(void* h) { return &((RthRenderer*)h)->r->accumulator[0].x; }
 const unsigned* rth_renderer_pixels(void* h) { return ((RthRenderer*)h)->r->screenPixels; }
-int rth_renderer_trace(void* h, int path, const float* O, const float* D, int depth, float* rgb)
+int rth_renderer_trace(void* h, int path, const float* O, const float* D, int depth, const float* energy, float* rgb)
 {
 	RthRenderer* r = (RthRenderer*)h;
 	Ray ray(f3(O), f3(D), float3(0));
 	float3 c;
-	GUARD(r, c = path ? r->r->Sample(ray, depth, float3(1)) : r->r->Trace(ray, depth, float3(1)));
+	GUARD(r, c = path ? r->r->Sample(ray, depth, f3(energy)) : r->r->Trace(ray, depth, f3(energy)));
 	rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
 	return 0;
 }
@@ -271,6 +271,44 @@ int rth_scene_find_nearest(void* h, const float* O, const float* D, float tmax, 
 	GUARD(s, s->sc->FindNearest(ray, t_min));
 	*t = ray.t, *obj = ray.objIdx;
 	normal[0] = ray.hitNormal.x, normal[1] = ray.hitNormal.y, normal[2] = ray.hitNormal.z;
+	return 0;
+}
+// the members below Scene level: which = 0 bvh (scene bvh, or BLAS 'index' in TLAS mode), 1 tlas, 2 bvhInstance 'index'
+int rth_member_intersect(void* h, int which, int index, const float* O, const float* D, float tmax, float* t, int* obj, float* normal)
+{
+	RthScene* s = (RthScene*)h;
+	Ray ray(f3(O), f3(D), float3(0), tmax);
+	ray.objIdx = -1;
+	GUARD(s, {
+		Scene& sc = *s->sc;
+		if (which == 0) { bvh* bv = sc.useTLAS ? nullptr : sc.b; if (sc.useTLAS) for (uint i = 0; i < sc.bvhCount; i++) if (sc.bvhList[i].blas->blasIndex == index) bv = sc.bvhList[i].blas; if (!bv) throw std::runtime_error("no such bvh"); bv->Intersect(ray); }
+		else if (which == 1) { if (!sc.tl) throw std::runtime_error("no tlas"); sc.tl->Intersect(ray); }
+		else { if (index < 0 || index >= (int)sc.bvhCount) throw std::runtime_error("no such instance"); sc.bvhList[index].BIntersect(ray); }
+	});
+	*t = ray.t, *obj = ray.objIdx;
+	normal[0] = ray.hitNormal.x, normal[1] = ray.hitNormal.y, normal[2] = ray.hitNormal.z;
+	return 0;
+}
+int rth_member_occluded(void* h, int which, int index, const float* O, const float* D, float tmax)
+{
+	RthScene* s = (RthScene*)h;
+	Ray ray(f3(O), f3(D), float3(0), tmax);
+	bool o = false;
+	GUARD(s, {
+		Scene& sc = *s->sc;
+		if (which == 0) { bvh* bv = sc.useTLAS ? nullptr : sc.b; if (sc.useTLAS) for (uint i = 0; i < sc.bvhCount; i++) if (sc.bvhList[i].blas->blasIndex == index) bv = sc.bvhList[i].blas; if (!bv) throw std::runtime_error("no such bvh"); o = bv->IsOccluded(ray); }
+		else if (which == 1) { if (!sc.tl) throw std::runtime_error("no tlas"); o = sc.tl->IsOccluded(ray); }
+		else { if (index < 0 || index >= (int)sc.bvhCount) throw std::runtime_error("no such instance"); o = sc.bvhList[index].IsOccluded(ray); }
+	});
+	return o ? 1 : 0;
+}
+int rth_scene_sky_color(void* h, const float* D, float* rgb)
+{
+	RthScene* s = (RthScene*)h;
+	Ray ray(float3(0), f3(D), float3(0));
+	float3 c;
+	GUARD(s, c = s->sc->GetSkyColor(ray));
+	rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
 	return 0;
 }
 int rth_scene_is_occluded(void* h, const float* O, const float* D, float tmax)

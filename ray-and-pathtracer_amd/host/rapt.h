@@ -199,6 +199,10 @@ public:
 	// throws for what the device builder refuses (no triangle or sphere, non-finite geometry)
 	void BuildOnDevice(rt_ctx* ctx);
 	void Refit();
+	// bvh.h:57, :65 -- on the device, in this bvh's own space (rt_intersect_scope RT_SCOPE_BLAS); valid after Scene::Commit
+	void Intersect(Ray& ray);
+	bool IsOccluded(Ray& ray);
+	Scene* owner = nullptr; int blasIndex = -1; // set by Scene::Commit
 	uint rootNodeIdx = 0, nodesUsed = 2, NTri = 0, NSph = 0, NPla = 0, N = 0;
 	uint* primitiveIdx = nullptr;
 	Scene* scene = nullptr;
@@ -217,6 +221,10 @@ public:
 	bvhInstance() = default;
 	bvhInstance(bvh* blas);
 	void SetTransform(mat4& transform);
+	// bvhInstance.h:11-12 -- on the device (RT_SCOPE_INSTANCE); valid after Scene::Commit
+	void BIntersect(Ray& ray);
+	bool IsOccluded(Ray& ray);
+	Scene* owner = nullptr; int index = -1; // set by Scene::Commit
 	mat4 invTransform, matTransform;
 	bvh* blas = nullptr; // the reference names this member 'bvh'
 	aabb bounds;
@@ -236,6 +244,10 @@ public:
 	~tlas();
 	void build();
 	void BuildOnDevice(rt_ctx* ctx); // tlas::build through rt_build_tlas
+	// tlas.h:20-21 -- on the device (RT_SCOPE_ACCEL); valid after Scene::Commit
+	void Intersect(Ray& ray);
+	bool IsOccluded(Ray& ray);
+	Scene* owner = nullptr; // set by Scene::Commit
 	int FindBestMatch(int* list, int N, int A);
 	TLASNode* tlasNode = nullptr;
 	uint nodesUsed = 0;
@@ -293,7 +305,10 @@ public:
 	void SetTime(float t);
 	void FindNearest(Ray& ray, float t_min) const;   // template/scene.h:1248
 	bool IsOccluded(Ray& ray) const;                 // template/scene.h:1286
-	float3 GetSkyColor(Ray& ray) const;              // template/scene.h:1312 (host evaluation of a miss is not needed by the path; throws)
+	float3 GetSkyColor(Ray& ray) const;              // template/scene.h:1312, evaluated on the device (rt_sky_color_batch)
+	// the queries below Scene level (bvh / tlas / bvhInstance members call these)
+	void ScopeNearest(int scope, int index, Ray& ray) const;
+	bool ScopeOccluded(int scope, int index, Ray& ray) const;
 	void FindNearestBatch(int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out) const;
 	void IsOccludedBatch(int n, const float* O, const float* D, const float* tmax, uint8_t* out) const;
 
@@ -343,7 +358,7 @@ public:
 	void UseAllDevices();                                  // every device rt_device_count() reports
 	void Init();                                           // renderer.cpp:5-11
 	void Commit();                                         // scene.Commit() on every context
-	float3 Trace(Ray& ray, int depth, float3 energy);      // renderer.cpp:21 (energy must be float3(1), as at its only call site :269)
+	float3 Trace(Ray& ray, int depth, float3 energy);      // renderer.cpp:21
 	float3 Sample(Ray& ray, int depth, float3 energy);     // renderer.cpp:128
 	void Tick(float deltaTime);                            // renderer.cpp:240
 	void Shutdown();

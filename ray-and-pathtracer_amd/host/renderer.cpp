@@ -121,21 +121,13 @@ void Renderer::Tick(float /*deltaTime*/)
 	camera.SetChange(false);
 }
 
-static float3 eval(rt_ctx* ctx, int mode, const Ray& ray, int depth, uint32_t seed)
+static float3 eval(rt_ctx* ctx, int mode, const Ray& ray, int depth, const float3& energy, uint32_t seed)
 {
 	float rgb[3];
-	check(ctx, rt_trace_batch(ctx, mode, 1, &ray.O.x, &ray.D.x, depth, seed, rgb));
+	check(ctx, rt_trace_batch_energy(ctx, mode, 1, &ray.O.x, &ray.D.x, depth, seed, &energy.x, rgb));
 	return float3(rgb[0], rgb[1], rgb[2]);
 }
-float3 Renderer::Trace(Ray& ray, int depth, float3 energy)
-{
-	if (energy.x != 1 || energy.y != 1 || energy.z != 1) throw std::runtime_error("Renderer::Trace: energy must be float3(1) (its value at the only external call site, renderer.cpp:269)");
-	return eval(ctx, RT_MODE_WHITTED, ray, depth, seedBase);
-}
-float3 Renderer::Sample(Ray& ray, int depth, float3 energy)
-{
-	if (energy.x != 1 || energy.y != 1 || energy.z != 1) throw std::runtime_error("Renderer::Sample: energy must be float3(1) (renderer.cpp:278)");
-	return eval(ctx, RT_MODE_PATH, ray, depth, seedBase);
-}
+float3 Renderer::Trace(Ray& ray, int depth, float3 energy) { return eval(ctx, RT_MODE_WHITTED, ray, depth, energy, seedBase); }
+float3 Renderer::Sample(Ray& ray, int depth, float3 energy) { return eval(ctx, RT_MODE_PATH, ray, depth, energy, seedBase); }
 
 } // namespace rapt

@@ -379,6 +379,18 @@ void Scene::Commit(rt_ctx* c)
 {
 	ctx = c;
 	check(ctx, rt_upload_scene(ctx, &Describe()));
+	// the accelerator objects learn where they live, for their own Intersect / IsOccluded members
+	if (!useTLAS) { if (b) b->owner = this, b->blasIndex = 0; }
+	else {
+		std::map<const bvh*, int> idx;
+		for (uint i = 0; i < bvhCount; i++) {
+			bvh* bv = bvhList[i].blas;
+			if (!idx.count(bv)) { const int k = (int)idx.size(); idx[bv] = k; }
+			bv->owner = this, bv->blasIndex = idx[bv]; // the order Describe() flattened them in
+			bvhList[i].owner = this, bvhList[i].index = (int)i;
+		}
+		if (tl) tl->owner = this;
+	}
 }
 
 void Scene::CommitAlso(rt_ctx* other) const
@@ -425,9 +437,44 @@ bool Scene::IsOccluded(Ray& ray) const
 	IsOccludedBatch(1, &ray.O.x, &ray.D.x, &ray.t, &o);
 	return o != 0;
 }
-float3 Scene::GetSkyColor(Ray&) const
+float3 Scene::GetSkyColor(Ray& ray) const
 {
-	throw std::runtime_error("Scene::GetSkyColor is evaluated on the device inside Trace/Sample; no host entry point");
+	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");
+	float rgb[3];
+	check(ctx, rt_sky_color_batch(ctx, 1, &ray.D.x, rgb));
+	return float3(rgb[0], rgb[1], rgb[2]);
 }
+
+// bvh::Intersect, tlas::Intersect, bvhInstance::BIntersect and their IsOccluded forms: the same contract as
+// FindNearest (the Ray is mutated when something closer than ray.t is hit), one device round trip per call
+void Scene::ScopeNearest(int scope, int index, Ray& ray) const
+{
+	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");
+	rt_hit h;
+	check(ctx, rt_intersect_scope(ctx, scope, index, 1, &ray.O.x, &ray.D.x, &ray.t, 0.0f, &h));
+	if (h.obj_idx == -1) return; // nothing closer than ray.t: the ray keeps what it had
+	ray.objIdx = h.obj_idx, ray.t = h.t;
+	ray.hitNormal = float3(h.normal[0], h.normal[1], h.normal[2]);
+	ray.m = nullptr;
+	for (auto& kv : flat->matIndex) if (kv.second == h.material) ray.m = const_cast<material*>(kv.first);
+}
+bool Scene::ScopeOccluded(int scope, int index, Ray& ray) const
+{
+	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");
+	uint8_t o = 0;
+	check(ctx, rt_occluded_scope(ctx, scope, index, 1, &ray.O.x, &ray.D.x, &ray.t, &o));
+	return o != 0;
+}
+static Scene* committed(Scene* owner, const char* who)
+{
+	if (!owner) throw std::runtime_error(std::string(who) + ": the scene has not been committed (Scene::Commit)");
+	return owner;
+}
+void bvh::Intersect(Ray& ray) { committed(owner, "bvh::Intersect")->ScopeNearest(RT_SCOPE_BLAS, blasIndex, ray); }
+bool bvh::IsOccluded(Ray& ray) { return committed(owner, "bvh::IsOccluded")->ScopeOccluded(RT_SCOPE_BLAS, blasIndex, ray); }
+void tlas::Intersect(Ray& ray) { committed(owner, "tlas::Intersect")->ScopeNearest(RT_SCOPE_ACCEL, 0, ray); }
+bool tlas::IsOccluded(Ray& ray) { return committed(owner, "tlas::IsOccluded")->ScopeOccluded(RT_SCOPE_ACCEL, 0, ray); }
+void bvhInstance::BIntersect(Ray& ray) { committed(owner, "bvhInstance::BIntersect")->ScopeNearest(RT_SCOPE_INSTANCE, index, ray); }
+bool bvhInstance::IsOccluded(Ray& ray) { return committed(owner, "bvhInstance::IsOccluded")->ScopeOccluded(RT_SCOPE_INSTANCE, index, ray); }
 
 } // namespace rapt

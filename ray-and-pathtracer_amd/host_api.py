@@ -24,7 +24,8 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_render", "rt_render_rows", "rt_clear", "rt_download_accumulator", "rt_resolve", "rt_accumulator_device_ptr",
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
-              "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_device_of"]
+              "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_device_of",
+              "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy"]
 
 
 class RtCamera(C.Structure):
@@ -89,6 +90,10 @@ def rt_lib():
         L.rt_occluded_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_primary_hits.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         L.rt_trace_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+        L.rt_trace_batch_energy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rt_intersect_scope.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.rt_occluded_scope.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_sky_color_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.rt_set_counting.argtypes = [C.c_void_p, C.c_int]
         L.rt_build_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_build_bvh_split.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -269,6 +274,21 @@ class HostScene:
         self._chk(self.L.rth_scene_find_nearest(self.h, _f3(O), _f3(D), C.c_float(tmax), C.c_float(t_min), C.byref(t), C.byref(obj), n))
         return t.value, obj.value, np.array(list(n), dtype=np.float32)
 
+    def member_intersect(self, which, index, O, D, tmax=1e34):
+        """bvh::Intersect (which 0), tlas::Intersect (1), bvhInstance::BIntersect (2) on one ray: (t, objIdx, normal)"""
+        t, obj = C.c_float(), C.c_int()
+        n = (C.c_float * 3)()
+        self._chk(self.L.rth_member_intersect(self.h, which, index, _f3(O), _f3(D), C.c_float(tmax), C.byref(t), C.byref(obj), n))
+        return t.value, obj.value, np.array(list(n), dtype=np.float32)
+
+    def member_occluded(self, which, index, O, D, tmax=1e34):
+        return bool(self._chk(self.L.rth_member_occluded(self.h, which, index, _f3(O), _f3(D), C.c_float(tmax))))
+
+    def sky_color_one(self, D):
+        rgb = (C.c_float * 3)()
+        self._chk(self.L.rth_scene_sky_color(self.h, _f3(D), rgb))
+        return np.array(list(rgb), dtype=np.float32)
+
     def is_occluded_one(self, O, D, tmax=1e34):
         return bool(self._chk(self.L.rth_scene_is_occluded(self.h, _f3(O), _f3(D), C.c_float(tmax))))
 
@@ -336,9 +356,9 @@ class HostRenderer:
         p = C.cast(self.L.rth_renderer_pixels(self.h), C.POINTER(C.c_uint32))
         return np.ctypeslib.as_array(p, shape=(self.hgt, self.w)).copy()
 
-    def trace_one(self, O, D, depth, path=False):
+    def trace_one(self, O, D, depth, path=False, energy=(1, 1, 1)):
         rgb = (C.c_float * 3)()
-        self._chk(self.L.rth_renderer_trace(self.h, int(path), _f3(O), _f3(D), depth, rgb))
+        self._chk(self.L.rth_renderer_trace(self.h, int(path), _f3(O), _f3(D), depth, _f3(energy), rgb))
         return np.array(list(rgb), dtype=np.float32)
 
     # ---- C ABI, direct ----
@@ -427,11 +447,34 @@ class HostRenderer:
         self._rt(self.rt.rt_primary_hits(self.ctx, t_min, _p(obj), _p(t)))
         return obj, t
 
-    def trace_batch(self, mode, O, D, depth=4, seed_base=0x12345678):
+    def trace_batch(self, mode, O, D, depth=4, seed_base=0x12345678, energy=(1, 1, 1)):
         O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
         D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
         out = np.zeros((len(O), 3), dtype=np.float32)
-        self._rt(self.rt.rt_trace_batch(self.ctx, mode, len(O), _p(O), _p(D), depth, seed_base, _p(out)))
+        self._rt(self.rt.rt_trace_batch_energy(self.ctx, mode, len(O), _p(O), _p(D), depth, seed_base, _f3(energy), _p(out)))
+        return out
+
+    def scope_nearest(self, scope, index, O, D, tmax=None):
+        """rt_intersect_scope: 1 the accelerator alone, 2 BLAS index, 3 instance index"""
+        O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(len(O), dtype=RT_HIT_DTYPE)
+        tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
+        self._rt(self.rt.rt_intersect_scope(self.ctx, scope, index, len(O), _p(O), _p(D), tm, C.c_float(0.0), _p(out)))
+        return dict(t=out["t"].copy(), obj=out["obj_idx"].copy(), mat=out["material"].copy(), normal=out["normal"].copy())
+
+    def scope_occluded(self, scope, index, O, D, tmax=None):
+        O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(len(O), dtype=np.uint8)
+        tm = None if tmax is None else _p(np.ascontiguousarray(tmax, dtype=np.float32))
+        self._rt(self.rt.rt_occluded_scope(self.ctx, scope, index, len(O), _p(O), _p(D), tm, _p(out)))
+        return out
+
+    def sky_color(self, D):
+        D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(D), 3), dtype=np.float32)
+        self._rt(self.rt.rt_sky_color_batch(self.ctx, len(D), _p(D), _p(out)))
         return out
 
     def set_counting(self, on):

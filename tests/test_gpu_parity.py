@@ -374,6 +374,58 @@ def test_bench_two_ranks_equal_one(host_api):
     assert two["rays_per_step"] == one["rays_per_step"]  # the two shards trace exactly the rays of the whole frame
 
 
+@pytest.mark.parametrize("name,kw", [("tlas_test2", {"mesh": "BigB"}), ("pretty_tlas", {"n_instances": 4}), ("mixed_small", {})])
+def test_members_below_scene_level(name, kw, scenes, oracle_api, host_api):
+    """The surface SURVEY.md 8b lists under Scene: bvh::Intersect / IsOccluded (bvh.h:57, :65), tlas::Intersect /
+    IsOccluded (tlas.h:20-21), bvhInstance::BIntersect / IsOccluded (bvhInstance.h:11-12) and Scene::GetSkyColor
+    (template/scene.h:1312) -- batch forms through rt_intersect_scope / rt_occluded_scope / rt_sky_color_batch and the
+    one-ray members of the C++ mirror -- and Trace / Sample with an energy other than float3(1)."""
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 48, 32, **kw)
+    O, D = random_rays(12000, 21, center=(0.0, 1.0, 3.0), spread=5.0)
+    pO, pD = orr.primary_rays()
+    O, D = np.concatenate([O, pO]), np.concatenate([D, pD])
+    tmax = np.random.default_rng(2).uniform(0.2, 30.0, len(O)).astype(np.float32)
+    scopes = [(1, 0), (2, 0)] + ([(3, 0), (3, o.n_instances - 1), (2, r.scene.blas_count() - 1)] if d["tlas"] else [])
+    for scope, index in scopes:
+        for tm in (None, tmax):
+            ref = o.scope_nearest(scope, index, O, D, tm)
+            got = r.scope_nearest(scope, index, O, D, tm)
+            assert np.array_equal(got["obj"], ref["obj"]), (scope, index)
+            hit = ref["obj"] != -1
+            assert np.array_equal(got["t"][hit].view(np.uint32), ref["t"][hit].view(np.uint32))
+            assert np.array_equal(got["normal"][hit].view(np.uint32), ref["normal"][hit].view(np.uint32))
+            assert np.array_equal(got["mat"][hit], ref["mat"][hit])
+            assert np.array_equal(r.scope_occluded(scope, index, O, D, tm), o.scope_occluded(scope, index, O, D, tm))
+        assert (o.scope_nearest(scope, index, O, D)["obj"] != -1).mean() > 0.002
+    # the one-ray members of the host mirror
+    for i in (0, 777, 4000, len(O) - 50):
+        for which, index, scope in ([(0, 0, 2), (1, 0, 1), (2, o.n_instances - 1, 3)] if d["tlas"] else [(0, 0, 2)]):
+            ref1 = o.scope_nearest(scope, index, O[i:i + 1], D[i:i + 1])
+            t, obj, n = r.scene.member_intersect(which, index, O[i], D[i])
+            assert obj == ref1["obj"][0]
+            if obj != -1:
+                assert np.float32(t) == ref1["t"][0] and np.array_equal(n, ref1["normal"][0])
+            assert r.scene.member_occluded(which, index, O[i], D[i], 9.0) == bool(o.scope_occluded(scope, index, O[i:i + 1], D[i:i + 1], np.array([9.0], np.float32))[0])
+    # Scene::GetSkyColor
+    sky_ref = o.sky_color(D)
+    assert np.array_equal(r.sky_color(D).view(np.uint32), sky_ref.view(np.uint32))
+    assert np.array_equal(r.scene.sky_color_one(D[5]), sky_ref[5])
+    # Trace / Sample with a caller energy
+    e = (0.5, 0.75, 0.25)
+    for mode in (host_api.RT_MODE_WHITTED, host_api.RT_MODE_PATH):
+        o.set_raytracer(mode == host_api.RT_MODE_WHITTED)
+        ref = orr.trace_rays(mode, pO, pD, 4, e, seed_base=99)
+        got = r.trace_batch(mode, pO, pD, depth=4, seed_base=99, energy=e)
+        err, cls_ok = rel_err(got, ref)
+        assert cls_ok and err.max() <= RADIANCE_TOL
+        one = r.trace_one(pO[200], pD[200], 4, path=False, energy=e) if mode == host_api.RT_MODE_WHITTED else None
+        if one is not None:
+            r.scene.set_raytracer(True)
+            e1, c1 = rel_err(r.trace_one(pO[200], pD[200], 4, path=False, energy=e), orr.trace_rays(0, pO[200:201], pD[200:201], 4, e, seed_base=0x12345678)[0])
+            assert c1 and e1.max() <= RADIANCE_TOL
+    r.close()
+
+
 def test_edge_cases(scenes, oracle_api, host_api):
     r = host_api.HostRenderer(16, 8)
     # calls before a scene is uploaded fail loudly
