@@ -181,7 +181,7 @@ def kernel_hash():
     d = os.path.join(ROOT, "ray-and-pathtracer_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip")) or f == "Makefile":
+        if f.endswith(".h") or f == "Makefile":  # the device code (kernels, traversal, arithmetic) and its compile flags; rt_api.hip is host code
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -76,6 +76,7 @@ struct rt_ctx {
 	std::vector<Timer> timers; // pending event pairs, resolved lazily
 	std::vector<int> timerKind;
 	int* hostCounts = nullptr; // pinned
+	uint* resolveBuf = nullptr; // rt_resolve's device pixels (width * height), allocated on first use
 	float4* samples = nullptr; // finished samples of the current batch, [frame][tile pixel]
 	size_t sampleCap = 0;
 };
@@ -259,6 +260,7 @@ void rt_destroy(rt_ctx* c)
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
 	if (c->samples) (void)hipFree(c->samples);
+	if (c->resolveBuf) (void)hipFree(c->resolveBuf);
 	if (c->flags) (void)hipFree(c->flags);
 	if (c->counters) (void)hipFree(c->counters);
 	if (c->hostCounts) (void)hipHostFree(c->hostCounts);
@@ -1337,13 +1339,11 @@ int rt_resolve(rt_ctx* c, int iteration, int y0, int y1, uint32_t* rgb8_out)
 	if (!c || !rgb8_out || y0 < 0 || y1 > c->height || y0 >= y1 || iteration == 0) return fail(c, RT_E_ARG, "rt_resolve: bad argument");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int n = (y1 - y0) * c->width;
-	uint* d = nullptr;
-	HIPCHK(c, hipMalloc((void**)&d, (size_t)n * 4));
-	hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, y0 * c->width, n, iteration, d);
-	hipError_t e = hipStreamSynchronize(c->stream);
-	if (e == hipSuccess) e = hipMemcpy(rgb8_out, d, (size_t)n * 4, hipMemcpyDeviceToHost);
-	(void)hipFree(d);
-	if (e != hipSuccess) return fail(c, RT_E_HIP, "rt_resolve: %s", hipGetErrorString(e));
+	// one frame-sized pixel buffer per context, kept: Tick resolves every frame
+	if (!c->resolveBuf) HIPCHK(c, hipMalloc((void**)&c->resolveBuf, (size_t)c->width * c->height * 4));
+	hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->accum, y0 * c->width, n, iteration, c->resolveBuf);
+	HIPCHK(c, hipMemcpyAsync(rgb8_out, c->resolveBuf, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return RT_OK;
 }
 

@@ -88,9 +88,11 @@ int rth_add_mesh_tri(void* h, int group, const char* path, int mat)
 	GUARD(s, s->sc->meshes.push_back(Mesh(group, path, s->sc->materials[mat])));
 	return (int)s->sc->meshes.size() - 1;
 }
-int rth_mesh_count(void* h, int mesh) { return (int)((RthScene*)h)->sc->meshes[mesh].tri.size(); }
+int rth_meshes(void* h) { return (int)((RthScene*)h)->sc->meshes.size(); }
+int rth_mesh_count(void* h, int mesh) { const auto& ms = ((RthScene*)h)->sc->meshes; return mesh < 0 || mesh >= (int)ms.size() ? -1 : (int)ms[mesh].tri.size(); }
 void rth_mesh_get(void* h, int mesh, float* out15, int* outIdx)
 {
+	if (rth_mesh_count(h, mesh) < 0) return;
 	const Mesh& m = ((RthScene*)h)->sc->meshes[mesh];
 	for (size_t i = 0; i < m.tri.size(); i++) {
 		const Triangle& t = m.tri[i];

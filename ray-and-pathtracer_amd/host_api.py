@@ -227,8 +227,13 @@ class HostScene:
         self._chk(self.L.rth_scene_set_time(self.h, C.c_float(t)))
 
     # ---- dumps ----
+    def n_meshes(self):
+        return int(self.L.rth_meshes(self.h))
+
     def mesh_tris(self, mesh):
         n = self.L.rth_mesh_count(self.h, mesh)
+        if n < 0:
+            raise IndexError("mesh %d of %d" % (mesh, self.n_meshes()))
         out = np.zeros((n, 15), dtype=np.float32)
         ids = np.zeros(n, dtype=np.int32)
         self.L.rth_mesh_get(self.h, mesh, _p(out), _p(ids))

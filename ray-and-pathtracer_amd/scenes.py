@@ -250,8 +250,254 @@ def mixed_small(b, rt=True, split=BINNEDSAH):
     return dict(name="mixed_small", tlas=False)
 
 
+# ---- the remaining factories of template/scene.h:791-1209, as data -----------------------------------
+# Missing assets (.MISSING_LARGE_BLOBS: eifel.obj, christ.obj, the .hdr skies) are replaced by stated stand-ins: the
+# procedural tower for eifel.obj, stellatedDode.obj for christ.obj, the synthetic sky; everything else (positions,
+# materials, ids, light parameters, transforms) is the factory's own.  Cubes are omitted everywhere: the reference
+# never intersects them (template/scene.h:1253-1255; bvh.cpp:20-22 counts triangles, spheres and planes only).
+
+def _palette(b, rt):
+    """The material set most factories open with (template/scene.h:815-829, :845-856, :1009-1020)."""
+    m = {}
+    m["blueDiff"] = b.diffuse(0.8, BLUE, 0.2, 0.8, 1, rt=rt)
+    m["redDiff"] = b.diffuse(0.8, RED, 0.2, 0.8, 1, rt=rt)
+    m["whiteDiff"] = b.diffuse(0.8, WHITE, 0.0, 1.0, 4, rt=rt)
+    m["greenDiff"] = b.diffuse(0.8, GREEN, 0.2, 0.8, 2, rt=rt)
+    m["standardGlass"] = b.glass(1.5, WHITE, rt=rt)
+    m["blueGlass"] = b.glass(1.5, BABYBLUE, rt=rt)
+    m["blueMetal"] = b.metal(0.7, BLUE, rt=rt)
+    m["standardMetal"] = b.metal(0.7, WHITE, rt=rt)
+    m["greenMetal"] = b.metal(0.7, GREEN, rt=rt)
+    m["redMetal"] = b.metal(0.7, RED, rt=rt)
+    m["yellowMetal"] = b.metal(0.7, GOLD, rt=rt)
+    m["pinkMetal"] = b.metal(0.7, PINK, rt=rt)
+    return m
+
+
+def _tower_mesh(b, group, mat, pos, scale):
+    """Mesh(group, "Resources/eifel.obj", mat, pos, scale) with the tower stand-in (the factory's scale 0.08 suits the
+    real model's units; the stand-in is ~6 units tall and is given the scale that keeps the world size)."""
+    tris = assets.lattice_tower(60, 24).reshape(-1, 3)  # 11,520 triangles
+    tris = (tris * np.float32(scale) + np.array(pos, dtype=np.float32)).astype(np.float32).reshape(-1, 9)
+    return b.mesh_raw(group, mat, tris)
+
+
+def pretty_scene1(b, rt=True, split=BINNEDSAH):
+    """instantiatePrettyScene1 (template/scene.h:814-840): unity.tri in the scene BVH (config 3 instances it instead)."""
+    b.sky(assets.synthetic_sky(seed=5))
+    b.area_light(11, (0.1, 4.0, 5.0), 8.0, WHITE, 1.0, (0, -1, 0))
+    b.area_light(12, (0.1, 4.0, 3.0), 10.0, WHITE, 1.0, (0, -1, 0))
+    light_diff = b.diffuse(0.8, WHITE, 0.6, 0.4, 1200, emission=1.2, rt=rt)
+    standard_glass = b.glass(1.5, WHITE, rt=rt)
+    blue_diff = b.diffuse(0.8, BLUE, 0.6, 0.4, 10, rt=rt)
+    blue_glass = b.glass(1.5, BABYBLUE, rt=rt)
+    yellow_metal = b.metal(0.7, GOLD, rt=rt)
+    pink_metal = b.metal(0.7, PINK, rt=rt)
+    b.sphere(7, blue_diff, (-0.7, -0.5, 2.0), 0.5)
+    b.sphere(8, blue_glass, (-1.9, -0.5, 2.0), 0.5)
+    b.sphere(9, yellow_metal, (-3.1, -0.5, 2.0), 0.5)
+    b.sphere(6, pink_metal, (-4.3, -0.5, 2.0), 0.5)
+    b.plane(1, light_diff, (0, 1, 0), 1)
+    b.mesh_tri(2, assets.tri_path("unity"), standard_glass)
+    b.build(split)
+    return dict(name="pretty_scene1", tlas=False)
+
+
+def pretty_animation_scene(b, rt=True, split=BINNEDSAH):
+    """instantiatePrettyAnimationScene (:842-868): BigB.obj between four walls, the scene SetTime animates."""
+    b.sky(assets.synthetic_sky(seed=6))
+    m = _palette(b, rt)
+    b.area_light(11, (-1, 8.0, -1), 12.0, WHITE, 2.0, (0, -1, 0))
+    b.plane(0, m["whiteDiff"], (0, 1, 0), 1)
+    b.plane(4, m["blueDiff"], (0, 0, -1), 10)
+    b.plane(3, m["blueDiff"], (0, 0, 1), 10)
+    b.plane(1, m["greenDiff"], (-1, 0, 0), 2.99)
+    b.mesh_obj(2, assets.obj_path("BigB"), m["redDiff"], (-2, 1.0, 0), 4.0)
+    b.build(split)
+    return dict(name="pretty_animation", tlas=False)
+
+
+def bigb_scene(b, rt=True, split=BINNEDSAH):
+    """instantiateBigBScene (:880-889)."""
+    b.sky(assets.synthetic_sky(seed=7))
+    light_diff = b.diffuse(0.8, WHITE, 0.6, 0.4, 1200, emission=1.2, rt=rt)
+    b.plane(2, light_diff, (0, 1, 0), 1)
+    b.area_light(11, (0.1, 7.0, 3.0), 8.0, WHITE, 1.0, (0, -1, 0))
+    blue_diff = b.diffuse(0.8, BLUE, 0.2, 0.8, 1, rt=rt)
+    b.mesh_obj(2, assets.obj_path("BigB"), blue_diff, (0, 2.3, 5.0), 6.0)
+    b.build(split)
+    return dict(name="bigb_scene", tlas=False)
+
+
+def christ_scene(b, rt=True, split=BINNEDSAH):
+    """instantiateChristScene (:891-899) / instantiateScene8 (:1200-1208: the same mesh, another light); christ.obj is
+    missing from the snapshot: stellatedDode.obj stands in, scaled to a comparable size."""
+    b.sky(assets.synthetic_sky(seed=8))
+    light_diff = b.diffuse(0.8, WHITE, 0.6, 0.4, 1200, emission=1.2, rt=rt)
+    b.plane(2, light_diff, (0, 1, 0), 1)
+    b.area_light(11, (0.1, 7.0, 5.0), 8.0, WHITE, 1.0, (0, -1, 0))
+    yellow_metal = b.metal(0.7, GOLD, rt=rt)
+    b.mesh_obj(2, assets.obj_path("stellatedDode"), yellow_metal, (0, 0.6, 6.2), 1.5)
+    b.build(split)
+    return dict(name="christ_scene", tlas=False)
+
+
+def tlas_test(b, rt=True, split=BINNEDSAH):
+    """TLASSceneTest (:901-939): three DIFFERENT meshes, one instance each (BigB.obj; christ.obj and eifel.obj by their
+    stand-ins, with scales that give the factory's world sizes)."""
+    b.sky(assets.synthetic_sky(seed=3))
+    standard_metal = b.metal(0.7, WHITE, rt=rt)
+    gold_metal = b.metal(0.7, GOLD, rt=rt)
+    gold_diff = b.diffuse(0.8, GOLD, 0.8, 0.2, 1, rt=rt)
+    red_diff = b.diffuse(0.8, RED, 0.0, 1, 1, rt=rt)
+    spec_refl = b.diffuse(0.7, WHITE, 0.6, 0.4, 50, rt=rt)
+    b.area_light(11, (0, 8.0, 0), 10.0, WHITE, 1.0, (0, -1, 0))
+    m0 = b.mesh_obj(1, assets.obj_path("BigB"), red_diff, (0, 0.5, 0), 1)
+    m1 = b.mesh_obj(2, assets.obj_path("stellatedDode"), gold_metal, (0, 0.5, 0), 1)
+    m2 = _tower_mesh(b, 3, standard_metal, (0, 0.5, 0), 1)
+    T0 = b.trs((0, 0, 3), 4, 0.0, _f32(PI_F * 0.5), 0.0)
+    T1 = b.trs((2, 0, 3), 1.0, 0.0, PI_F, 0.0)
+    T2 = b.trs((_f32(-2.3), 0, 3), 0.5, 0.0, _f32(PI_F * 0.5), 0.0)
+    b.plane(0, spec_refl, (0, 1, 0), 0)
+    b.sphere(7, gold_diff, (1.8, -0.5, 2.0), 0.5)
+    b.build_tlas(split, [(m0, T0), (m1, T1), (m2, T2)])
+    return dict(name="tlas_test", tlas=True)
+
+
+def scene1(b, rt=True, split=BINNEDSAH):
+    """instantiateScene1 (:974-1004), animation off: the box of six planes, glass ball, "rounded corners" sphere, ico.obj."""
+    b.sky(assets.synthetic_sky(seed=12))
+    standard_glass = b.glass(1.5, WHITE, rt=rt)
+    specular_diff = b.diffuse(0.8, WHITE, 0.6, 0.4, 2, rt=rt)
+    light_diff = b.diffuse(0.8, WHITE, 0.6, 0.4, 1200, emission=1.2, rt=rt)
+    green_diff = b.diffuse(0.8, GREEN, 0.6, 0.4, 2, rt=rt)
+    red_diff = b.diffuse(0.8, RED, 0.6, 0.4, 2, rt=rt)
+    spec_refl = b.diffuse(0.7, WHITE, 0.6, 0.4, 50, rt=rt)
+    b.area_light(11, (0.1, 1.95, 1.5), 4.0, WHITE, 1.0, (0, -1, 0))
+    b.plane(0, red_diff, (1, 0, 0), 3)
+    b.plane(1, green_diff, (-1, 0, 0), 2.99)
+    b.plane(2, spec_refl, (0, 1, 0), 1)
+    b.plane(3, light_diff, (0, -1, 0), 2)
+    b.plane(4, light_diff, (0, 0, 1), 3)
+    b.plane(5, specular_diff, (0, 0, -1), 3.99)
+    b.sphere(7, standard_glass, (-1.5, -0.5, 2), 0.5)
+    b.sphere(8, b.diffuse(0.8, WHITE, 0, 0.3, 0, rt=rt), (0, 2.5, -3.07), 8)  # diffuse(0.8f, white, 0, 0.3f, 0.7f -> int 0, rt)
+    b.mesh_obj(1, assets.obj_path("ico"), green_diff, (0.1, -0.6, 1.5), 0.5)
+    b.build(split)
+    return dict(name="scene1", tlas=False)
+
+
+def scene2(b, rt=True, split=BINNEDSAH):
+    """instantiateScene2 (:1006-1043): eight spheres of every material, four planes, the tower (eifel.obj stand-in)."""
+    b.sky(assets.synthetic_sky(seed=13))
+    m = _palette(b, rt)
+    b.area_light(11, (-1, 8.0, -1), 25.0, WHITE, 3.0, (0, -1, 0))
+    b.plane(0, m["whiteDiff"], (0, 1, 0), 1)
+    b.plane(4, m["blueDiff"], (0, 0, -1), 10)
+    b.plane(3, m["blueDiff"], (0, 0, 1), 10)
+    b.plane(1, m["greenDiff"], (-1, 0, 0), 2.99)
+    for idx, mat, pos in ((7, "redDiff", (-0.7, -0.5, 2.0)), (8, "blueGlass", (-1.9, -0.5, 2.0)), (9, "yellowMetal", (-3.1, -0.5, 2.0)),
+                          (6, "pinkMetal", (-4.3, -0.5, 2.0)), (10, "greenMetal", (-0.7, -0.5, 3.2)), (13, "standardGlass", (-1.9, -0.5, 3.2)),
+                          (14, "redDiff", (-3.1, -0.5, 3.2)), (15, "redMetal", (-4.3, -0.5, 3.2))):
+        b.sphere(idx, m[mat], pos, 0.5)
+    _tower_mesh(b, 2, m["standardMetal"], (-2, -1.0, 0), 0.8)
+    b.build(split)
+    return dict(name="scene2", tlas=False)
+
+
+def scene4(b, rt=True, split=BINNEDSAH):
+    """instantiateScene4 (:1094-1115); the light's normal points UP in the factory."""
+    b.sky(assets.synthetic_sky(seed=14))
+    blue_glass = b.glass(1.5, BABYBLUE, rt=rt)
+    standard_metal = b.metal(0.7, WHITE, rt=rt)
+    light_diff = b.diffuse(0.8, PINK, 0.6, 0.4, 30, rt=rt)
+    gold_diff = b.diffuse(0.8, GOLD, 0.6, 0.4, 30, rt=rt)
+    b.area_light(11, (1.8, 2.0, 5.5), 10.0, WHITE, 2.0, (0, 1, 0))
+    b.plane(0, b.diffuse(0.8, WHITE, 0.0, 1.0, 4, rt=rt), (0, 1, 0), 1)
+    b.sphere(7, blue_glass, (-0.7, -0.5, 2.0), 0.5)
+    b.sphere(8, standard_metal, (-2.2, -0.5, 2.0), 0.5)
+    b.sphere(9, light_diff, (-3.7, -0.5, 2.0), 0.5)
+    b.sphere(5, gold_diff, (1.8, -0.5, 2.0), 0.5)
+    b.mesh_obj(1, assets.obj_path("ico"), standard_metal, (0.5, -0.51, 2), 0.5)
+    b.build(split)
+    return dict(name="scene4", tlas=False)
+
+
+def scene5(b, rt=True, split=BINNEDSAH, mesh="BigB"):
+    """instantiateScene5 (:1117-1131): BigB.obj in the scene BVH, two lights."""
+    b.sky(assets.synthetic_sky(seed=15))
+    gold_diff = b.diffuse(0.8, GOLD, 0.6, 0.4, 30, rt=rt)
+    b.area_light(11, (1, 2.0, 1), 10.0, WHITE, 1.0, (0, -1, 0))
+    b.area_light(12, (-1, 2.0, -1), 5.0, WHITE, 1.0, (0, -1, 0))
+    b.plane(0, b.diffuse(0.8, WHITE, 0.0, 1.0, 4, rt=rt), (0, 1, 0), 0)
+    b.mesh_obj(1, assets.obj_path(mesh), gold_diff, (0, 0.5, 0), 1)
+    b.build(split)
+    return dict(name="scene5", tlas=False)
+
+
+def scene6(b, rt=True, split=BINNEDSAH):
+    """instantiateScene6 (:1133-1170): lowBigB.obj, instanced.  The factory fills four transforms into arrays of
+    bvhCount = 3 (template/scene.h:1372; the fourth write is out of bounds) and the TLAS is built over three."""
+    b.sky(assets.synthetic_sky(seed=16))
+    gold_diff = b.diffuse(0.8, GOLD, 0.8, 0.2, 1, rt=rt)
+    red_diff = b.diffuse(0.8, RED, 0.0, 1, 1, rt=rt)
+    b.area_light(11, (0, 6.0, 0), 16.0, WHITE, 2.0, (0, -1, 0))
+    m = b.mesh_obj(1, assets.obj_path("lowBigB"), red_diff, (0, 0.5, 0), 1)
+    ry = _f32(PI_F * 0.5)
+    inst = [(m, b.trs((0, 0, 3), 4, 0.0, ry, 0.0)), (m, b.trs((-3, 0, 2), 4, 0.0, ry, 0.0)), (m, b.trs((2, 0, -3), 4, 0.0, ry, 0.0))]
+    b.plane(0, b.diffuse(0.8, WHITE, 0.0, 1.0, 4, rt=rt), (0, 1, 0), 0)
+    b.sphere(7, gold_diff, (1.8, -0.5, 2.0), 0.5)
+    b.build_tlas(split, inst)
+    return dict(name="scene6", tlas=True)
+
+
+def _xorshift32_floats(seed=0x12345678):
+    """RandomFloat() of the template (template/template.cpp:684-691) from its initial seed, as a generator."""
+    s = seed
+    while True:
+        s ^= (s << 13) & 0xFFFFFFFF
+        s ^= s >> 17
+        s ^= (s << 5) & 0xFFFFFFFF
+        yield float(np.float32(s) * np.float32(2.3283064365387e-10))
+
+
+def scene7(b, rt=True, split=BINNEDSAH, nx=255, ny=255):
+    """instantiateScene7 (:1172-1198): nx x ny unit spheres on the floor, material and colour of each drawn from the
+    template's global RandomFloat() stream (assumed untouched before the Scene is constructed: the Scene is a member
+    of the Renderer, built before anything else draws); ids 13 + x + y collide by design."""
+    b.sky(assets.synthetic_sky(seed=17))
+    white_diff = b.diffuse(0.8, WHITE, 0.0, 1.0, 4, rt=rt)
+    b.plane(0, white_diff, (0, 1, 0), 1)
+    b.area_light(11, (-1, 8.0, -1), 25.0, WHITE, 3.0, (0, -1, 0))
+    rnd = _xorshift32_floats()
+    for x in range(nx):
+        for y in range(ny):
+            die = next(rnd)
+            col = (next(rnd), next(rnd), next(rnd))  # float3(RandomFloat(), RandomFloat(), RandomFloat()): argument order x, y, z
+            if die < 0.33:
+                mat = b.metal(0.7, col, rt=rt)
+            elif die < 0.66:
+                mat = b.glass(1.5, col, rt=rt)
+            else:
+                mat = b.diffuse(0.8, col, 0.2, 0.8, 2, rt=rt)
+            b.sphere(13 + x + y, mat, (float(x), -0.5, float(y)), 0.5)
+    b.build(split)
+    return dict(name="scene7", tlas=False)
+
+
 REGISTRY = {
     "config1": config1, "config2": config2, "config3": config3, "config4": config4, "config5": config5,
     "background": background_scene, "scene3": scene3, "pretty_tlas": pretty_tlas, "tower": tower_scene,
     "bigb_instanced": bigb_instanced, "tlas_test2": tlas_test2, "mixed_small": mixed_small,
+    # every factory of template/scene.h:791-1209 (instantiateBackgroundScene = "background", instantiateScene3 = "scene3",
+    # instantiateEifelScene = "tower", TLASSceneTest2 = "tlas_test2", instantiateScene8 = "christ_scene")
+    "pretty_scene1": pretty_scene1, "pretty_animation": pretty_animation_scene, "bigb_scene": bigb_scene, "christ_scene": christ_scene,
+    "tlas_test": tlas_test, "scene1": scene1, "scene2": scene2, "scene4": scene4, "scene5": scene5, "scene6": scene6, "scene7": scene7,
+}
+REFERENCE_FACTORIES = {  # reference factory -> registry name
+    "instantiateBackgroundScene": "background", "instantiatePrettyScene1": "pretty_scene1", "instantiatePrettyAnimationScene": "pretty_animation",
+    "instantiateEifelScene": "tower", "instantiateBigBScene": "bigb_scene", "instantiateChristScene": "christ_scene", "TLASSceneTest": "tlas_test",
+    "TLASSceneTest2": "tlas_test2", "instantiateScene1": "scene1", "instantiateScene2": "scene2", "instantiateScene3": "scene3",
+    "instantiateScene4": "scene4", "instantiateScene5": "scene5", "instantiateScene6": "scene6", "instantiateScene7": "scene7",
+    "instantiateScene8": "christ_scene",
 }

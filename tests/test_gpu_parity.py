@@ -205,6 +205,31 @@ def test_path_frames(name, kw, w, h, frames, scenes, oracle_api, host_api):
     r.close()
 
 
+@pytest.mark.parametrize("name,kw", [("pretty_scene1", {}), ("pretty_animation", {}), ("bigb_scene", {}), ("christ_scene", {}), ("tlas_test", {}),
+                                     ("scene1", {}), ("scene2", {}), ("scene4", {}), ("scene5", {}), ("scene6", {}), ("scene7", {"nx": 64, "ny": 64}),
+                                     ("scene7", {})])
+def test_reference_factories(name, kw, scenes, oracle_api, host_api):
+    """Every remaining scene factory of the reference (template/scene.h:791-1209, as data in scenes.py): primary hits and
+    their work tallies, one Whitted frame, two path frames.  scene7 at its full 255 x 255 spheres (65,025 materials):
+    primary hits and the Whitted frame."""
+    full7 = name == "scene7" and not kw
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 96, 54, **kw)
+    obj_ref, t_ref, cnt_ref = orr.primary_hits(1e-6)
+    r.set_counting(True)
+    r.counters()
+    obj, t = r.primary_hits(1e-6)
+    cnt = r.counters()
+    r.set_counting(False)
+    assert np.array_equal(obj, obj_ref)
+    assert np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits"):
+        assert cnt[k] == cnt_ref[k], k
+    check_frames(orr, r, "whitted", 1, host_api)
+    if not full7:
+        check_frames(orr, r, "path", 2, host_api)
+    r.close()
+
+
 def test_fisheye_camera(scenes, oracle_api, host_api):
     """Camera::GetPrimaryRay fisheye branch (camera.h:26-32): primary hits and a Whitted frame."""
     o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 64, 40)

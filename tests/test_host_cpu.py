@@ -46,7 +46,10 @@ def test_product_does_not_load_the_oracle():
 SCENES = [("background", {}), ("scene3", {"force_diffuse": False, "split": 0}), ("scene3", {"force_diffuse": False, "split": 1}),
           ("scene3", {"force_diffuse": False, "split": 2}), ("scene3", {"force_diffuse": False, "split": 3}),
           ("mixed_small", {"split": 0}), ("mixed_small", {"split": 3}), ("tlas_test2", {}), ("tlas_test2", {"mesh": "BigB"}),
-          ("pretty_tlas", {"n_instances": 8}), ("tower", {}), ("bigb_instanced", {"n": 16})]
+          ("pretty_tlas", {"n_instances": 8}), ("tower", {}), ("bigb_instanced", {"n": 16}),
+          # the remaining factories of template/scene.h:791-1209 (scenes.REFERENCE_FACTORIES)
+          ("pretty_scene1", {}), ("pretty_animation", {}), ("bigb_scene", {}), ("christ_scene", {}), ("tlas_test", {}), ("scene1", {}),
+          ("scene2", {}), ("scene4", {}), ("scene5", {}), ("scene6", {}), ("scene7", {"nx": 48, "ny": 48})]
 
 
 @pytest.mark.parametrize("name,kw", SCENES)
@@ -65,7 +68,7 @@ def test_builders_match_oracle(name, kw, scenes, oracle_api, host_api):
         assert np.array_equal(np.delete(A["nodes"], 1, axis=0), np.delete(B["nodes"], 1, axis=0))  # node 1 is never written (Q4)
     if d["tlas"]:
         assert np.array_equal(o.tlas_dump(), h.tlas_dump())
-        n_inst = kw.get("n_instances", kw.get("n", 3))
+        n_inst = o.n_instances
         for i in range(n_inst):
             a, b = o.instance_dump(i), h.instance_dump(i)
             assert a["blas"] == b["blas"]
@@ -120,8 +123,17 @@ def test_mat4_products_and_inverse(oracle_api, host_api):
     o.close(); h.close()
 
 
+def test_every_reference_factory_is_expressed_as_data(scenes):
+    """all 16 scene factories of template/scene.h:791-1209 exist as data in scenes.py (two share a
+    definition), each buildable by any implementation of the builder protocol and writable as a scene file."""
+    assert len(scenes.REFERENCE_FACTORIES) == 16
+    assert set(scenes.REFERENCE_FACTORIES.values()) <= set(scenes.REGISTRY)
+    assert len(set(scenes.REFERENCE_FACTORIES.values())) == 15
+
+
 @pytest.mark.parametrize("name,kw", [("background", {}), ("mixed_small", {"split": 3}), ("scene3", {"force_diffuse": False}),
-                                     ("tlas_test2", {}), ("pretty_tlas", {"n_instances": 4}), ("tower", {})])
+                                     ("tlas_test2", {}), ("pretty_tlas", {"n_instances": 4}), ("tower", {}),
+                                     ("tlas_test", {}), ("scene1", {}), ("scene2", {}), ("scene6", {}), ("scene7", {"nx": 20, "ny": 20})])
 def test_scene_file_round_trip(name, kw, tmp_path, scenes, host_api):
     """A scene recorded as a 'rapt-scene 1' file and loaded with Scene::LoadFile builds the same
     acceleration structures and flattens to the same primitives as the scene built through the API."""
@@ -139,7 +151,8 @@ def test_scene_file_round_trip(name, kw, tmp_path, scenes, host_api):
         assert np.array_equal(np.delete(A["nodes"], 1, axis=0), np.delete(B["nodes"], 1, axis=0))
     if d["tlas"]:
         assert np.array_equal(a.tlas_dump(), b.tlas_dump())
-    for m in range(2 if name in ("background", "pretty_tlas") else 1):
+    assert a.n_meshes() == b.n_meshes()
+    for m in range(a.n_meshes()):
         (ta, ia), (tb, ib) = a.mesh_tris(m), b.mesh_tris(m)
         assert np.array_equal(ia, ib) and np.array_equal(ta.view(np.uint32), tb.view(np.uint32))
     assert b.describe()
