@@ -272,7 +272,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 {
 	static_assert(!WIDE || (ANY && !COUNT && !MIXED), "the wide walk is exact for any-hit queries only");
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
-	const int refillMin = tuning & 0xFF, stepMin = (tuning >> 8) & 0xFF, pairAgain = (tuning >> 20) & 0x7F;
+	const int refillMin = tuning & 0xFF, stepMinBusy = (tuning >> 8) & 0xFF, pairAgainBusy = (tuning >> 20) & 0x7F;
 	const uint lane = threadIdx.x & 63;
 	const unsigned long long below = (1ull << lane) - 1;
 	// sub-queue h = [h * subLen, (h + 1) * subLen) cut at n; all of this is wave-uniform (SGPRs)
@@ -401,6 +401,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		// an entry or an exit), so an iteration repeats the pair step while at least pairAgain lanes still
 		// want one: the bookkeeping around the steps is paid once for up to RT_PAIR_REPEAT pair steps,
 		// and the rarer kinds find more lanes waiting when their turn comes.
+		// Once the queue is dry no new lane will ever join a postponed kind: waiting for company only stretches the
+		// dependent chains of the last rays (the drain of the launch), so every wanted kind runs in every iteration.
+		const int stepMin = exhausted ? 1 : stepMinBusy, pairAgain = exhausted ? 1 : pairAgainBusy;
 #pragma unroll
 		for (int rep = 0; rep < RT_PAIR_REPEAT; rep++) {
 			const uint lk = link;
