@@ -240,6 +240,9 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #define RT_LINK_EXIT 0xFFFFFFFCu // leave the current instance (the sentinel was popped)
 #define RT_LINK_DONE 0xFFFFFFFBu // this ray is finished; its result is written at the next refill
 #define RT_CHUNK 256 // queue entries a wave reserves per atomic on a work head (upper bound)
+#ifndef RT_CHUNK_MIN
+#define RT_CHUNK_MIN 64 // ... and the lower bound, near the end of a sub-queue (a power of two)
+#endif
 // Work distribution.  Same-address atomics retire at ~88 per microsecond on this part, so ONE work head
 // shared by 7000 waves is a real cost: a wave waits in line for every reservation, and large chunks (the
 // obvious cure) leave a long tail, because the wave that takes the last 256 rays works on them for
@@ -283,7 +286,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	int home = waveId % RT_HEADS;   // sub-queue this wave is drawing from
 	int tried = 0;                  // sub-queues found empty since the last successful reservation
 	int chunk = subLen / (wavesPerHead * 2); // size of the next reservation
-	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= 64 ? 64 : (chunk & ~63));
+	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= RT_CHUNK_MIN ? RT_CHUNK_MIN : (chunk & ~(RT_CHUNK_MIN - 1)));
 	Stack st = make_stack(ldsStack, spill, overflow);
 #ifdef RT_TAIL_PROBE
 	if ((threadIdx.x & 63) == 0) atomicMin(&g_tailProbe[0], __builtin_amdgcn_s_memrealtime());
@@ -341,12 +344,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 							chunkNext = lo + base, chunkEnd = chunkNext + chunk < hi ? chunkNext + chunk : hi;
 							// the next reservation: a share of what is left in this sub-queue
 							int next = (hi - chunkEnd) / (wavesPerHead * 2);
-							chunk = next >= RT_CHUNK ? RT_CHUNK : (next <= 64 ? 64 : (next & ~63));
+							chunk = next >= RT_CHUNK ? RT_CHUNK : (next <= RT_CHUNK_MIN ? RT_CHUNK_MIN : (next & ~(RT_CHUNK_MIN - 1)));
 							tried = 0;
 						} else {
 							// this sub-queue is empty: help with the next one, in small pieces
 							home = home + 1 == RT_HEADS ? 0 : home + 1;
-							chunk = 64;
+							chunk = RT_CHUNK_MIN;
 							if (++tried == RT_HEADS_PROBE) exhausted = true;
 						}
 					}
