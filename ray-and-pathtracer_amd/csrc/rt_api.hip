@@ -1087,7 +1087,8 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 // round: one work list for k_traverse (rt_kernels.h), one drain per round instead of two (a persistent traversal
 // launch ends several hundred microseconds after its queue ran dry, whatever the queue held).  light(r) runs after
 // it and still needs the hit of round r while the launch writes the hits of round r + 1: hitN / hitId are double
-// buffered by round parity like the rays.  Measured (1080p): 8 spp batch 11.3 -> 10.2 ms, 64 spp batch 60.1 -> 60.7
+// buffered by round parity like the rays.  Measured (1080p): 8 spp batch 11.3 -> 10.2 ms (10.3 -> 9.7 with the drain
+// change of trace_persistent), 16 spp 17.5 -> 17.1, 32 spp 31.8 -> 31.9, 64 spp batch 60.1 -> 60.7
 // (in full waves the mixed nearest / any-hit lanes cost more than the drains), so it is used for batches under
 // RT_FUSE_MAX samples -- the per-GPU share of a multi-GPU frame.  Not used by counting launches (their tallies are
 // kept per kind of query).
