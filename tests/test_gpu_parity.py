@@ -611,9 +611,9 @@ def test_cpp_host_example(tmp_path, scenes, oracle_api, host_api):
     scenes.mixed_small(w)
     o = oracle_api.OracleScene()
     scenes.mixed_small(o)
-    for mode, frames in (("whitted", 1), ("path", 3)):
+    for mode, frames, devs in (("whitted", 1, None), ("path", 3, None), ("path", 3, "0,0")):
         out = str(tmp_path / (mode + ".ppm"))
-        subprocess.check_call([exe, scene_path, out, "48", "32", mode, str(frames)])
+        subprocess.check_call([exe, scene_path, out, "48", "32", mode, str(frames)] + ([devs] if devs else []))  # "0,0": two contexts on device 0
         raw = open(out, "rb").read()
         px = np.frombuffer(raw[raw.index(b"255\n") + 4:], dtype=np.uint8).reshape(32, 48, 3)
         o.set_raytracer(mode == "whitted")
