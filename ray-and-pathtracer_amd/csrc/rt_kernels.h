@@ -403,6 +403,26 @@ __global__ void k_round_begin(Queues Q, int poolFollowsEnded, int allActive, int
 		for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
 }
 
+// Path state is streamed (each element read or written once per launch) while the scene -- a few MB -- has to stay in
+// the 4 MB L2 of every XCD: a traversal step waits for the slowest of its lanes, and with ~35 lanes per step one L2 miss
+// among them is the rule once streaming has pushed scene lines out.  The traversal kernels therefore mark their
+// path-state accesses non-temporal (nt: no retention priority in L2).  RT_NO_NT: measurement builds without the hint.
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef int nt_i2 __attribute__((ext_vector_type(2)));
+#ifdef RT_NT_LOADS
+__device__ __forceinline__ float4 ld_stream(const float4* p) { const nt_f4 v = __builtin_nontemporal_load((const nt_f4*)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint ld_stream(const uint* p) { return __builtin_nontemporal_load(p); }
+#else
+template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return *p; }
+#endif
+#ifdef RT_NT_STORES
+__device__ __forceinline__ void st_stream(float4* p, const float4& v) { nt_f4 t; t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w; __builtin_nontemporal_store(t, (nt_f4*)p); }
+__device__ __forceinline__ void st_stream(int2* p, const int2& v) { nt_i2 t; t.x = v.x, t.y = v.y; __builtin_nontemporal_store(t, (nt_i2*)p); }
+__device__ __forceinline__ void st_stream(unsigned char* p, unsigned char v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ __forceinline__ void st_stream(T* p, const T& v) { *p = v; }
+#endif
+
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
 // (renderer.cpp:24, :131); it applies to lights and brute-force primitives, the BVH uses 0.0001.
 template <bool DENSE> // DENSE: every slot is active and the queue is the identity (round 0 with a slot per sample)
@@ -414,9 +434,9 @@ struct ExtendPolicy {
 	int* flag;
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
 	{
-		const int slot = DENSE ? work : (int)queue[work];
+		const int slot = DENSE ? work : (int)ld_stream(queue + work);
 		RT_CHECK(slot >= 0 && slot < P.nSlots, 10, flag);
-		const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot];
+		const float4 o4 = ld_stream(P.O[parity] + slot), d4 = ld_stream(P.D[parity] + slot);
 		O = xyz(o4), D = xyz(d4), tmax = o4.w; // o4.w: ray.t after the head tests made when the ray was created
 		unpack_head(__float_as_uint(d4.w), head);
 		return true;
@@ -424,20 +444,20 @@ struct ExtendPolicy {
 	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
 	{
 		// the ray in registers may be the object-space one; the sphere normal needs the world ray
-		const int slot = DENSE ? work : (int)queue[work];
+		const int slot = DENSE ? work : (int)ld_stream(queue + work);
 		int objIdx, mat;
 		f3 normal;
 		const PathState& Pc = P;
 		const int par = parity;
-		resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = xyz(Pc.O[par][slot]), d = xyz(Pc.D[par][slot]); }, objIdx, mat, normal);
-		P.hitN[parity][slot] = mk4(normal, hit.t);
-		P.hitId[parity][slot] = make_int2(objIdx, mat);
+		resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = xyz(ld_stream(Pc.O[par] + slot)), d = xyz(ld_stream(Pc.D[par] + slot)); }, objIdx, mat, normal);
+		st_stream(P.hitN[parity] + slot, mk4(normal, hit.t));
+		st_stream(P.hitId[parity] + slot, make_int2(objIdx, mat));
 	}
 };
 template <bool COUNT, bool DENSE>
 __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, int refillMin, uint* spill, DCounters* counters)
 {
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	__shared__ uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -587,10 +607,10 @@ struct ConnectPolicy {
 	int* flag;
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef&) const
 	{
-		const int slot = (int)queue[work / nLights], li = work % nLights;
+		const int slot = (int)ld_stream(queue + work / nLights), li = work % nLights;
 		RT_CHECK(slot >= 0 && slot < P.nSlots && li >= 0 && li < nLights, 11, flag);
-		const f3 I = xyz(P.hitP[slot]); // O + t * D, as shade computed it
-		const f3 pickedPos = xyz(P.sh[(size_t)li * P.nSlots + slot]);
+		const f3 I = xyz(ld_stream(P.hitP + slot)); // O + t * D, as shade computed it
+		const f3 pickedPos = xyz(ld_stream(P.sh + ((size_t)li * P.nSlots + slot)));
 		f3 lightRayDirection = pickedPos - I;
 		const float len2 = dot(lightRayDirection, lightRayDirection);
 		lightRayDirection = normalize(lightRayDirection);
@@ -599,8 +619,8 @@ struct ConnectPolicy {
 	}
 	__device__ __forceinline__ void store(int work, bool occluded) const
 	{
-		const int slot = (int)queue[work / nLights], li = work % nLights;
-		P.vis[(size_t)li * P.nSlots + slot] = occluded ? 1 : 0;
+		const int slot = (int)ld_stream(queue + work / nLights), li = work % nLights;
+		st_stream(P.vis + ((size_t)li * P.nSlots + slot), (unsigned char)(occluded ? 1 : 0));
 	}
 	uint* leftoverList; int* leftoverCount;
 	__device__ __forceinline__ void leftover(int work) const { leftoverList[atomicAdd(leftoverCount, 1)] = (uint)work; }
@@ -620,7 +640,7 @@ struct ListedPolicy {
 template <bool COUNT, bool WIDE = false, bool LISTED = false>
 __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S, PathState P, Queues Q, int parity, int refillMin, uint* spill, DCounters* counters)
 {
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	__shared__ uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -654,7 +674,7 @@ struct TraversePolicy {
 #endif
 __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse(DScene S, PathState P, Queues Q, int parityExtend, float t_min, int refillMin, uint* spill)
 {
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	__shared__ uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -988,7 +1008,7 @@ template <bool COUNT, bool HEAD = true>
 __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, const float* O3, const float* D3, const float* tmax, float t_min, int refillMin,
                                                             QueryHit* out, uint* spill, int* work, DCounters* counters)
 {
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	__shared__ uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -1002,7 +1022,7 @@ template <bool COUNT, bool WIDE = false, bool LISTED = false>
 __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax, int refillMin,
                                                              unsigned char* out, uint* spill, int* work, DCounters* counters, uint* leftover)
 {
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	__shared__ uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -1018,7 +1038,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, co
 template <bool COUNT>
 __global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, float t_min, int refillMin, int* objOut, float* tOut, uint* spill, int* work, DCounters* counters)
 {
-	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	__shared__ uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;

@@ -62,6 +62,8 @@ namespace rtd {
 
 #define RT_BLOCK 256
 #define RT_STACK_LDS 16   // stack entries per lane held in LDS
+#define RT_LDS_WORDS ((RT_STACK_LDS + 6) * RT_BLOCK) // a traversal block's LDS: the stack rows, then six rows for the world-space
+                                                     // ray of a lane that is inside an instance (trace_persistent)
 #define RT_STACK_MAX 130  // tlas::Intersect's stack[64] (tlas.cpp:67) + the instance sentinel + bvh::BIntersect's own stack[64]
                           // (bvh.cpp:608) live on ONE stack here; whatever the reference can traverse fits
 
@@ -124,9 +126,14 @@ struct LaneCounters {
 // Per-lane traversal stack: entries [0, RT_STACK_LDS) live in LDS laid out [entry][lane] (one
 // bank per lane, conflict free), deeper entries spill to a per-lane column of a global buffer
 // laid out [entry][global lane].  Depth is capped at the reference's 64.
+// The two halves are typed by address space: with generic pointers the compiler folds "LDS or spill" into ONE
+// flat_load / flat_store on a selected address, and a flat access takes the vector-memory path (the traversal's
+// co-limit) even when it lands in LDS.  Typed, a pop is a ds_read_b32 and the spill a rare branch.
+typedef __attribute__((address_space(3))) uint lds_uint;
+typedef __attribute__((address_space(1))) uint glb_uint;
 struct Stack {
-	uint* lds;        // &ldsStack[0][threadIdx.x]
-	uint* spill;      // &spill[0][global lane]
+	lds_uint* lds;    // &ldsStack[0][threadIdx.x]
+	glb_uint* spill;  // &spill[0][global lane]
 	uint spillStride; // lanes in the grid
 	uint sp;
 	int* overflow;
@@ -142,16 +149,17 @@ struct Stack {
 	{
 		RT_CHECK(sp >= 1 && sp <= RT_STACK_MAX, 2, overflow);
 		sp--;
-		return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : spill[(size_t)(sp - RT_STACK_LDS) * spillStride];
+		if (sp < RT_STACK_LDS) return lds[sp * RT_BLOCK];
+		return spill[(size_t)(sp - RT_STACK_LDS) * spillStride];
 	}
 };
 
 __device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* overflow)
 {
 	Stack st;
-	st.lds = ldsBase + threadIdx.x;
+	st.lds = (lds_uint*)ldsBase + threadIdx.x;
 	st.spillStride = gridDim.x * blockDim.x;
-	st.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	st.spill = (glb_uint*)spill + (blockIdx.x * blockDim.x + threadIdx.x);
 	st.sp = 0;
 	st.overflow = overflow;
 	return st;
@@ -288,6 +296,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	int chunk = subLen / (wavesPerHead * 2); // size of the next reservation
 	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= RT_CHUNK_MIN ? RT_CHUNK_MIN : (chunk & ~(RT_CHUNK_MIN - 1)));
 	Stack st = make_stack(ldsStack, spill, overflow);
+	// the world-space ray while the lane walks a BLAS: rows [RT_STACK_LDS, RT_STACK_LDS + 6) of the block's LDS, [row][lane]
+	lds_uint* const worldRay = (lds_uint*)ldsStack + RT_STACK_LDS * RT_BLOCK + threadIdx.x;
 #ifdef RT_TAIL_PROBE
 	if ((threadIdx.x & 63) == 0) atomicMin(&g_tailProbe[0], __builtin_amdgcn_s_memrealtime());
 	bool probed = false;
@@ -533,6 +543,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			RT_CHECK(S.useTLAS && inst >= 0 && inst < 256, 5, overflow);
 			if (COUNT) lc.inst++;
 			const DInstance* I = S.inst + inst;
+			worldRay[0 * RT_BLOCK] = __float_as_uint(O.x), worldRay[1 * RT_BLOCK] = __float_as_uint(O.y), worldRay[2 * RT_BLOCK] = __float_as_uint(O.z);
+			worldRay[3 * RT_BLOCK] = __float_as_uint(D.x), worldRay[4 * RT_BLOCK] = __float_as_uint(D.y), worldRay[5 * RT_BLOCK] = __float_as_uint(D.z);
 			const f3 Oo = xform_pos(I->invT, O);
 			const f3 Do = xform_vec(I->invT, D);
 			O = Oo, D = Do, rD = rcp3(Do);
@@ -543,10 +555,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			if constexpr (WIDE) { if (!clean) { pol.leftover(work); work = -1; link = RT_LINK_DONE; } } // not clean in object space: the binary walk redoes this ray
 		}
 		if (runExit && wantExit) {
-			// back to world space (the backup ray of bvhInstance.cpp:6, :20), then the next TLAS entry
-			float tmaxUnused;
-			HitRef headUnused;
-			pol.load(work, O, D, tmaxUnused, headUnused);
+			// back to world space (the backup ray of bvhInstance.cpp:6, :20), then the next TLAS entry.  The backup is in
+			// LDS: fetching the ray again from the path state cost two HBM round trips per exit -- a random slot each
+			// time, 0.75 exits per ray -- which was most of this kernel's HBM traffic, and the whole wave waited for them.
+			O = f3(__uint_as_float(worldRay[0 * RT_BLOCK]), __uint_as_float(worldRay[1 * RT_BLOCK]), __uint_as_float(worldRay[2 * RT_BLOCK]));
+			D = f3(__uint_as_float(worldRay[3 * RT_BLOCK]), __uint_as_float(worldRay[4 * RT_BLOCK]), __uint_as_float(worldRay[5 * RT_BLOCK]));
 			rD = rcp3(D);
 			clean = ray_is_clean(O, D, rD);
 			inst = -1;
