@@ -161,6 +161,26 @@ static void tail_probe_print(hipStream_t st, const char* what, int round)
 }
 #endif
 
+#ifdef RT_SECTION_PROBE
+// measurement build only: per traversal launch of the plain round loop, the waves' cycles by section (rt_scene_dev.h)
+static void section_probe_reset(hipStream_t st)
+{
+	const unsigned long long zero[16] = { 0 };
+	(void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sectionProbe), zero, sizeof(zero), 0, hipMemcpyHostToDevice, st);
+}
+static void section_probe_print(hipStream_t st, const char* what, int round)
+{
+	unsigned long long v[16];
+	(void)hipStreamSynchronize(st);
+	(void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_sectionProbe), sizeof(v), 0, hipMemcpyDeviceToHost);
+	const double tot = (double)v[7] > 0 ? (double)v[7] : 1;
+	fprintf(stderr, "section probe %s round %d: refill %.1f%% (%llu, %.0f cyc)  pair wait %.1f%% rest %.1f%% (%llu steps, %.0f + %.0f cyc)  leaf wait %.1f%% rest %.1f%% (%llu, %.0f + %.0f)  enter %.1f%% (%llu, %.0f)  exit %.1f%% (%llu, %.0f)  other %.1f%%  iterations %llu (%.0f cyc)\n",
+	        what, round, 100 * v[0] / tot, v[13], v[13] ? (double)v[0] / v[13] : 0, 100 * v[1] / tot, 100 * v[2] / tot, v[9], v[9] ? (double)v[1] / v[9] : 0, v[9] ? (double)v[2] / v[9] : 0,
+	        100 * v[3] / tot, 100 * v[4] / tot, v[10], v[10] ? (double)v[3] / v[10] : 0, v[10] ? (double)v[4] / v[10] : 0, 100 * v[5] / tot, v[11], v[11] ? (double)v[5] / v[11] : 0,
+	        100 * v[6] / tot, v[12], v[12] ? (double)v[6] / v[12] : 0, 100 * (tot - v[0] - v[1] - v[2] - v[3] - v[4] - v[5] - v[6]) / tot, v[8], v[8] ? tot / v[8] : 0);
+}
+#endif
+
 extern "C" {
 
 int rt_device_count(void)
@@ -681,6 +701,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		S.tlasBase = tlasBase;
 		S.reachOriginMax = (float)originMax;
 		S.tlasPairs = (int)tlasSlots.size();
+		S.nInst = (int)d->n_instances;
+		S.tlasLds = S.tlasPairs * 28 + S.nInst * 16 <= RT_TLAS_LDS_WORDS ? 1 : 0;
+		if (getenv("RT_TLAS_LDS")) S.tlasLds = S.tlasLds && atoi(getenv("RT_TLAS_LDS")) != 0;
 	}
 	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);
 	for (uint i = 0; i < d->n_lights; i++) {
@@ -1017,6 +1040,9 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 #ifdef RT_TAIL_PROBE
 			tail_probe_reset(st);
 #endif
+#ifdef RT_SECTION_PROBE
+			section_probe_reset(st);
+#endif
 			prof_begin(c, K_EXTEND, st);
 			{
 				auto extendKernel = c->counting ? (allActive ? k_extend<true, true> : k_extend<true, false>) : (allActive ? k_extend<false, true> : k_extend<false, false>);
@@ -1026,6 +1052,9 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 #ifdef RT_TAIL_PROBE
 			tail_probe_print(st, "extend", round);
 #endif
+#ifdef RT_SECTION_PROBE
+			section_probe_print(st, "extend", round);
+#endif
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity, round == 0 && Rs[k].finishInline ? 1 : 0);
 			prof_end(c, st);
@@ -1033,11 +1062,17 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 #ifdef RT_TAIL_PROBE
 			tail_probe_reset(st);
 #endif
+#ifdef RT_SECTION_PROBE
+			section_probe_reset(st);
+#endif
 			prof_begin(c, K_CONNECT, st);
 			launch_connect(c, st, P[k], Q, parity, pl.spill);
 			prof_end(c, st);
 #ifdef RT_TAIL_PROBE
 			tail_probe_print(st, "connect", round);
+#endif
+#ifdef RT_SECTION_PROBE
+			section_probe_print(st, "connect", round);
 #endif
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
@@ -1411,7 +1446,7 @@ static int scoped_scene(rt_ctx* c, int scope, int index, DScene& S, const char* 
 	if (scope == RT_SCOPE_SCENE || scope == RT_SCOPE_ACCEL) return RT_OK;
 	if (scope == RT_SCOPE_BLAS) {
 		if (index < 0 || index >= (int)c->blasRoot.size()) return fail(c, RT_E_ARG, "%s: blas %d of %d", who, index, (int)c->blasRoot.size());
-		S.useTLAS = 0, S.rootLink = c->blasRoot[(size_t)index], S.rootWide = c->blasRootWide[(size_t)index], S.nBruteSph = S.nBrutePla = 0;
+		S.useTLAS = 0, S.tlasLds = 0, S.rootLink = c->blasRoot[(size_t)index], S.rootWide = c->blasRootWide[(size_t)index], S.nBruteSph = S.nBrutePla = 0;
 		return RT_OK;
 	}
 	if (scope == RT_SCOPE_INSTANCE) {

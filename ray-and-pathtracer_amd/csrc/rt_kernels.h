@@ -457,7 +457,7 @@ struct ExtendPolicy {
 template <bool COUNT, bool DENSE>
 __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, int refillMin, uint* spill, DCounters* counters)
 {
-	__shared__ uint ldsStack[RT_LDS_WORDS];
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -640,7 +640,7 @@ struct ListedPolicy {
 template <bool COUNT, bool WIDE = false, bool LISTED = false>
 __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S, PathState P, Queues Q, int parity, int refillMin, uint* spill, DCounters* counters)
 {
-	__shared__ uint ldsStack[RT_LDS_WORDS];
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -674,7 +674,7 @@ struct TraversePolicy {
 #endif
 __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse(DScene S, PathState P, Queues Q, int parityExtend, float t_min, int refillMin, uint* spill)
 {
-	__shared__ uint ldsStack[RT_LDS_WORDS];
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -1008,7 +1008,7 @@ template <bool COUNT, bool HEAD = true>
 __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, const float* O3, const float* D3, const float* tmax, float t_min, int refillMin,
                                                             QueryHit* out, uint* spill, int* work, DCounters* counters)
 {
-	__shared__ uint ldsStack[RT_LDS_WORDS];
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -1022,7 +1022,7 @@ template <bool COUNT, bool WIDE = false, bool LISTED = false>
 __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax, int refillMin,
                                                              unsigned char* out, uint* spill, int* work, DCounters* counters, uint* leftover)
 {
-	__shared__ uint ldsStack[RT_LDS_WORDS];
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
@@ -1038,7 +1038,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, co
 template <bool COUNT>
 __global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, float t_min, int refillMin, int* objOut, float* tOut, uint* spill, int* work, DCounters* counters)
 {
-	__shared__ uint ldsStack[RT_LDS_WORDS];
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;

@@ -61,9 +61,10 @@ namespace rtd {
 #define RT_MAX_LIGHTS 8
 
 #define RT_BLOCK 256
-#define RT_STACK_LDS 16   // stack entries per lane held in LDS
-#define RT_LDS_WORDS ((RT_STACK_LDS + 6) * RT_BLOCK) // a traversal block's LDS: the stack rows, then six rows for the world-space
-                                                     // ray of a lane that is inside an instance (trace_persistent)
+#define RT_STACK_LDS 15   // stack entries per lane held in LDS
+#define RT_TLAS_LDS_WORDS 352 // a block's copy of a small TLAS: per pair 16 (boxes + links) + 12 (reach) dwords, per instance 16
+#define RT_LDS_ROWS ((RT_STACK_LDS + 6) * RT_BLOCK)  // the stack rows, then six rows for the world-space ray of a lane that is inside an instance
+#define RT_LDS_WORDS (RT_LDS_ROWS + RT_TLAS_LDS_WORDS) // a traversal block's LDS (trace_persistent): 22,912 bytes, seven blocks per CU
 #define RT_STACK_MAX 130  // tlas::Intersect's stack[64] (tlas.cpp:67) + the instance sentinel + bvh::BIntersect's own stack[64]
                           // (bvh.cpp:608) live on ONE stack here; whatever the reference can traverse fits
 
@@ -109,6 +110,8 @@ struct DScene {
 	uint tlasBase; // pair index of the first TLAS record
 	float reachOriginMax; // reach[] boxes are inflated for world ray origins with |O|_1 up to this
 	int tlasPairs; // number of TLAS pair records
+	int nInst;     // instances
+	int tlasLds;   // the TLAS (pairs, reach records, instance transforms) fits RT_TLAS_LDS_WORDS: every traversal block walks its own LDS copy
 	int useTLAS;
 	int nBruteSph, nBrutePla;
 	int nLights;
@@ -130,6 +133,9 @@ struct LaneCounters {
 // flat_load / flat_store on a selected address, and a flat access takes the vector-memory path (the traversal's
 // co-limit) even when it lands in LDS.  Typed, a pop is a ds_read_b32 and the spill a rare branch.
 typedef __attribute__((address_space(3))) uint lds_uint;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+__device__ __forceinline__ float4 ld_lds(const lds_v4f* p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 typedef __attribute__((address_space(1))) uint glb_uint;
 struct Stack {
 	lds_uint* lds;    // &ldsStack[0][threadIdx.x]
@@ -274,6 +280,25 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // [0] first wave in, [1] first wave that finds every sub-queue empty, [2] last wave out (s_memrealtime, 100 MHz)
 __device__ unsigned long long g_tailProbe[4];
 #endif
+#ifdef RT_SECTION_PROBE
+// measurement build: where do a traversal wave's cycles go?  Shader-clock cycles per section, summed over all waves:
+// [0] flush + refill  [1] pair: loads issued -> data there  [2] pair: arithmetic + stack  [3] leaf: wait  [4] leaf: rest
+// [5] enter  [6] exit  [7] whole loop; step counts: [8] iterations [9] pair [10] leaf [11] enter [12] exit [13] refills
+__device__ unsigned long long g_sectionProbe[16];
+// (the clock is wave-uniform; the sums live in LDS, one set per wave, added to by the first enabled lane, so that probe
+// points inside divergent code cost no vector registers)
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+#define RT_SEC_NOW() __builtin_readcyclecounter()
+#define RT_SEC_PUT(k, v) do { const unsigned long long secV = (v); if ((__ballot(true) & below) == 0) secAcc[k] += secV; } while (0)
+#define RT_SEC_ADD(k, t0) RT_SEC_PUT(k, __builtin_readcyclecounter() - (t0))
+#define RT_SEC_COUNT(k) RT_SEC_PUT(k, 1ull)
+#define RT_SEC_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define RT_SEC_NOW() 0ull
+#define RT_SEC_ADD(k, t0) ((void)(t0))
+#define RT_SEC_COUNT(k) ((void)0)
+#define RT_SEC_WAIT() ((void)0)
+#endif
 // WIDE == true (occlusion queries only, never counting launches): inside a BLAS / the scene BVH the walk uses the
 // 4-wide nodes (wide[], see the layout notes above); a ray that is not clean is given back through
 // pol.leftover(work) for the binary walk.  The TLAS level keeps its pair records and reach test.
@@ -298,9 +323,31 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	Stack st = make_stack(ldsStack, spill, overflow);
 	// the world-space ray while the lane walks a BLAS: rows [RT_STACK_LDS, RT_STACK_LDS + 6) of the block's LDS, [row][lane]
 	lds_uint* const worldRay = (lds_uint*)ldsStack + RT_STACK_LDS * RT_BLOCK + threadIdx.x;
+	// A small TLAS is walked in LDS.  The traversal is bound by the vector-memory path (lane accesses through the
+	// texture addresser and L1); a TLAS visit is seven of them (pair + reach record) and an
+	// instance entry four, together a quarter of all accesses on the bench scene; ds_read takes another pipe.
+	// Layout: [pair][4] | [pair][3] reach | [instance][4] = invT rows 0-2, {rootLink, rootWide, -, -}
+	lds_v4f* const tlasL = (lds_v4f*)((lds_uint*)ldsStack + RT_LDS_ROWS);
+	if (S.tlasLds) {
+		const int nP = S.tlasPairs * 4, nR = S.tlasPairs * 3, nI = S.nInst * 4;
+		for (int i = (int)threadIdx.x; i < nP + nR + nI; i += RT_BLOCK) {
+			v4f v;
+			if (i < nP) v = ((const v4f*)S.pairs)[4 * (size_t)S.tlasBase + i];
+			else if (i < nP + nR) v = ((const v4f*)S.reach)[i - nP];
+			else { const int k = i - nP - nR; v = ((const v4f*)S.inst)[(size_t)(k >> 2) * 8 + ((k & 3) == 3 ? 6 : (k & 3))]; }
+			tlasL[i] = v;
+		}
+		__syncthreads();
+	}
 #ifdef RT_TAIL_PROBE
 	if ((threadIdx.x & 63) == 0) atomicMin(&g_tailProbe[0], __builtin_amdgcn_s_memrealtime());
 	bool probed = false;
+#endif
+#ifdef RT_SECTION_PROBE
+	__shared__ unsigned long long secLds[(RT_BLOCK / 64) * 16];
+	lds_u64* const secAcc = (lds_u64*)secLds + (threadIdx.x >> 6) * 16;
+	if (lane < 16) secAcc[lane] = 0;
+	const unsigned long long secStart = RT_SEC_NOW();
 #endif
 	int work = -1;           // queue entry this lane is tracing, -1 = idle
 	int chunkNext = 0, chunkEnd = 0; // wave-uniform: reserved, not yet handed out
@@ -329,9 +376,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		const bool idle = work < 0;
 		const bool doneLane = work >= 0 && link == RT_LINK_DONE;
 		const unsigned long long freeMask = __ballot(idle || doneLane);
+		RT_SEC_COUNT(8);
 		if (freeMask != 0) {
 			const int cnt = __popcll(freeMask);
 			if (cnt >= refillMin || freeMask == ~0ull) {
+				const unsigned long long secT = RT_SEC_NOW();
+				RT_SEC_COUNT(13);
 				if (doneLane) {
 					RT_CHECK(work >= 0 && work < n && st.sp <= RT_STACK_MAX, 4, overflow);
 					// results are written here, many lanes at a time, not one lane per iteration
@@ -387,6 +437,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 						chunkNext += cnt < avail ? cnt : avail;
 					}
 				}
+				RT_SEC_WAIT();
+				RT_SEC_ADD(0, secT);
 			}
 		}
 #ifdef RT_TAIL_PROBE
@@ -400,6 +452,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #endif
 #ifdef RT_EXPERIMENT_EXTRA_LOADS
 				if (xdummy == 0x7fc12345u && n < 0) *overflow = 3; // keeps the register allocated to the loads
+#endif
+#ifdef RT_SECTION_PROBE
+				if (lane == 0) secAcc[7] = RT_SEC_NOW() - secStart;
+				if (lane < 14) atomicAdd(&g_sectionProbe[lane], (unsigned long long)secAcc[lane]);
 #endif
 				break;
 			}
@@ -464,21 +520,62 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 					if (have) link = next; else pop_next();
 					continue;
 				}
-				const float4* p = S.pairs + 4 * (size_t)lk;
-				const float4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+				const unsigned long long secT = RT_SEC_NOW();
+				RT_SEC_COUNT(9);
+				// TLAS level: the reach record of the pair (see reach[] above) is fetched in the same round trip as the pair
+				// itself (nearly every pair step has a TLAS lane or two among its ~35)
+				const bool useReach = (!COUNT || (tuning & RT_TUNE_CULL_COUNTED)) && atTlas && clean && fabsf(O.x) + fabsf(O.y) + fabsf(O.z) <= S.reachOriginMax;
+				float4 a0, a1, b0, b1, r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+				if (S.tlasLds && atTlas) {
+					const uint tp = lk - S.tlasBase;
+					const lds_v4f* q = tlasL + 4 * tp;
+					a0 = ld_lds(q), a1 = ld_lds(q + 1), b0 = ld_lds(q + 2), b1 = ld_lds(q + 3);
+					if (useReach) {
+						const lds_v4f* qr = tlasL + 4 * S.tlasPairs + 3 * tp;
+						r0 = ld_lds(qr), r1 = ld_lds(qr + 1), r2 = ld_lds(qr + 2);
+					}
+				} else {
+					const float4* p = S.pairs + 4 * (size_t)lk;
+					a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
+					if (useReach) {
+						const float4* q = S.reach + 3 * (size_t)(lk - S.tlasBase);
+						r0 = q[0], r1 = q[1], r2 = q[2];
+					}
+				}
+				RT_SEC_WAIT();
+				RT_SEC_ADD(1, secT);
+				const unsigned long long secT2 = RT_SEC_NOW();
 #ifdef RT_EXPERIMENT_EXTRA_LOADS
-				// measurement only: N more loads of the record just fetched (L1 hits, nobody waits for them): does the
+				// measurement only: N more loads of a pair record (L1 hits, nobody waits for them): does the
 				// vector-memory path limit this kernel?
-				for (int xl = 0; xl < RT_EXPERIMENT_EXTRA_LOADS; xl++) asm volatile("global_load_dword %0, %1, off offset:%2" : "+v"(xdummy) : "v"(p), "i"(4 * (xl & 15)));
+				{
+					const float4* xp = S.pairs + 4 * (size_t)(S.tlasLds && atTlas ? 0u : lk);
+					for (int xl = 0; xl < RT_EXPERIMENT_EXTRA_LOADS; xl++) asm volatile("global_load_dword %0, %1, off offset:%2" : "+v"(xdummy) : "v"(xp), "i"(4 * (xl & 15)));
+				}
+#endif
+#ifdef RT_EXPERIMENT_EXTRA_VALU
+				// measurement only: N more independent VALU instructions per pair step: is the vector ALU the limiter?
+				{
+					float xv0 = rayT, xv1 = O.x, xv2 = O.y, xv3 = O.z;
+					for (int xl = 0; xl < RT_EXPERIMENT_EXTRA_VALU / 4; xl++)
+						asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(xv0), "+v"(xv1), "+v"(xv2), "+v"(xv3));
+					if (xv0 + xv1 + xv2 + xv3 == 123.456f && n < 0) *overflow = 3;
+				}
+#endif
+#ifdef RT_EXPERIMENT_EXTRA_SALU
+				// measurement only: N more scalar instructions per pair step
+				{
+					int xs = n;
+					for (int xl = 0; xl < RT_EXPERIMENT_EXTRA_SALU; xl++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(xs));
+					if (xs == 0x7fffffff && n < 0) *overflow = 3;
+				}
 #endif
 				float dist1, dist2;
 				if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
 				else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
 				uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
-				if ((!COUNT || (tuning & RT_TUNE_CULL_COUNTED)) && atTlas && clean && fabsf(O.x) + fabsf(O.y) + fabsf(O.z) <= S.reachOriginMax) {
-					// TLAS level: drop children whose geometry the ray cannot reach (see reach[] above)
-					const float4* q = S.reach + 3 * (size_t)(lk - S.tlasBase);
-					const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+				if (useReach) {
+					// drop children whose geometry the ray cannot reach
 					if (!box_reachable(O, rD, rayT, xyz(r0), f3(r0.w, r1.x, r1.y))) dist1 = 1e30f;
 					if (!box_reachable(O, rD, rayT, f3(r1.z, r1.w, r2.x), f3(r2.y, r2.z, r2.w))) dist2 = 1e30f;
 				}
@@ -488,6 +585,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 					link = c1;
 					if (dist2 != 1e30f) st.push(c2);
 				}
+				RT_SEC_WAIT();
+				RT_SEC_ADD(2, secT2);
 			}
 		}
 		// the other kinds, on the links as they are now
@@ -517,7 +616,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			// one go (nearly every record is a triangle)
 			const uint slot = lk & ~RT_LEAF_BIT;
 			const float4* rec = S.prims + 4 * (size_t)slot;
+			const unsigned long long secT = RT_SEC_NOW();
+			RT_SEC_COUNT(10);
 			const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+			RT_SEC_WAIT();
+			RT_SEC_ADD(3, secT);
+			const unsigned long long secT2 = RT_SEC_NOW();
 			const int kl = __float_as_int(r3.w);
 			const int kind = kl & 3;
 			if (COUNT) lc.prim++;
@@ -534,27 +638,48 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				if (kl & RT_LAST_BIT) pop_next();
 				else link = lk + 1;
 			}
+			RT_SEC_WAIT();
+			RT_SEC_ADD(4, secT2);
 		}
 		if (runEnter && wantEnter) {
+			const unsigned long long secT = RT_SEC_NOW();
+			RT_SEC_COUNT(11);
 			// TLAS leaf: bvhInstance::BIntersect / IsOccluded (bvhInstance.cpp:3-35): ray to object space
 			// with invTransform (direction not renormalised: t is shared by both spaces); the BLAS is
 			// walked above a sentinel on the same stack
 			inst = (int)(lk & ~RT_INST_BIT);
 			RT_CHECK(S.useTLAS && inst >= 0 && inst < 256, 5, overflow);
 			if (COUNT) lc.inst++;
-			const DInstance* I = S.inst + inst;
+			float invT[12];
+			uint rootB, rootW;
+			if (S.tlasLds) {
+				const lds_v4f* I = tlasL + 7 * S.tlasPairs + 4 * inst;
+				const v4f m0 = I[0], m1 = I[1], m2 = I[2], m3 = I[3];
+				invT[0] = m0.x, invT[1] = m0.y, invT[2] = m0.z, invT[3] = m0.w, invT[4] = m1.x, invT[5] = m1.y, invT[6] = m1.z, invT[7] = m1.w;
+				invT[8] = m2.x, invT[9] = m2.y, invT[10] = m2.z, invT[11] = m2.w;
+				rootB = __float_as_uint(m3.x), rootW = __float_as_uint(m3.y);
+			} else {
+				const DInstance* I = S.inst + inst;
+#pragma unroll
+				for (int k = 0; k < 12; k++) invT[k] = I->invT[k];
+				rootB = I->rootLink, rootW = I->rootWide;
+			}
 			worldRay[0 * RT_BLOCK] = __float_as_uint(O.x), worldRay[1 * RT_BLOCK] = __float_as_uint(O.y), worldRay[2 * RT_BLOCK] = __float_as_uint(O.z);
 			worldRay[3 * RT_BLOCK] = __float_as_uint(D.x), worldRay[4 * RT_BLOCK] = __float_as_uint(D.y), worldRay[5 * RT_BLOCK] = __float_as_uint(D.z);
-			const f3 Oo = xform_pos(I->invT, O);
-			const f3 Do = xform_vec(I->invT, D);
+			const f3 Oo = xform_pos(invT, O);
+			const f3 Do = xform_vec(invT, D);
 			O = Oo, D = Do, rD = rcp3(Do);
 			clean = ray_is_clean(O, D, rD);
-			link = WIDE ? I->rootWide : I->rootLink;
+			link = WIDE ? rootW : rootB;
 			if (link == RT_EMPTY) link = RT_LINK_EXIT;
 			else st.push(RT_SENTINEL);
 			if constexpr (WIDE) { if (!clean) { pol.leftover(work); work = -1; link = RT_LINK_DONE; } } // not clean in object space: the binary walk redoes this ray
+			RT_SEC_WAIT();
+			RT_SEC_ADD(5, secT);
 		}
 		if (runExit && wantExit) {
+			const unsigned long long secT = RT_SEC_NOW();
+			RT_SEC_COUNT(12);
 			// back to world space (the backup ray of bvhInstance.cpp:6, :20), then the next TLAS entry.  The backup is in
 			// LDS: fetching the ray again from the path state cost two HBM round trips per exit -- a random slot each
 			// time, 0.75 exits per ray -- which was most of this kernel's HBM traffic, and the whole wave waited for them.
@@ -564,6 +689,8 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			clean = ray_is_clean(O, D, rD);
 			inst = -1;
 			pop_next();
+			RT_SEC_WAIT();
+			RT_SEC_ADD(6, secT);
 		}
 	}
 }
