@@ -109,6 +109,27 @@ __global__ void __launch_bounds__(256, 7) walkAs(const float4* __restrict__ tab,
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// A with cache-policy bits on the loads (sc0: wave scope, sc1: system scope, nt: streaming): does a policy make an L1 miss cheaper?
+#define WALK_POLICY(NAME, MOD) \
+__global__ void __launch_bounds__(256, 7) NAME(const float4* __restrict__ tab, int steps, unsigned mask, float* out) \
+{ \
+	unsigned idx = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u & mask; \
+	float acc = 0; \
+	const char* base = (const char*)tab; \
+	for (int s = 0; s < steps; s++) { \
+		const unsigned off = idx << 6; \
+		float4 a, b, c, d; \
+		asm volatile("global_load_dwordx4 %0, %4, %5 " MOD "\n global_load_dwordx4 %1, %4, %5 offset:16 " MOD "\n global_load_dwordx4 %2, %4, %5 offset:32 " MOD "\n global_load_dwordx4 %3, %4, %5 offset:48 " MOD "\n s_waitcnt vmcnt(0)" \
+		             : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(off), "s"(base) : "memory"); \
+		acc += a.x + b.y + c.z + d.x; \
+		idx = __float_as_uint(a.w) & mask; \
+	} \
+	out[blockIdx.x * blockDim.x + threadIdx.x] = acc; \
+}
+WALK_POLICY(walkSc0, "sc0")
+WALK_POLICY(walkSc1, "sc1")
+WALK_POLICY(walkNt, "nt")
+WALK_POLICY(walkSc01, "sc0 sc1")
 // one lane per walker, ONE dwordx4 per step (16-byte records at a 64-byte stride)
 __global__ void __launch_bounds__(256, 7) walkA1(const float4* __restrict__ tab, int steps, unsigned mask, float* out)
 {
@@ -162,7 +183,7 @@ int main()
 		hipEvent_t a, b;
 		CHK(hipEventCreate(&a));
 		CHK(hipEventCreate(&b));
-		for (int variant = 0; variant < 10; variant++) {
+		for (int variant = 0; variant < 14; variant++) {
 			for (int rep = 0; rep < 2; rep++) {
 				CHK(hipEventRecord(a));
 				if (variant == 0) hipLaunchKernelGGL(walkA, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
@@ -174,13 +195,17 @@ int main()
 				if (variant == 7) hipLaunchKernelGGL(walkAmask<2>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 8) hipLaunchKernelGGL(walkAmask<4>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 9) hipLaunchKernelGGL(walkAs, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 10) hipLaunchKernelGGL(walkSc0, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 11) hipLaunchKernelGGL(walkSc1, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 12) hipLaunchKernelGGL(walkNt, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 13) hipLaunchKernelGGL(walkSc01, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 6) hipLaunchKernelGGL(walkA8, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				CHK(hipEventRecord(b));
 				CHK(hipEventSynchronize(b));
 				float ms;
 				CHK(hipEventElapsedTime(&ms, a, b));
-				const double per[10] = { 1, 0.25, 0.5, 0.5, 1, 1, 1, 0.5, 0.25, 1 };
-				const char* names[10] = { "A  lane, 4 loads/rec", "Q  quad, 1 load/lane", "P  pair, 2 loads/lane", "Q2 quad, 2 chains", "Q4 quad, 4 chains", "A1 lane, 1 load (16 B)", "A8 lane, 8 loads (128 B)", "A  every 2nd lane only", "A  every 4th lane only", "As lane, 4 loads, saddr+voffset" };
+				const double per[14] = { 1, 0.25, 0.5, 0.5, 1, 1, 1, 0.5, 0.25, 1, 1, 1, 1, 1 };
+				const char* names[14] = { "A  lane, 4 loads/rec", "Q  quad, 1 load/lane", "P  pair, 2 loads/lane", "Q2 quad, 2 chains", "Q4 quad, 4 chains", "A1 lane, 1 load (16 B)", "A8 lane, 8 loads (128 B)", "A  every 2nd lane only", "A  every 4th lane only", "As lane, 4 loads, saddr+voffset", "As + sc0", "As + sc1", "As + nt", "As + sc0 sc1" };
 				const double walkers = (double)blocks * threads * per[variant];
 				if (rep == 1) printf("table %5u KB  %-26s %8.3f ms  %8.2f G records/s  (%.0f walkers)\n", R * 64 / 1024, names[variant], ms, walkers * steps / ms / 1e6, walkers);
 			}

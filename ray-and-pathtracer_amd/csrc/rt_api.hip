@@ -66,8 +66,9 @@ struct rt_ctx {
 	int gridBlocks = 0;
 	int gridExtend = 0, gridConnect = 0, gridQuery = 0, gridTraverse = 0, gridConnectWide = 0, gridLeftover = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
 	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
-	int refillAny = 32; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
+	int refillAny = 24; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int pairAgain = 16; // lanes that must still want a pair step for an iteration to repeat it (RT_PAIRAGAIN); tuning bits 20-26
+	int stepMinXform = 0; // RT_STEPMIN_XFORM: lanes that must want an instance entry / exit before it runs (0: the same as RT_STEPMIN)
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
 	int counting = 0; // 0 off, 1 the reference's walk (RT_COUNT_REFERENCE), 2 the walk the timed kernels make (RT_COUNT_EXECUTED)
@@ -107,7 +108,7 @@ static void free_pool(std::vector<void*>& pool)
 	pool.clear();
 }
 
-static int tuning(const rt_ctx* c, int base) { return base | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgain << 20); }
+static int tuning(const rt_ctx* c, int base) { return base | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgain << 20) | (c->stepMinXform << 27); }
 
 // ---- profiling helpers ---------------------------------------------------------------------
 enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_CONNECT, K_QUERY };
@@ -238,10 +239,12 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (c->refillMin < 1) c->refillMin = 1;
 	if (c->refillMin > 64) c->refillMin = 64;
 	if (getenv("RT_REFILL_ANY")) c->refillAny = atoi(getenv("RT_REFILL_ANY"));
-	if (c->refillAny < 1 || c->refillAny > 64) c->refillAny = 32;
+	if (c->refillAny < 1 || c->refillAny > 64) c->refillAny = 24;
 	if (getenv("RT_PAIRAGAIN")) c->pairAgain = atoi(getenv("RT_PAIRAGAIN"));
 	if (c->pairAgain < 1 || c->pairAgain > 65) c->pairAgain = 16;
-	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 12; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
+	if (getenv("RT_STEPMIN_XFORM")) c->stepMinXform = atoi(getenv("RT_STEPMIN_XFORM"));
+	if (c->stepMinXform < 0 || c->stepMinXform > 15) c->stepMinXform = 0;
+	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 8; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
 	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->flags, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
 	ok = ok && hipMemset(c->flags, 0, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;

@@ -266,6 +266,9 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // sub-queues when its own is empty.
 #define RT_TUNE_CULL_COUNTED 0x10000 // 'tuning' bit: a counting launch drops unreachable TLAS children like a timed one
 #define RT_HEADS 16
+#ifndef RT_FETCH_STEP
+#define RT_FETCH_STEP 0 // 1: pair and leaf records fetched by one step kind (measured: extend 27.6 -> 32.3 ms, see FETCH below)
+#endif
 #ifndef RT_PAIR_REPEAT
 #define RT_PAIR_REPEAT 4 // pair steps per iteration at most (unrolled)
 #endif
@@ -309,6 +312,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	static_assert(!WIDE || (ANY && !COUNT && !MIXED), "the wide walk is exact for any-hit queries only");
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
 	const int refillMin = tuning & 0xFF, stepMinBusy = (tuning >> 8) & 0xFF, pairAgainBusy = (tuning >> 20) & 0x7F;
+	const int stepMinXformBusy = ((tuning >> 27) & 0xF) ? ((tuning >> 27) & 0xF) : stepMinBusy; // entry / exit: arithmetic and LDS only when the TLAS is in LDS
 	const uint lane = threadIdx.x & 63;
 	const unsigned long long below = (1ull << lane) - 1;
 	// sub-queue h = [h * subLen, (h + 1) * subLen) cut at n; all of this is wave-uniform (SGPRs)
@@ -370,6 +374,33 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		const uint v = st.pop();
 		link = v == RT_SENTINEL ? RT_LINK_EXIT : v;
 	};
+
+	// one primitive of a leaf (bvh.cpp:616-629 / :770-783) on its record, for the lanes enabled
+	auto leaf_test = [&](uint lk, const float4& r0, const float4& r1, const float4& r2, const float4& r3) {
+		const uint slot = lk & ~RT_LEAF_BIT;
+		const int kl = __float_as_int(r3.w);
+		const int kind = kl & 3;
+		if (COUNT) lc.prim++;
+		float t;
+		bool h;
+		if (kind == RT_KIND_TRI) h = tri_hit(O, D, rayT, bvh_t_min, xyz(r0), xyz(r1), xyz(r2), f3(r0.w, r1.w, r2.w), r3.x, t);
+		else if (kind == RT_KIND_SPHERE) {
+			if (MIXED ? laneAny : ANY) h = sphere_occludes(O, D, rayT, bvh_t_min, xyz(r0), r0.w);
+			else h = sphere_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
+		} else h = plane_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
+		if (h && (MIXED ? laneAny : ANY)) hit.kind = 1, link = RT_LINK_DONE; // first occluder ends the query
+		else {
+			if (h) rayT = t, hit.prim = slot, hit.inst = inst, hit.kind = 0;
+			if (kl & RT_LAST_BIT) pop_next();
+			else link = lk + 1;
+		}
+	};
+	// FETCH (experiment, off): a leaf's primitive record can be fetched by the same four loads as a pair record (another
+	// base address per lane), which makes "pair" and "leaf" ONE step kind and saves the leaf steps' load instructions
+	// (the texture addresser spends ~16 cycles per dwordx4 instruction whatever the number of enabled lanes).  It loses:
+	// the triangle arithmetic then runs in every pair step for the ~5 lanes that happen to be at a leaf instead of every
+	// few iterations for ~13 (extend 27.6 -> 32.3 ms, connect 10.3 -> 12.5 ms).
+	constexpr bool FETCH = RT_FETCH_STEP && !WIDE;
 
 	while (true) {
 		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
@@ -472,28 +503,30 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		// and the rarer kinds find more lanes waiting when their turn comes.
 		// Once the queue is dry no new lane will ever join a postponed kind: waiting for company only stretches the
 		// dependent chains of the last rays (the drain of the launch), so every wanted kind runs in every iteration.
-		const int stepMin = exhausted ? 1 : stepMinBusy, pairAgain = exhausted ? 1 : pairAgainBusy;
+		const int stepMin = exhausted ? 1 : stepMinBusy, pairAgain = exhausted ? 1 : pairAgainBusy, stepMinXform = exhausted ? 1 : stepMinXformBusy;
 #pragma unroll
 		for (int rep = 0; rep < RT_PAIR_REPEAT; rep++) {
 			const uint lk = link;
 			const bool live = work >= 0 && lk != RT_LINK_DONE;
 			const bool wantPair = live && !(lk & (RT_LEAF_BIT | RT_INST_BIT));
-			const int nP = __popcll(__ballot(wantPair));
+			const bool isLeaf = live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
+			const bool wantFetch = wantPair || (FETCH && isLeaf);
+			const int nP = __popcll(__ballot(wantFetch));
 			if (nP == 0) break;
 			if (rep == 0) {
 				if (nP < stepMin) {
 					// fewer than stepMin: only if nothing else is wanted more
-					const int nL = __popcll(__ballot(live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT)));
+					const int nL = FETCH ? 0 : __popcll(__ballot(isLeaf));
 					const int nN = __popcll(__ballot(live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT)));
 					const int nE = __popcll(__ballot(live && lk == RT_LINK_EXIT));
 					if (nP < nL || nP < nN || nP < nE) break;
 				}
 			} else if (nP < pairAgain) break;
-			if (wantPair) {
+			if (wantFetch) {
 				// one sibling pair: of the BLAS (bvh.cpp:638-654 / :788-804) or, outside an instance in TLAS
 				// mode, of the TLAS (tlas.cpp:77-91 / :106-120) -- same test, same ordering rule
-				if (COUNT) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
-				const bool atTlas = S.useTLAS && inst < 0;
+				if (COUNT && wantPair) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
+				const bool atTlas = wantPair && S.useTLAS && inst < 0;
 				if (WIDE && !atTlas) {
 					// one 4-wide node: every child whose box the ray passes is visited, in any order (a boolean query)
 					const float4* w = S.wide + 8 * (size_t)lk;
@@ -535,7 +568,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 						r0 = ld_lds(qr), r1 = ld_lds(qr + 1), r2 = ld_lds(qr + 2);
 					}
 				} else {
-					const float4* p = S.pairs + 4 * (size_t)lk;
+					const float4* p = FETCH && !wantPair ? S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT) : S.pairs + 4 * (size_t)lk;
 					a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
 					if (useReach) {
 						const float4* q = S.reach + 3 * (size_t)(lk - S.tlasBase);
@@ -570,6 +603,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 					if (xs == 0x7fffffff && n < 0) *overflow = 3;
 				}
 #endif
+				if (FETCH && !wantPair) {
+					leaf_test(lk, a0, a1, b0, b1);
+					continue;
+				}
 				float dist1, dist2;
 				if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
 				else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
@@ -595,14 +632,14 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		const bool wantLeaf = live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
 		const bool wantExit = live && lk == RT_LINK_EXIT;
 		const bool wantEnter = live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT);
-		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(live && !(lk & (RT_LEAF_BIT | RT_INST_BIT))));
+		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(live && !(lk & (RT_LEAF_BIT | RT_INST_BIT)))); // FETCH: max(nL, nP) stands for their sum below
 		const int nN = __popcll(__ballot(wantEnter)), nE = __popcll(__ballot(wantExit));
 		int most = nL > nP ? nL : nP;
 		most = nN > most ? nN : most;
 		most = nE > most ? nE : most;
-		const bool runLeaf = nL > 0 && (nL >= stepMin || nL == most);
-		const bool runEnter = nN > 0 && (nN >= stepMin || nN == most);
-		const bool runExit = nE > 0 && (nE >= stepMin || nE == most);
+		const bool runLeaf = !FETCH && nL > 0 && (nL >= stepMin || nL == most);
+		const bool runEnter = nN > 0 && (nN >= stepMinXform || nN == most);
+		const bool runExit = nE > 0 && (nE >= stepMinXform || nE == most);
 		if (most == 0 && __ballot(live) != 0) {
 			// live lanes whose link no step kind understands (a corrupt tree): nothing would ever change again.  Every
 			// wave must reach its exit, so the rays are dropped and the launch reports RT_E_STATE.
@@ -612,32 +649,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		}
 
 		if (runLeaf && wantLeaf) {
-			// one primitive of a leaf (bvh.cpp:616-629 / :770-783); all four vectors of the record in
-			// one go (nearly every record is a triangle)
-			const uint slot = lk & ~RT_LEAF_BIT;
-			const float4* rec = S.prims + 4 * (size_t)slot;
+			// a leaf step of its own (the wide walk): all four vectors of the record in one go (nearly every record is a triangle)
+			const float4* rec = S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT);
 			const unsigned long long secT = RT_SEC_NOW();
 			RT_SEC_COUNT(10);
 			const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
 			RT_SEC_WAIT();
 			RT_SEC_ADD(3, secT);
 			const unsigned long long secT2 = RT_SEC_NOW();
-			const int kl = __float_as_int(r3.w);
-			const int kind = kl & 3;
-			if (COUNT) lc.prim++;
-			float t;
-			bool h;
-			if (kind == RT_KIND_TRI) h = tri_hit(O, D, rayT, bvh_t_min, xyz(r0), xyz(r1), xyz(r2), f3(r0.w, r1.w, r2.w), r3.x, t);
-			else if (kind == RT_KIND_SPHERE) {
-				if (MIXED ? laneAny : ANY) h = sphere_occludes(O, D, rayT, bvh_t_min, xyz(r0), r0.w);
-				else h = sphere_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
-			} else h = plane_hit(O, D, rayT, bvh_t_min, xyz(r0), r0.w, t);
-			if (h && (MIXED ? laneAny : ANY)) hit.kind = 1, link = RT_LINK_DONE; // first occluder ends the query
-			else {
-				if (h) rayT = t, hit.prim = slot, hit.inst = inst, hit.kind = 0;
-				if (kl & RT_LAST_BIT) pop_next();
-				else link = lk + 1;
-			}
+			leaf_test(lk, r0, r1, r2, r3);
 			RT_SEC_WAIT();
 			RT_SEC_ADD(4, secT2);
 		}
