@@ -705,7 +705,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		S.reachOriginMax = (float)originMax;
 		S.tlasPairs = (int)tlasSlots.size();
 		S.nInst = (int)d->n_instances;
-		S.tlasLds = S.tlasPairs * 28 + S.nInst * 16 <= RT_TLAS_LDS_WORDS ? 1 : 0;
+		S.tlasLds = S.tlasPairs * 28 + S.nInst * 13 <= RT_TLAS_LDS_WORDS ? 1 : 0;
 		if (getenv("RT_TLAS_LDS")) S.tlasLds = S.tlasLds && atoi(getenv("RT_TLAS_LDS")) != 0;
 	}
 	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);

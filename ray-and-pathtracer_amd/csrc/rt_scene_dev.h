@@ -61,8 +61,12 @@ namespace rtd {
 #define RT_MAX_LIGHTS 8
 
 #define RT_BLOCK 256
+#ifndef RT_STACK_LDS
 #define RT_STACK_LDS 15   // stack entries per lane held in LDS
-#define RT_TLAS_LDS_WORDS 352 // a block's copy of a small TLAS: per pair 16 (boxes + links) + 12 (reach) dwords, per instance 16
+#endif
+#ifndef RT_TLAS_LDS_WORDS
+#define RT_TLAS_LDS_WORDS 352 // a block's copy of a small TLAS: per pair 16 (boxes + links) + 12 (reach) dwords, per instance 12 (invT) + 1 (root link)
+#endif
 #define RT_LDS_ROWS ((RT_STACK_LDS + 6) * RT_BLOCK)  // the stack rows, then six rows for the world-space ray of a lane that is inside an instance
 #define RT_LDS_WORDS (RT_LDS_ROWS + RT_TLAS_LDS_WORDS) // a traversal block's LDS (trace_persistent): 22,912 bytes, seven blocks per CU
 #define RT_STACK_MAX 130  // tlas::Intersect's stack[64] (tlas.cpp:67) + the instance sentinel + bvh::BIntersect's own stack[64]
@@ -330,17 +334,19 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	// A small TLAS is walked in LDS.  The traversal is bound by the vector-memory path (lane accesses through the
 	// texture addresser and L1); a TLAS visit is seven of them (pair + reach record) and an
 	// instance entry four, together a quarter of all accesses on the bench scene; ds_read takes another pipe.
-	// Layout: [pair][4] | [pair][3] reach | [instance][4] = invT rows 0-2, {rootLink, rootWide, -, -}
+	// Layout: [pair][4] | [pair][3] reach | [instance][3] invT rows 0-2 | [instance] root link (rootWide for the wide walk)
 	lds_v4f* const tlasL = (lds_v4f*)((lds_uint*)ldsStack + RT_LDS_ROWS);
 	if (S.tlasLds) {
-		const int nP = S.tlasPairs * 4, nR = S.tlasPairs * 3, nI = S.nInst * 4;
+		const int nP = S.tlasPairs * 4, nR = S.tlasPairs * 3, nI = S.nInst * 3;
 		for (int i = (int)threadIdx.x; i < nP + nR + nI; i += RT_BLOCK) {
 			v4f v;
 			if (i < nP) v = ((const v4f*)S.pairs)[4 * (size_t)S.tlasBase + i];
 			else if (i < nP + nR) v = ((const v4f*)S.reach)[i - nP];
-			else { const int k = i - nP - nR; v = ((const v4f*)S.inst)[(size_t)(k >> 2) * 8 + ((k & 3) == 3 ? 6 : (k & 3))]; }
+			else { const int k = i - nP - nR; v = ((const v4f*)S.inst)[(size_t)(k / 3) * 8 + k % 3]; }
 			tlasL[i] = v;
 		}
+		lds_uint* const roots = (lds_uint*)(tlasL + nP + nR + nI);
+		for (int i = (int)threadIdx.x; i < S.nInst; i += RT_BLOCK) roots[i] = WIDE ? S.inst[i].rootWide : S.inst[i].rootLink;
 		__syncthreads();
 	}
 #ifdef RT_TAIL_PROBE
@@ -673,11 +679,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			float invT[12];
 			uint rootB, rootW;
 			if (S.tlasLds) {
-				const lds_v4f* I = tlasL + 7 * S.tlasPairs + 4 * inst;
-				const v4f m0 = I[0], m1 = I[1], m2 = I[2], m3 = I[3];
+				const lds_v4f* I = tlasL + 7 * S.tlasPairs + 3 * inst;
+				const v4f m0 = I[0], m1 = I[1], m2 = I[2];
 				invT[0] = m0.x, invT[1] = m0.y, invT[2] = m0.z, invT[3] = m0.w, invT[4] = m1.x, invT[5] = m1.y, invT[6] = m1.z, invT[7] = m1.w;
 				invT[8] = m2.x, invT[9] = m2.y, invT[10] = m2.z, invT[11] = m2.w;
-				rootB = __float_as_uint(m3.x), rootW = __float_as_uint(m3.y);
+				rootB = rootW = ((const lds_uint*)(tlasL + 7 * S.tlasPairs + 3 * S.nInst))[inst];
 			} else {
 				const DInstance* I = S.inst + inst;
 #pragma unroll
