@@ -235,6 +235,9 @@ def roofline_block(args, ha, near, avg_ms, launches_per_step, W, H, spp, world, 
         rb["hbm"]["counter_frac_of_hbm_peak"] = round(k["hbm_bytes_per_launch"] / sec / 8e12, 4)
         rb["valu"] = {"lanes_enabled": k["lanes_enabled"], "valu_pipe_busy": k["valu_pipe_busy"], "wave_wait_frac": k["wave_wait_frac"],
                       "l1_accesses_per_cu_cycle": k["l1_accesses_per_cu_cycle"], "profile_launch_ms": round(k["ms"] / k["launches"], 4)}
+        if "ta_busy_avg" in k:  # the busiest unit: the texture addressers (every vector-memory instruction costs ~16-19 of their cycles)
+            rb["ta"] = {"busy_avg": k["ta_busy_avg"], "busy_max": k["ta_busy_max"], "cycles_per_vmem_inst": k.get("ta_cycles_per_vmem_inst"),
+                        "vmem_insts_per_launch": int(k["vmem_insts"] / k["launches"]) if k.get("vmem_insts") else None}
     return rb
 
 

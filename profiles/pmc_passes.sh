@@ -15,3 +15,6 @@ run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE GRBM_TA_BUSY
+# the texture addresser (vector-memory address path) and what it is fed; TA_ADDR_STALLED_BY_TD / TD_* hang on this pool: not collected
+run ta1 TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max TA_ADDR_STALLED_BY_TC_CYCLES_sum
+run sq3 SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_IFETCH

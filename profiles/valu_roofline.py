@@ -12,6 +12,9 @@ For the traversal kernel k_extend (all timed variants summed) per step of the be
                       "VALU active" for 4 cycles per instruction; up to two waves of a SIMD can be at once)
   frac                lane_ops / (peak lane-ops/s * kernel seconds): <= 1 by construction; = lanes_enabled x pipe busy
   hbm_bytes           FETCH_SIZE x 2 (gfx950 correction of the guide's HBM section) + WRITE_SIZE, in bytes
+  ta_busy_avg / max   TA_BUSY_avr / TA_BUSY_max over the kernel's cycles: the share of time the texture addressers (one per
+                      CU: every vector-memory instruction passes through) are busy, averaged over them / for the busiest
+  ta_cycles_per_vmem_inst   TA_TA_BUSY_sum / SQ_INSTS_VMEM: addresser-busy cycles per vector-memory instruction
 The file is stamped with a hash of the kernel sources (csrc/); bench.py ignores it when the sources changed.
 Usage: valu_roofline.py <pmc_summary.json> <workload> <width> <height> <spp>   (what the profiled bench.py run rendered)"""
 import hashlib, json, os, sys
@@ -61,6 +64,12 @@ def main():
              "l1_accesses_per_cu_cycle": round(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / (256 * cycles), 4),
              "l2_hit_rate": round(c["TCC_HIT_sum"] / max(1.0, c["TCC_REQ_sum"]), 4),
              "hbm_bytes": int(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024)}
+        if "TA_BUSY_avr" in c and cycles > 0:
+            o["ta_busy_avg"] = round(c["TA_BUSY_avr"] / cycles, 4)
+            o["ta_busy_max"] = round(c["TA_BUSY_max"] / cycles, 4)
+            o["vmem_insts"] = c.get("SQ_INSTS_VMEM")
+            if c.get("SQ_INSTS_VMEM"):
+                o["ta_cycles_per_vmem_inst"] = round(c["TA_TA_BUSY_sum"] / c["SQ_INSTS_VMEM"], 2)
         o["hbm_bytes_per_launch"] = int(o["hbm_bytes"] / launches)
         o["lane_ops_per_launch"] = o["lane_ops"] / launches
         out["kernels"][g] = o
