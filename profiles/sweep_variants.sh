@@ -3,5 +3,5 @@
 # Usage: [BENCH_ARGS="--spp 8"] sweep_variants.sh "<flags>" "<flags>" ...
 for v in "$@"; do
   make -s -C ray-and-pathtracer_amd/csrc clean; make -s -C ray-and-pathtracer_amd/csrc EXTRA="$v" 2>&1 | grep -i error
-  echo "[$v]: $(python bench.py --no-cpu-baseline --steps 4 --warmup 2 $BENCH_ARGS 2>/dev/null | grep -o 'ms_per_step.: [0-9.]*\|kernel_ms_per_step.*}}\|frame_checksum.: .[0-9a-f]*' | tr '\n' ' ')"
+  echo "[$v]: $(python bench.py --no-cpu-baseline --steps ${STEPS:-4} --warmup 2 $BENCH_ARGS 2>/dev/null | grep -o 'ms_per_step.: [0-9.]*\|kernel_ms_per_step.*}}\|frame_checksum.: .[0-9a-f]*' | tr '\n' ' ')"
 done

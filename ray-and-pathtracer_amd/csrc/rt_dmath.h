@@ -56,12 +56,20 @@ __device__ __forceinline__ int f2i(float f)
 
 // Transcendentals: evaluated in f64, rounded once to f32 (DESIGN.md "Transcendentals"); the same
 // definition is used by every CPU implementation this path is compared with.
-__device__ __forceinline__ float x_cosf(float x) { return (float)cos((double)x); }
-__device__ __forceinline__ float x_sinf(float x) { return (float)sin((double)x); }
-__device__ __forceinline__ float x_acosf(float x) { return (float)acos((double)x); }
-__device__ __forceinline__ float x_asinf(float x) { return (float)asin((double)x); }
-__device__ __forceinline__ float x_expf(float x) { return (float)exp((double)x); }
-__device__ __forceinline__ float x_powf(float a, float b) { return (float)pow((double)a, (double)b); }
+// They are real functions, not inlined: the double-precision library bodies pushed k_shade to 128 VGPRs (its bound; four
+// waves per SIMD) and k_light to 181 (two); called, the kernels need 89 and 114 (five and four waves) and the shading
+// side of a bench step takes 15.6 instead of 16.5 ms.  RT_INLINE_MATH restores the inlined form.
+#ifdef RT_INLINE_MATH
+#define RT_MATH_FN __device__ __forceinline__
+#else
+#define RT_MATH_FN __device__ __noinline__
+#endif
+RT_MATH_FN float x_cosf(float x) { return (float)cos((double)x); }
+RT_MATH_FN float x_sinf(float x) { return (float)sin((double)x); }
+RT_MATH_FN float x_acosf(float x) { return (float)acos((double)x); }
+RT_MATH_FN float x_asinf(float x) { return (float)asin((double)x); }
+RT_MATH_FN float x_expf(float x) { return (float)exp((double)x); }
+RT_MATH_FN float x_powf(float a, float b) { return (float)pow((double)a, (double)b); }
 
 #define RT_PI 3.14159265358979323846264f
 #define RT_INVPI 0.31830988618379067153777f

@@ -473,7 +473,10 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, 
 // shade: everything Trace / Sample do at a hit except the occlusion-dependent direct terms.
 // Outcomes per slot: continue with a new ray (next active queue), hand the diffuse direct terms to
 // connect + light (shadow queue), or end the segment (done queue).
-__global__ void __launch_bounds__(RT_BLOCK, 4) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity, int fresh)
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
+__global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity, int fresh)
 {
 	const int pout = 1 - parity;
 	const int nActive = Q.counts[0];
@@ -686,7 +689,12 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse(DScene
 // light: the direct-light terms of a diffuse hit, in light order.
 // Whitted (renderer.cpp:89-105): scatter first (energy changes even when occluded), then the
 // occlusion test.  Path (renderer.cpp:158-176): occlusion test first, scatter only when visible.
-__global__ void __launch_bounds__(RT_BLOCK) k_light(DScene S, RenderParams R, PathState P, Queues Q, int parity)
+#ifdef RT_LIGHT_WAVES
+#define RT_LIGHT_BOUNDS __launch_bounds__(RT_BLOCK, RT_LIGHT_WAVES)
+#else
+#define RT_LIGHT_BOUNDS __launch_bounds__(RT_BLOCK)
+#endif
+__global__ void RT_LIGHT_BOUNDS k_light(DScene S, RenderParams R, PathState P, Queues Q, int parity)
 {
 	const int nShadow = Q.counts[2];
 	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nShadow; e += gridDim.x * blockDim.x) {
