@@ -1060,7 +1060,7 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 			section_probe_print(st, "extend", round);
 #endif
 			prof_begin(c, K_SHADE, st);
-			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity, round == 0 && Rs[k].finishInline ? 1 : 0);
+			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, Rs[k], P[k], Q, parity, round == 0 && Rs[k].finishInline ? 1 : 0);
 			prof_end(c, st);
 			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
 #ifdef RT_TAIL_PROBE
@@ -1172,7 +1172,7 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 		}
 		if (round < rounds) {
 			prof_begin(c, K_SHADE, st);
-			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, R, P, Q, parity, round == 0 ? 1 : 0);
+			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q, parity, round == 0 ? 1 : 0);
 			prof_end(c, st);
 			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 0, 0, 2);
 			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);

@@ -318,8 +318,31 @@ __device__ __forceinline__ float mode_t_min(int mode) { return mode == 0 ? (floa
 // Put sample 'sid' of the pool into a slot: seed, jitter, primary ray (renderer.cpp:263-278)
 // depth a fresh sample starts with (renderer.cpp:269 / :278; rt_trace_batch: the caller's)
 __device__ __forceinline__ int start_depth(const RenderParams& R) { return R.customO ? R.customDepth : (R.mode == 0 ? R.maxDepth : 4); }
+// camera sample 'sid' of the pool (renderer.cpp:263-278): its seed, jitter and primary ray; deterministic in (R, C, sid)
+__device__ __forceinline__ void sample_primary(const DCamera& C, const RenderParams& R, uint sid, f3& O, f3& D, uint& seed)
+{
+	const uint lp = sid % R.tilePixels, frame = R.frame0 + sid / R.tilePixels;
+	const int x = (int)(lp % (uint)C.width), y = R.rowFirst + (int)(lp / (uint)C.width) * R.rowStride;
+	const int pixel = y * C.width + x;
+	seed = StreamSeed(R.seedBase + (uint)pixel + frame * (uint)(C.width * C.height));
+	if (R.mode == 0) primary_ray(C, x, y, O, D);
+	else {
+		float newX = x + (RandomFloat(seed) * 2 - 1);
+		float newY = y + (RandomFloat(seed) * 2 - 1);
+		primary_ray(C, (int)newX, (int)newY, O, D); // jitter truncated by the int parameters (renderer.cpp:276-278)
+	}
+}
+// energy and RNG state a sample starts its first segment with
+__device__ __forceinline__ float4 fresh_energy(const DCamera& C, const RenderParams& R, uint sid)
+{
+	if (R.customO) return make_float4(R.customE[0], R.customE[1], R.customE[2], __uint_as_float(StreamSeed(R.seedBase + sid)));
+	f3 O, D;
+	uint seed;
+	sample_primary(C, R, sid, O, D, seed); // the ray itself is not needed here (and not computed: dead code)
+	return make_float4(1, 1, 1, __uint_as_float(seed));
+}
 // writeWL = false: the caller guarantees that the first shade of this slot runs with 'fresh' set and rebuilds
-// W = (1,1,1,depth) and L = (0,0,0,sid) itself instead of reading them
+// W = (1,1,1,depth), L = (0,0,0,sid) and E = fresh_energy() itself instead of reading them
 __device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, const RenderParams& R, PathState& P, int slot, uint sid, int parityOut, bool writeWL = true)
 {
 	f3 O, D;
@@ -331,23 +354,12 @@ __device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, 
 		seed = StreamSeed(R.seedBase + sid);
 		depth = R.customDepth;
 	} else {
-		const uint lp = sid % R.tilePixels, frame = R.frame0 + sid / R.tilePixels;
-		const int x = (int)(lp % (uint)C.width), y = R.rowFirst + (int)(lp / (uint)C.width) * R.rowStride;
-		const int pixel = y * C.width + x;
-		seed = StreamSeed(R.seedBase + (uint)pixel + frame * (uint)(C.width * C.height));
-		if (R.mode == 0) {
-			primary_ray(C, x, y, O, D);
-			depth = R.maxDepth;
-		} else {
-			float newX = x + (RandomFloat(seed) * 2 - 1);
-			float newY = y + (RandomFloat(seed) * 2 - 1);
-			primary_ray(C, (int)newX, (int)newY, O, D); // jitter truncated by the int parameters (renderer.cpp:276-278)
-			depth = 4;
-		}
+		sample_primary(C, R, sid, O, D, seed);
+		depth = R.mode == 0 ? R.maxDepth : 4;
 	}
 	emit_ray(S, P, parityOut, slot, O, D, mode_t_min(R.mode));
-	P.E[slot] = R.customO ? make_float4(R.customE[0], R.customE[1], R.customE[2], __uint_as_float(seed)) : make_float4(1, 1, 1, __uint_as_float(seed));
 	if (writeWL) {
+		P.E[slot] = fresh_energy(C, R, sid);
 		P.W[slot] = make_float4(1, 1, 1, __int_as_float(depth));
 		P.L[slot] = make_float4(0, 0, 0, __uint_as_float(sid));
 	}
@@ -476,7 +488,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, 
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
-__global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) k_shade(DScene S, RenderParams R, PathState P, Queues Q, int parity, int fresh)
+__global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) k_shade(DScene S, DCamera C, RenderParams R, PathState P, Queues Q, int parity, int fresh)
 {
 	const int pout = 1 - parity;
 	const int nActive = Q.counts[0];
@@ -487,8 +499,8 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) k_shade(DScene S, Re
 		{
 			const float4 o4 = P.O[parity][slot], d4 = P.D[parity][slot], hn = P.hitN[parity][slot];
 			const int2 id = P.hitId[parity][slot];
-			// fresh: first segment of a sample whose slot index is its sample (k_generate did not write W and L)
-			const float4 e4 = P.E[slot];
+			// fresh: first segment of a sample whose slot index is its sample (k_generate did not write W, L and E)
+			const float4 e4 = fresh ? fresh_energy(C, R, R.sampleFirst + (uint)slot) : P.E[slot];
 			const float4 w4 = fresh ? make_float4(1, 1, 1, __int_as_float(start_depth(R))) : P.W[slot];
 			const float4 l4 = fresh ? make_float4(0, 0, 0, __uint_as_float(R.sampleFirst + (uint)slot)) : P.L[slot];
 			const f3 O = xyz(o4), D = xyz(d4), normal = xyz(hn);
@@ -578,7 +590,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) k_shade(DScene S, Re
 			// only if they changed (a fresh slot's L has never been written)
 			const bool doneHere = R.finishInline && segmentEnds && !wantShadow;
 			if (!doneHere) {
-				if (E.x != e4.x || E.y != e4.y || E.z != e4.z || seed != __float_as_uint(e4.w)) P.E[slot] = mk4(E, __uint_as_float(seed));
+				if (fresh || E.x != e4.x || E.y != e4.y || E.z != e4.z || seed != __float_as_uint(e4.w)) P.E[slot] = mk4(E, __uint_as_float(seed));
 				if (fresh || Lsum.x != l4.x || Lsum.y != l4.y || Lsum.z != l4.z) P.L[slot] = mk4(Lsum, l4.w);
 			}
 			if (wantShadow) {
