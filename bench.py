@@ -217,10 +217,9 @@ def roofline_block(args, ha, near, avg_ms, launches_per_step, W, H, spp, world, 
         pj = json.load(open(ppath))
     except Exception:
         pj = None
-    if W * H * spp // world < (48 << 20):
-        rb["note"] = ("per-rank batches below 48 M samples run extend(r + 1) and connect(r) as ONE launch (k_traverse, DESIGN.md finding 19): "
-                      "kernel_ms_per_step.extend is that launch plus round 0's extend, .connect the last round's shadow rays only, "
-                      "and the algorithmic bytes above cover the nearest-hit work alone")
+    if W * H * spp // world < (100 << 20):
+        rb["note"] = ("per-rank batches below 100 M samples run extend(r + 1) beside connect(r) + light(r) on a second stream (DESIGN.md "
+                      "findings 19, 33): the kernel times of kernel_ms_per_step overlap and do not add up to the step")
     usable = (pj is not None and pj.get("kernel_hash") == kernel_hash() and world == 1 and
               pj.get("workload") == [args.workload, W, H, spp])
     rb["pmc"] = {"file": "profiles/roofline_pmc.json", "used": bool(usable), "kernel_hash": kernel_hash(),

@@ -58,7 +58,11 @@ struct rt_ctx {
 		hipEvent_t done = nullptr;
 	};
 	Pool pools[RT_MAX_POOLS];
-	int fuseTraversal = -1;  // one traversal launch per round (run_rounds_fused): -1 for batches under RT_FUSE_MAX samples, RT_FUSE=0 / 1 forces
+	int fuseTraversal = -1;  // one traversal launch per round (run_rounds_fused): -1 for batches under RT_FUSE_MAX samples, RT_FUSE=0 / 1 forces;
+	                         // RT_FUSE=2: the same round structure with extend(r + 1) and connect(r) + light(r) as separate kernels on two streams
+	hipStream_t sideStream = nullptr;
+	uint* sideSpill = nullptr;
+	hipEvent_t sideFork = nullptr, sideJoin = nullptr;
 	int nPoolsWanted = 1; // RT_POOLS; measured: 2 pools overlap their kernels but do not shorten the frame
 	hipEvent_t fork = nullptr;
 	// traversal stack spill of pool 0 and of the batch queries + flags
@@ -208,7 +212,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	memset(&c->S, 0, sizeof(c->S));
 	for (int k = 0; k < RT_MAX_POOLS; k++) memset(&c->pools[k].P, 0, sizeof(PathState)), memset(&c->pools[k].Q, 0, sizeof(Queues));
 	if (getenv("RT_POOLS")) c->nPoolsWanted = atoi(getenv("RT_POOLS"));
-	if (getenv("RT_FUSE")) c->fuseTraversal = atoi(getenv("RT_FUSE")) != 0 ? 1 : 0;
+	if (getenv("RT_FUSE")) c->fuseTraversal = atoi(getenv("RT_FUSE")) < 0 ? -1 : (atoi(getenv("RT_FUSE")) > 2 ? 1 : atoi(getenv("RT_FUSE")));
 	if (c->nPoolsWanted < 1) c->nPoolsWanted = 1;
 	if (c->nPoolsWanted > RT_MAX_POOLS) c->nPoolsWanted = RT_MAX_POOLS;
 	memset(&c->prof, 0, sizeof(c->prof));
@@ -281,6 +285,10 @@ void rt_destroy(rt_ctx* c)
 		free_pool(pl.allocs);
 	}
 	if (c->fork) (void)hipEventDestroy(c->fork);
+	if (c->sideStream) { (void)hipStreamSynchronize(c->sideStream); (void)hipStreamDestroy(c->sideStream); }
+	if (c->sideSpill) (void)hipFree(c->sideSpill);
+	if (c->sideFork) (void)hipEventDestroy(c->sideFork);
+	if (c->sideJoin) (void)hipEventDestroy(c->sideJoin);
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
 	if (c->samples) (void)hipFree(c->samples);
@@ -1133,7 +1141,7 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 // kept per kind of query).
 //   generate | begin extend(0) shade(0) cs(0) | begin ca(1) traverse{extend(1), connect(0)} light(0) shade(1) cs(1) | ...
 //   ... | connect(R-1) light(R-1)
-static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
+static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds, int mode)
 {
 	rt_ctx::Pool& pl = c->pools[0];
 	const float t_min = 0.001f; // renderer.cpp:131
@@ -1142,11 +1150,19 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 	P.pend = nullptr, P.pendCount = nullptr;
 	const Queues Q = pl.Q;
 	hipStream_t st = pl.stream;
+	const bool twoStreams = mode == 2;
+	if (twoStreams && !c->sideStream) {
+		HIPCHK(c, hipStreamCreate(&c->sideStream));
+		HIPCHK(c, hipMalloc((void**)&c->sideSpill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
+		HIPCHK(c, hipEventCreateWithFlags(&c->sideFork, hipEventDisableTiming));
+		HIPCHK(c, hipEventCreateWithFlags(&c->sideJoin, hipEventDisableTiming));
+	}
 	prof_begin(c, K_GENERATE, st);
 	hipLaunchKernelGGL(k_generate, dim3((P.nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q);
 	prof_end(c, st);
 	for (int round = 0; round <= rounds; round++) {
 		const int parity = round & 1;
+		bool lightDone = false;
 		if (round == 0) {
 			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, P.nSlots, 3);
 			prof_begin(c, K_EXTEND, st);
@@ -1155,9 +1171,28 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 		} else if (round < rounds) {
 			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
 			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
-			prof_begin(c, K_EXTEND, st);
-			hipLaunchKernelGGL(k_traverse, dim3(c->gridTraverse), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill);
-			prof_end(c, st);
+			if (twoStreams) {
+				// connect(r - 1) and light(r - 1) on the side stream, extend(r) here: two kernels, each with its own kind of lanes
+				hipStream_t sb = c->sideStream;
+				HIPCHK(c, hipEventRecord(c->sideFork, st));
+				HIPCHK(c, hipStreamWaitEvent(sb, c->sideFork, 0));
+				prof_begin(c, K_CONNECT, sb);
+				launch_connect(c, sb, P, Q, 1 - parity, c->sideSpill);
+				prof_end(c, sb);
+				prof_begin(c, K_SHADE, sb);
+				hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, sb, c->S, R, P, Q, 1 - parity);
+				prof_end(c, sb);
+				HIPCHK(c, hipEventRecord(c->sideJoin, sb));
+				prof_begin(c, K_EXTEND, st);
+				hipLaunchKernelGGL((k_extend<false, false>), dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
+				prof_end(c, st);
+				HIPCHK(c, hipStreamWaitEvent(st, c->sideJoin, 0));
+				lightDone = true;
+			} else {
+				prof_begin(c, K_EXTEND, st);
+				hipLaunchKernelGGL(k_traverse, dim3(c->gridTraverse), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill);
+				prof_end(c, st);
+			}
 		} else {
 			// the shadow rays of the last round have no extend to share a launch with
 			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
@@ -1165,7 +1200,7 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 			launch_connect(c, st, P, Q, 1 - parity, pl.spill);
 			prof_end(c, st);
 		}
-		if (round > 0) {
+		if (round > 0 && !lightDone) {
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, R, P, Q, 1 - parity);
 			prof_end(c, st);
@@ -1191,8 +1226,12 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds)
 	return RT_OK;
 }
 
-#define RT_FUSE_MAX ((size_t)48 << 20)
-static bool use_fused(const rt_ctx* c, size_t samples) { return !c->counting && (c->fuseTraversal < 0 ? samples < RT_FUSE_MAX : c->fuseTraversal != 0); }
+// Which round loop a path batch with a slot per sample takes: 0 the plain one (run_rounds), 1 extend(r + 1) and connect(r)
+// as ONE launch (k_traverse), 2 as two kernels on two streams.  Measured (r02_ab_fuse2.txt): 2 beats 1 at every size
+// (1/8 frame 9.22 -> 9.02 ms) and 0 up to half a frame (32 spp: 29.1 -> 28.5 ms); on the full frame 0 and 2 are level,
+// and 0 keeps the per-kernel times of bench.py's roofline block free of overlap.
+#define RT_FUSE_MAX ((size_t)100 << 20)
+static int fuse_mode(const rt_ctx* c, size_t samples) { return c->counting ? 0 : (c->fuseTraversal < 0 ? (samples < RT_FUSE_MAX ? 2 : 0) : c->fuseTraversal); }
 
 // Split 'total' samples over the pools and size their slots.
 static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& base, RenderParams* Rs, int& nPools, int& maxSlots, bool& slotPerSample)
@@ -1287,7 +1326,7 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		const int maxRounds = (int)((total / nPools + slots) / slots) * seg + seg + 4;
 		const bool direct = mode == RT_MODE_PATH && slotPerSample;
 		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
-		rc = direct && nPools == 1 && use_fused(c, total) ? run_rounds_fused(c, Rs[0], seg) : run_rounds(c, Rs, nPools, maxRounds, direct ? seg : 0);
+		rc = direct && nPools == 1 && fuse_mode(c, total) ? run_rounds_fused(c, Rs[0], seg, fuse_mode(c, total)) : run_rounds(c, Rs, nPools, maxRounds, direct ? seg : 0);
 		if (rc != RT_OK) return rc;
 		hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 	}
@@ -1346,7 +1385,7 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 		const int seg = segments_per_sample(mode, depth, c->S.nLights);
 		const bool direct = mode == RT_MODE_PATH && slotPerSample;
 		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
-		if (rc == RT_OK) rc = direct && nPools == 1 && use_fused(c, (size_t)n) ? run_rounds_fused(c, Rs[0], seg) : run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, direct ? seg : 0);
+		if (rc == RT_OK) rc = direct && nPools == 1 && fuse_mode(c, (size_t)n) ? run_rounds_fused(c, Rs[0], seg, fuse_mode(c, (size_t)n)) : run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, direct ? seg : 0);
 	}
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);

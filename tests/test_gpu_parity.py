@@ -905,26 +905,27 @@ def test_fewer_slots_than_samples(slots, name, kw, scenes, oracle_api, host_api,
 
 @pytest.mark.parametrize("name,kw,w,h,frames", [("pretty_tlas", {"n_instances": 4}, 160, 90, 7), ("mixed_small", {}, 96, 64, 5), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72, 3)])
 def test_fused_traversal_launch_equals_separate_launches(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
-    """Path batches with a slot per sample run, below 48 M samples, with ONE traversal launch per round (k_traverse:
-    the next round's rays and this round's shadow rays in one work list, csrc/rt_api.hip run_rounds_fused); larger
-    batches and counting launches keep extend and connect apart.  Both must produce the same accumulator bits, and
-    the oracle's frame."""
+    """Path batches with a slot per sample overlap extend(r + 1) with connect(r) + light(r) (csrc/rt_api.hip
+    run_rounds_fused): below 100 M samples as two kernels on two streams (RT_FUSE=2, the default there), optionally as
+    ONE launch over one work list (RT_FUSE=1, k_traverse); larger batches and counting launches keep the plain round
+    loop (RT_FUSE=0).  All three must produce the same accumulator bits, and the oracle's frame."""
     out = {}
-    for fuse in ("0", "1"):
+    for fuse in ("0", "1", "2"):
         monkeypatch.setenv("RT_FUSE", fuse)
         o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
         r.clear()
         r.render(host_api.RT_MODE_PATH, 0, frames)
         out[fuse] = r.accumulator().copy()
-        if fuse == "1":
+        if fuse != "0":
             check_frames(orr, r, "path", frames, host_api)
             # rows shards through the fused path too
             r.clear()
             r.render_rows(host_api.RT_MODE_PATH, 0, frames, 0, 2, (h + 1) // 2)
             r.render_rows(host_api.RT_MODE_PATH, 0, frames, 1, 2, h // 2)
-            assert np.array_equal(r.accumulator().view(np.uint32), out["1"].view(np.uint32))
+            assert np.array_equal(r.accumulator().view(np.uint32), out[fuse].view(np.uint32))
         r.close()
     assert np.array_equal(out["0"].view(np.uint32), out["1"].view(np.uint32))
+    assert np.array_equal(out["0"].view(np.uint32), out["2"].view(np.uint32))
 
 
 def test_sample_pools_on_separate_streams(scenes, oracle_api, host_api, monkeypatch):
