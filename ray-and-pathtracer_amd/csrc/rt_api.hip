@@ -224,8 +224,8 @@ rt_ctx* rt_create(int device, int width, int height)
 	// through shared work heads, so the same grid serves every queue length
 	c->gridBlocks = prop.multiProcessorCount * 8;
 	{
-		// the traversal kernels give every wave a fixed first chunk of the queue, so their grids must be
-		// fully resident: blocks per CU from the occupancy calculator, per kernel
+		// the persistent traversal kernels are launched with exactly the blocks a CU can hold (occupancy calculator, per
+		// kernel): a block that had to wait for a slot would find its share of the queue already taken
 		const int capBlocks = getenv("RT_TRAV_BLOCKS") ? atoi(getenv("RT_TRAV_BLOCKS")) : 8; // experiment: leave room on every CU for another stream's kernels
 		auto resident = [&](const void* fn) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, RT_BLOCK, 0) != hipSuccess || b < 1) b = 1; if (b > 8) b = 8; if (capBlocks >= 1 && b > capBlocks) b = capBlocks; return b * prop.multiProcessorCount; };
 		const int e0 = std::min(resident((const void*)k_extend<false, false>), resident((const void*)k_extend<false, true>)), e1 = std::min(resident((const void*)k_extend<true, false>), resident((const void*)k_extend<true, true>));
