@@ -554,7 +554,7 @@ def test_limits_are_reported(scenes, oracle_api, host_api):
 
 
 def test_deep_tree_uses_the_spill_stack(oracle_api, host_api):
-    """A degenerate LONGESTAXIS tree over geometrically spaced triangles is deeper than the 16 stack
+    """A degenerate LONGESTAXIS tree over geometrically spaced triangles is deeper than the 15 stack
     entries kept in LDS: the global spill part of the traversal stack must give the same hits."""
     n = 40
     tris = []
@@ -581,6 +581,33 @@ def test_deep_tree_uses_the_spill_stack(oracle_api, host_api):
     assert np.array_equal(got["obj"], ref["obj"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
     assert np.array_equal(r.is_occluded(O, D), o.is_occluded(O, D)["occluded"])
     r.close()
+
+
+@pytest.mark.parametrize("name,kw", [("pretty_tlas", {"n_instances": 8}), ("pretty_tlas", {"n_instances": 3}), ("tlas_test2", {})])
+def test_tlas_copy_in_lds_equals_global_walk(name, kw, scenes, oracle_api, host_api, monkeypatch):
+    """A TLAS that fits (28 words per pair + 13 per instance <= 352) is walked in every traversal block's own LDS copy
+    (csrc/rt_scene_dev.h trace_persistent, RT_TLAS_LDS read at rt_upload_scene); larger ones and RT_TLAS_LDS=0 keep the
+    records in global memory.  Same hits, same occlusion answers, same frames, and the oracle's."""
+    out = {}
+    for lds in ("1", "0"):
+        monkeypatch.setenv("RT_TLAS_LDS", lds)
+        o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 96, 54, **kw)
+        if lds == "1":
+            O, D = random_rays(20000, 5, center=(0.5, 1.0, 2.0), spread=6.0)
+            ref = o.find_nearest(O, D)
+            occ = o.is_occluded(O, D)["occluded"]
+        got = r.find_nearest(O, D)
+        assert np.array_equal(got["obj"], ref["obj"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+        assert np.array_equal(r.is_occluded(O, D), occ)
+        frames = {}
+        for mode, n in ((host_api.RT_MODE_WHITTED, 1), (host_api.RT_MODE_PATH, 3)):
+            r.clear()
+            r.render(mode, 0, n)
+            frames[mode] = r.accumulator().copy()
+        out[lds] = frames
+        r.close()
+    for mode in out["1"]:
+        assert np.array_equal(out["1"][mode].view(np.uint32), out["0"][mode].view(np.uint32))
 
 
 def test_zero_hash_stream(scenes, oracle_api, host_api):
