@@ -270,6 +270,9 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // sub-queues when its own is empty.
 #define RT_TUNE_CULL_COUNTED 0x10000 // 'tuning' bit: a counting launch drops unreachable TLAS children like a timed one
 #define RT_HEADS 16
+#ifndef RT_SHORT_QUEUE_RAYS
+#define RT_SHORT_QUEUE_RAYS 32 // queue entries per wave below which further waves of the grid do not take part
+#endif
 #ifndef RT_FETCH_STEP
 #define RT_FETCH_STEP 0 // 1: pair and leaf records fetched by one step kind (measured: extend 27.6 -> 32.3 ms, see FETCH below)
 #endif
@@ -361,7 +364,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #endif
 	int work = -1;           // queue entry this lane is tracing, -1 = idle
 	int chunkNext = 0, chunkEnd = 0; // wave-uniform: reserved, not yet handed out
-	bool exhausted = n <= 0; // wave-uniform: the queue has no more entries
+	// A short queue does not need the whole grid: a wave beyond one per RT_SHORT_QUEUE_RAYS entries (and beyond one per
+	// head) leaves at once instead of finding every sub-queue empty one same-address atomic at a time.
+	bool exhausted = n <= 0 || (waveId >= RT_HEADS && (long long)waveId * RT_SHORT_QUEUE_RAYS >= (long long)n); // wave-uniform: the queue has no more entries (for this wave)
 	f3 O(0.0f), D(0.0f), rD(0.0f);
 	float rayT = 0;
 	uint link = RT_LINK_DONE;
