@@ -250,7 +250,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_STEPMIN_XFORM")) c->stepMinXform = atoi(getenv("RT_STEPMIN_XFORM"));
 	if (c->stepMinXform < 0 || c->stepMinXform > 15) c->stepMinXform = 0;
 	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 8; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
-	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
+	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->flags, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
 	ok = ok && hipMemset(c->flags, 0, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->counters, 2 * sizeof(DCounters)) == hipSuccess;
@@ -566,6 +566,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		HIPCHK(c, hipMemcpy(c->refitLevelStart, levelStart.data(), levelStart.size() * 4, hipMemcpyHostToDevice));
 	}
 	S.useTLAS = d->use_tlas ? 1 : 0;
+	S.stackRows = RT_STACK_ROWS_MAX;
 
 	if (d->use_tlas) {
 		std::vector<DInstance> inst(d->n_instances);
@@ -714,8 +715,14 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		S.reachOriginMax = (float)originMax;
 		S.tlasPairs = (int)tlasSlots.size();
 		S.nInst = (int)d->n_instances;
-		S.tlasLds = S.tlasPairs * 28 + S.nInst * 13 <= RT_TLAS_LDS_WORDS ? 1 : 0;
-		if (getenv("RT_TLAS_LDS")) S.tlasLds = S.tlasLds && atoi(getenv("RT_TLAS_LDS")) != 0;
+		// the split of a traversal block's LDS (rt_scene_dev.h RT_LDS_WORDS): as many stack rows as the TLAS copy leaves
+		{
+			const int words = RT_TLAS_COPY_WORDS(S.tlasPairs, S.nInst);
+			const int rows = (RT_LDS_WORDS - ((words + 3) & ~3)) / RT_BLOCK - 6;
+			S.tlasLds = rows >= RT_STACK_ROWS_MIN ? 1 : 0;
+			if (getenv("RT_TLAS_LDS")) S.tlasLds = S.tlasLds && atoi(getenv("RT_TLAS_LDS")) != 0;
+			if (S.tlasLds) S.stackRows = rows < RT_STACK_ROWS_MAX ? rows : RT_STACK_ROWS_MAX;
+		}
 	}
 	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);
 	for (uint i = 0; i < d->n_lights; i++) {
@@ -948,7 +955,7 @@ static int ensure_state(rt_ctx* c, int k, int nSlots, bool pend)
 	rt_ctx::Pool& pl = c->pools[k];
 	if (!pl.stream) HIPCHK(c, hipStreamCreate(&pl.stream));
 	if (!pl.done) HIPCHK(c, hipEventCreateWithFlags(&pl.done, hipEventDisableTiming));
-	if (!pl.spill) HIPCHK(c, hipMalloc((void**)&pl.spill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
+	if (!pl.spill) HIPCHK(c, hipMalloc((void**)&pl.spill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
 	if (pl.stateSlots >= nSlots && pl.stateLights == c->S.nLights && (pl.statePend || !pend)) { pl.P.nSlots = nSlots; return RT_OK; }
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipStreamSynchronize(pl.stream));
@@ -1153,7 +1160,7 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds, int mo
 	const bool twoStreams = mode == 2;
 	if (twoStreams && !c->sideStream) {
 		HIPCHK(c, hipStreamCreate(&c->sideStream));
-		HIPCHK(c, hipMalloc((void**)&c->sideSpill, (size_t)(RT_STACK_MAX - RT_STACK_LDS) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
+		HIPCHK(c, hipMalloc((void**)&c->sideSpill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
 		HIPCHK(c, hipEventCreateWithFlags(&c->sideFork, hipEventDisableTiming));
 		HIPCHK(c, hipEventCreateWithFlags(&c->sideJoin, hipEventDisableTiming));
 	}

@@ -61,14 +61,21 @@ namespace rtd {
 #define RT_MAX_LIGHTS 8
 
 #define RT_BLOCK 256
-#ifndef RT_STACK_LDS
-#define RT_STACK_LDS 15   // stack entries per lane held in LDS
+// A traversal block's LDS (trace_persistent): 23,040 bytes, seven blocks = 28 waves per CU of the 160 KB.  Three parts,
+// split per scene (DScene::stackRows, set at upload):
+//   [0, rows)            the top 'rows' entries of every lane's traversal stack, [entry][lane]
+//   [rows, rows + 6)     the world-space ray of a lane that is inside an instance, [component][lane]
+//   the rest             the block's copy of the TLAS (pairs, reach records, instance transforms), when it fits
+// rows = 16 without a TLAS copy; a copy takes rows away down to RT_STACK_ROWS_MIN (the 16 instances of config 5: 13 rows;
+// measured there: 13 rows cost nothing, the copy takes 4 % off the frame set); a TLAS too large for that stays in global memory.
+#define RT_LDS_WORDS 5760
+#define RT_STACK_ROWS_MAX 16
+#ifndef RT_STACK_ROWS_MIN
+#define RT_STACK_ROWS_MIN 8
 #endif
-#ifndef RT_TLAS_LDS_WORDS
-#define RT_TLAS_LDS_WORDS 352 // a block's copy of a small TLAS: per pair 16 (boxes + links) + 12 (reach) dwords, per instance 12 (invT) + 1 (root link)
-#endif
-#define RT_LDS_ROWS ((RT_STACK_LDS + 6) * RT_BLOCK)  // the stack rows, then six rows for the world-space ray of a lane that is inside an instance
-#define RT_LDS_WORDS (RT_LDS_ROWS + RT_TLAS_LDS_WORDS) // a traversal block's LDS (trace_persistent): 22,912 bytes, seven blocks per CU
+#define RT_STACK_LDS RT_STACK_ROWS_MAX // kernels with a plain LDS stack (k_sample_general)
+// words of a TLAS copy: per pair 16 (boxes + links) + 12 (reach), per instance 12 (invT rows) + 1 (root link)
+#define RT_TLAS_COPY_WORDS(pairs, instances) ((pairs) * 28 + (instances) * 13)
 #define RT_STACK_MAX 130  // tlas::Intersect's stack[64] (tlas.cpp:67) + the instance sentinel + bvh::BIntersect's own stack[64]
                           // (bvh.cpp:608) live on ONE stack here; whatever the reference can traverse fits
 
@@ -115,7 +122,8 @@ struct DScene {
 	float reachOriginMax; // reach[] boxes are inflated for world ray origins with |O|_1 up to this
 	int tlasPairs; // number of TLAS pair records
 	int nInst;     // instances
-	int tlasLds;   // the TLAS (pairs, reach records, instance transforms) fits RT_TLAS_LDS_WORDS: every traversal block walks its own LDS copy
+	int tlasLds;   // every traversal block walks its own LDS copy of the TLAS (pairs, reach records, instance transforms)
+	int stackRows; // stack entries per lane kept in LDS (the split of the block's LDS, see RT_LDS_WORDS)
 	int useTLAS;
 	int nBruteSph, nBrutePla;
 	int nLights;
@@ -130,7 +138,7 @@ struct LaneCounters {
 	__device__ __forceinline__ void clear() { inner = prim = tlasInner = inst = brute = light = 0; }
 };
 
-// Per-lane traversal stack: entries [0, RT_STACK_LDS) live in LDS laid out [entry][lane] (one
+// Per-lane traversal stack: entries [0, rows) live in LDS laid out [entry][lane] (one
 // bank per lane, conflict free), deeper entries spill to a per-lane column of a global buffer
 // laid out [entry][global lane].  Depth is capped at the reference's 64.
 // The two halves are typed by address space: with generic pointers the compiler folds "LDS or spill" into ONE
@@ -145,13 +153,14 @@ struct Stack {
 	lds_uint* lds;    // &ldsStack[0][threadIdx.x]
 	glb_uint* spill;  // &spill[0][global lane]
 	uint spillStride; // lanes in the grid
+	uint rows;        // entries held in LDS
 	uint sp;
 	int* overflow;
 	__device__ __forceinline__ void push(uint v)
 	{
 		RT_CHECK(sp <= RT_STACK_MAX, 1, overflow);
-		if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v;
-		else if (sp < RT_STACK_MAX) spill[(size_t)(sp - RT_STACK_LDS) * spillStride] = v;
+		if (sp < rows) lds[sp * RT_BLOCK] = v;
+		else if (sp < RT_STACK_MAX) spill[(size_t)(sp - rows) * spillStride] = v;
 		else { *overflow = 1; sp = 0; return; } // reported as RT_E_OVERFLOW by the host; the ray ends at its next pop instead of walking a wrong stack
 		sp++;
 	}
@@ -159,14 +168,15 @@ struct Stack {
 	{
 		RT_CHECK(sp >= 1 && sp <= RT_STACK_MAX, 2, overflow);
 		sp--;
-		if (sp < RT_STACK_LDS) return lds[sp * RT_BLOCK];
-		return spill[(size_t)(sp - RT_STACK_LDS) * spillStride];
+		if (sp < rows) return lds[sp * RT_BLOCK];
+		return spill[(size_t)(sp - rows) * spillStride];
 	}
 };
 
-__device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* overflow)
+__device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* overflow, uint rows = RT_STACK_ROWS_MAX)
 {
 	Stack st;
+	st.rows = rows;
 	st.lds = (lds_uint*)ldsBase + threadIdx.x;
 	st.spillStride = gridDim.x * blockDim.x;
 	st.spill = (glb_uint*)spill + (blockIdx.x * blockDim.x + threadIdx.x);
@@ -331,14 +341,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	int tried = 0;                  // sub-queues found empty since the last successful reservation
 	int chunk = subLen / (wavesPerHead * 2); // size of the next reservation
 	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= RT_CHUNK_MIN ? RT_CHUNK_MIN : (chunk & ~(RT_CHUNK_MIN - 1)));
-	Stack st = make_stack(ldsStack, spill, overflow);
-	// the world-space ray while the lane walks a BLAS: rows [RT_STACK_LDS, RT_STACK_LDS + 6) of the block's LDS, [row][lane]
-	lds_uint* const worldRay = (lds_uint*)ldsStack + RT_STACK_LDS * RT_BLOCK + threadIdx.x;
+	const uint stackRows = (uint)S.stackRows;
+	Stack st = make_stack(ldsStack, spill, overflow, stackRows);
+	// the world-space ray while the lane walks a BLAS: rows [stackRows, stackRows + 6) of the block's LDS, [row][lane]
+	lds_uint* const worldRay = (lds_uint*)ldsStack + stackRows * RT_BLOCK + threadIdx.x;
 	// A small TLAS is walked in LDS.  The traversal is bound by the vector-memory path (lane accesses through the
 	// texture addresser and L1); a TLAS visit is seven of them (pair + reach record) and an
 	// instance entry four, together a quarter of all accesses on the bench scene; ds_read takes another pipe.
 	// Layout: [pair][4] | [pair][3] reach | [instance][3] invT rows 0-2 | [instance] root link (rootWide for the wide walk)
-	lds_v4f* const tlasL = (lds_v4f*)((lds_uint*)ldsStack + RT_LDS_ROWS);
+	lds_v4f* const tlasL = (lds_v4f*)((lds_uint*)ldsStack + (stackRows + 6) * RT_BLOCK);
 	if (S.tlasLds) {
 		const int nP = S.tlasPairs * 4, nR = S.tlasPairs * 3, nI = S.nInst * 3;
 		for (int i = (int)threadIdx.x; i < nP + nR + nI; i += RT_BLOCK) {
