@@ -421,10 +421,12 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	// 4-wide nodes (rt_scene_dev.h, wide[]): collapse every BLAS; all or nothing (one flag for the kernels)
 	std::vector<float> wide;
 	std::vector<uint> rootWide(d->n_blas);
-	// Off unless RT_WIDE=1: exact (tests/test_gpu_parity.py::test_wide_walk_*), but measured 6 % SLOWER than the binary
-	// walk on the bench scene (connect 11.2 -> 11.9 ms per step; 12.9 without the distance sort): four slab tests, a
-	// sorting network and up to three pushes per step cost more issue slots than the halved fetch chain returns.
-	bool wideOK = getenv("RT_WIDE") ? atoi(getenv("RT_WIDE")) != 0 : false;
+	// Default: on for a scene BVH, off with a TLAS (RT_WIDE=0 / 1 forces).  Exact either way (tests/test_gpu_parity.py::
+	// test_wide_walk_*).  Measured (profiles/r02_wide_by_config.txt): one big tree gains (config 4: connect 19.3 -> 16.3 ms
+	// per step, config 2: 2.63 -> 2.47), instanced scenes lose or stay level (config 5: 625 -> 660 ms, config 3: 10.1 -> 10.2):
+	// there the walk spends its steps on the TLAS level and the first levels of many BLASes, where a 4-wide step
+	// replaces fewer binary ones than it costs (four slab tests, a sorting network and up to three pushes).
+	bool wideOK = getenv("RT_WIDE") ? atoi(getenv("RT_WIDE")) != 0 : !d->use_tlas;
 	{
 		size_t primBase = 0;
 		for (uint k = 0; k < d->n_blas && wideOK; k++) {
