@@ -322,7 +322,7 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // WIDE == true (occlusion queries only, never counting launches): inside a BLAS / the scene BVH the walk uses the
 // 4-wide nodes (wide[], see the layout notes above); a ray that is not clean is given back through
 // pol.leftover(work) for the binary walk.  The TLAS level keeps its pair records and reach test.
-template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false, bool WIDE = false>
+template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false, bool WIDE = false, int REPEAT = RT_PAIR_REPEAT>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
@@ -527,7 +527,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		// dependent chains of the last rays (the drain of the launch), so every wanted kind runs in every iteration.
 		const int stepMin = exhausted ? 1 : stepMinBusy, pairAgain = exhausted ? 1 : pairAgainBusy, stepMinXform = exhausted ? 1 : stepMinXformBusy;
 #pragma unroll
-		for (int rep = 0; rep < RT_PAIR_REPEAT; rep++) {
+		for (int rep = 0; rep < REPEAT; rep++) {
 			const uint lk = link;
 			const bool live = work >= 0 && lk != RT_LINK_DONE;
 			const bool wantPair = live && !(lk & (RT_LEAF_BIT | RT_INST_BIT));
