@@ -72,6 +72,7 @@ struct rt_ctx {
 	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
 	int refillAny = 24; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int pairAgain = 16; // lanes that must still want a pair step for an iteration to repeat it (RT_PAIRAGAIN); tuning bits 20-26
+	int stepMinAny = 8, pairAgainAny = 16; // the any-hit kernel's RT_STEPMIN / RT_PAIRAGAIN (RT_STEPMIN_ANY, RT_PAIRAGAIN_ANY)
 	int stepMinXform = 0; // RT_STEPMIN_XFORM: lanes that must want an instance entry / exit before it runs (0: the same as RT_STEPMIN)
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
@@ -249,7 +250,9 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (c->pairAgain < 1 || c->pairAgain > 65) c->pairAgain = 16;
 	if (getenv("RT_STEPMIN_XFORM")) c->stepMinXform = atoi(getenv("RT_STEPMIN_XFORM"));
 	if (c->stepMinXform < 0 || c->stepMinXform > 15) c->stepMinXform = 0;
-	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 8; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8; }
+	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 8; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8;
+	  c->stepMinAny = getenv("RT_STEPMIN_ANY") ? atoi(getenv("RT_STEPMIN_ANY")) : sm; if (c->stepMinAny < 0 || c->stepMinAny > 64) c->stepMinAny = sm;
+	  c->pairAgainAny = getenv("RT_PAIRAGAIN_ANY") ? atoi(getenv("RT_PAIRAGAIN_ANY")) : c->pairAgain; if (c->pairAgainAny < 1 || c->pairAgainAny > 65) c->pairAgainAny = c->pairAgain; }
 	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->flags, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
 	ok = ok && hipMemset(c->flags, 0, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
@@ -1010,7 +1013,8 @@ static int slot_budget();
 // walk handed back because they are not clean.
 static void launch_connect(rt_ctx* c, hipStream_t st, const PathState& P, const Queues& Q, int parity, uint* spill)
 {
-	const int tun = tuning(c, (c->refillMin & ~0xFF) | c->refillAny);
+	// the any-hit walk has its own thresholds (RT_REFILL_ANY, RT_STEPMIN_ANY, RT_PAIRAGAIN_ANY)
+	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27);
 	if (c->counting) hipLaunchKernelGGL((k_connect<true>), dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
 	else if (!c->S.wide) hipLaunchKernelGGL((k_connect<false>), dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
 	else {
