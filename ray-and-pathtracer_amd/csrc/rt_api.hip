@@ -68,6 +68,7 @@ struct rt_ctx {
 	// traversal stack spill of pool 0 and of the batch queries + flags
 	uint* spill = nullptr;
 	int gridBlocks = 0;
+	std::vector<int> matTypes; // material types of the uploaded scene (measurement builds)
 	int gridExtend = 0, gridConnect = 0, gridQuery = 0, gridTraverse = 0, gridConnectWide = 0, gridLeftover = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
 	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
 	int refillAny = 24; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
@@ -167,6 +168,48 @@ static void tail_probe_print(hipStream_t st, const char* what, int round)
 }
 #endif
 
+#ifdef RT_STEP_COUNT
+// measurement build only: steps per nearest-hit ray of every extend launch of the plain round loop, by the material
+// type of the hit the ray left from (previous round's hit record) -- which rays are the long ones?
+static uint* g_stepBuf = nullptr;
+static size_t g_stepCap = 0;
+static void step_count_begin(rt_ctx* c, hipStream_t st, int nSlots)
+{
+	if (g_stepCap < (size_t)nSlots) { if (g_stepBuf) (void)hipFree(g_stepBuf); (void)hipMalloc((void**)&g_stepBuf, (size_t)nSlots * 4); g_stepCap = (size_t)nSlots; }
+	(void)hipMemsetAsync(g_stepBuf, 0xFF, (size_t)nSlots * 4, st);
+	(void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_stepOut), &g_stepBuf, sizeof(g_stepBuf), 0, hipMemcpyHostToDevice, st);
+}
+static void step_count_print(rt_ctx* c, hipStream_t st, const PathState& P, int parity, int round, const std::vector<int>& matType)
+{
+	(void)hipStreamSynchronize(st);
+	const int n = P.nSlots;
+	std::vector<uint> steps((size_t)n);
+	std::vector<int2> prevHit((size_t)n);
+	(void)hipMemcpy(steps.data(), g_stepBuf, (size_t)n * 4, hipMemcpyDeviceToHost);
+	(void)hipMemcpy(prevHit.data(), P.hitId[1 - parity], (size_t)n * 8, hipMemcpyDeviceToHost);
+	std::vector<uint> v;
+	double sum = 0;
+	unsigned long long byType[8] = { 0 }, longByType[8] = { 0 }, stepsByType[8] = { 0 }, byEnt[12] = { 0 }, longByEnt[12] = { 0 }, stepsByEnt[12] = { 0 };
+	for (int i = 0; i < n; i++) {
+		if (steps[(size_t)i] == 0xFFFFFFFFu) continue;
+		{ const uint e = std::min(11u, steps[(size_t)i] >> 16); steps[(size_t)i] &= 0xFFFFu; byEnt[e]++, stepsByEnt[e] += steps[(size_t)i]; if (steps[(size_t)i] > 150) longByEnt[e]++; }
+		v.push_back(steps[(size_t)i]);
+		sum += steps[(size_t)i];
+		int t = 7; // 7: no previous hit record (round 0)
+		if (round > 0) { const int m = prevHit[(size_t)i].y; t = m >= 0 && m < (int)matType.size() ? matType[(size_t)m] & 3 : 6; }
+		byType[t]++, stepsByType[t] += steps[(size_t)i];
+		if (steps[(size_t)i] > 150) longByType[t]++;
+	}
+	if (v.empty()) return;
+	std::sort(v.begin(), v.end());
+	auto q = [&](double f) { return v[(size_t)std::min<double>((double)v.size() - 1, f * (double)v.size())]; };
+	fprintf(stderr, "step count extend round %d: %zu rays, mean %.1f, p50 %u p90 %u p99 %u p99.9 %u p99.99 %u max %u\n", round, v.size(), sum / (double)v.size(), q(0.5), q(0.9), q(0.99), q(0.999), q(0.9999), v.back());
+	for (int e = 0; e < 12; e++)
+		if (byEnt[e]) fprintf(stderr, "   %d instance entries: %llu rays (%.2f %%), mean %.1f steps, %llu with > 150 steps (%.2f %% of them)\n", e, byEnt[e], 100.0 * (double)byEnt[e] / (double)v.size(), (double)stepsByEnt[e] / (double)byEnt[e], longByEnt[e], 100.0 * (double)longByEnt[e] / (double)byEnt[e]);
+	for (int t = 0; t < 8; t++)
+		if (byType[t]) fprintf(stderr, "   left a surface of type %d: %llu rays (%.1f %%), mean %.1f steps, %llu with > 150 steps (%.2f %% of them)\n", t, byType[t], 100.0 * (double)byType[t] / (double)v.size(), (double)stepsByType[t] / (double)byType[t], longByType[t], 100.0 * (double)longByType[t] / (double)byType[t]);
+}
+#endif
 #ifdef RT_SECTION_PROBE
 // measurement build only: per traversal launch of the plain round loop, the waves' cycles by section (rt_scene_dev.h)
 static void section_probe_reset(hipStream_t st)
@@ -747,6 +790,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		o.type = m.type, o.raytracer = m.raytracer, o.specu = m.specu, o.diffu = m.diffu, o.shinieness = m.shinieness, o.N = m.N, o.ir = m.ir;
 		memcpy(o.col, m.col, 12), memcpy(o.albedo, m.albedo, 12), memcpy(o.absorption, m.absorption, 12);
 	}
+	c->matTypes.clear();
+	for (size_t i = 0; i < mats.size(); i++) c->matTypes.push_back(mats[i].type);
 	DMaterial* dm = nullptr;
 	HIPCHK(c, dalloc(c->sceneAllocs, &dm, mats.size()));
 	HIPCHK(c, hipMemcpy(dm, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
@@ -1068,6 +1113,9 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 #ifdef RT_SECTION_PROBE
 			section_probe_reset(st);
 #endif
+#ifdef RT_STEP_COUNT
+			step_count_begin(c, st, P[k].nSlots);
+#endif
 			prof_begin(c, K_EXTEND, st);
 			{
 				auto extendKernel = c->counting ? (allActive ? k_extend<true, true> : k_extend<true, false>) : (allActive ? k_extend<false, true> : k_extend<false, false>);
@@ -1079,6 +1127,9 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 #endif
 #ifdef RT_SECTION_PROBE
 			section_probe_print(st, "extend", round);
+#endif
+#ifdef RT_STEP_COUNT
+			step_count_print(c, st, P[k], parity, round, c->matTypes);
 #endif
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, Rs[k], P[k], Q, parity, round == 0 && Rs[k].finishInline ? 1 : 0);

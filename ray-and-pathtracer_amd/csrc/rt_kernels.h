@@ -453,6 +453,7 @@ struct ExtendPolicy {
 		unpack_head(__float_as_uint(d4.w), head);
 		return true;
 	}
+	__device__ __forceinline__ int slot_of(int work) const { return DENSE ? work : (int)queue[work]; }
 	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
 	{
 		// the ray in registers may be the object-space one; the sphere normal needs the world ray
@@ -985,6 +986,7 @@ struct ArrayRays {
 };
 struct NearestQueryPolicy : ArrayRays {
 	const DScene& S; QueryHit* out;
+	__device__ __forceinline__ int slot_of(int i) const { return i; }
 	__device__ __forceinline__ NearestQueryPolicy(const DScene& s, const float* o, const float* d, const float* t, QueryHit* q) : ArrayRays{ o, d, t }, S(s), out(q) {}
 	__device__ __forceinline__ void store(int i, const HitRef& hit, const f3&, const f3&) const
 	{
@@ -1010,6 +1012,7 @@ struct OccludedQueryPolicy : ArrayRays {
 // Camera::GetPrimaryRay + Scene::FindNearest for every pixel
 struct PrimaryPolicy {
 	const DScene& S; const DCamera& C; int* objOut; float* tOut;
+	__device__ __forceinline__ int slot_of(int i) const { return i; }
 	__device__ __forceinline__ bool load(int i, f3& O, f3& D, float& tm, HitRef&) const { primary_ray(C, i % C.width, i / C.width, O, D); tm = 1e34f; return true; }
 	__device__ __forceinline__ void store(int i, const HitRef& hit, const f3&, const f3&) const
 	{

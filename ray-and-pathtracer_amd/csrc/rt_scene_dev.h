@@ -300,6 +300,10 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // [0] first wave in, [1] first wave that finds every sub-queue empty, [2] last wave out (s_memrealtime, 100 MHz)
 __device__ unsigned long long g_tailProbe[4];
 #endif
+#ifdef RT_STEP_COUNT
+// measurement build: steps per nearest-hit ray, written per work item at flush time (profiles/step_histogram.sh)
+__device__ uint* g_stepOut;
+#endif
 #ifdef RT_SECTION_PROBE
 // measurement build: where do a traversal wave's cycles go?  Shader-clock cycles per section, summed over all waves:
 // [0] flush + refill  [1] pair: loads issued -> data there  [2] pair: arithmetic + stack  [3] leaf: wait  [4] leaf: rest
@@ -373,6 +377,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	if (lane < 16) secAcc[lane] = 0;
 	const unsigned long long secStart = RT_SEC_NOW();
 #endif
+#ifdef RT_STEP_COUNT
+	uint nsteps = 0, nenter = 0;
+#endif
 	int work = -1;           // queue entry this lane is tracing, -1 = idle
 	int chunkNext = 0, chunkEnd = 0; // wave-uniform: reserved, not yet handed out
 	// A short queue does not need the whole grid: a wave beyond one per RT_SHORT_QUEUE_RAYS entries (and beyond one per
@@ -437,6 +444,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				RT_SEC_COUNT(13);
 				if (doneLane) {
 					RT_CHECK(work >= 0 && work < n && st.sp <= RT_STACK_MAX, 4, overflow);
+#ifdef RT_STEP_COUNT
+					if constexpr (!ANY && !MIXED) { if (g_stepOut) g_stepOut[pol.slot_of(work)] = (nsteps & 0xFFFFu) | (nenter << 16); }
+					nsteps = 0, nenter = 0;
+#endif
 					// results are written here, many lanes at a time, not one lane per iteration
 					if constexpr (MIXED) {
 						if (laneAny) pol.store(work, hit.kind == 1);
@@ -545,6 +556,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				}
 			} else if (nP < pairAgain) break;
 			if (wantFetch) {
+#ifdef RT_STEP_COUNT
+				nsteps++;
+#endif
 				// one sibling pair: of the BLAS (bvh.cpp:638-654 / :788-804) or, outside an instance in TLAS
 				// mode, of the TLAS (tlas.cpp:77-91 / :106-120) -- same test, same ordering rule
 				if (COUNT && wantPair) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
@@ -670,6 +684,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			continue;
 		}
 
+#ifdef RT_STEP_COUNT
+		if ((runLeaf && wantLeaf) || (runEnter && wantEnter) || (runExit && wantExit)) nsteps++;
+		if (runEnter && wantEnter) nenter++;
+#endif
 		if (runLeaf && wantLeaf) {
 			// a leaf step of its own (the wide walk): all four vectors of the record in one go (nearly every record is a triangle)
 			const float4* rec = S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT);
