@@ -585,9 +585,10 @@ def test_deep_tree_uses_the_spill_stack(oracle_api, host_api):
 
 @pytest.mark.parametrize("name,kw", [("pretty_tlas", {"n_instances": 8}), ("pretty_tlas", {"n_instances": 3}), ("tlas_test2", {})])
 def test_tlas_copy_in_lds_equals_global_walk(name, kw, scenes, oracle_api, host_api, monkeypatch):
-    """A TLAS that fits (28 words per pair + 13 per instance <= 352) is walked in every traversal block's own LDS copy
-    (csrc/rt_scene_dev.h trace_persistent, RT_TLAS_LDS read at rt_upload_scene); larger ones and RT_TLAS_LDS=0 keep the
-    records in global memory.  Same hits, same occlusion answers, same frames, and the oracle's."""
+    """A TLAS that leaves at least 8 stack rows of a traversal block's LDS (28 words per pair + 13 per instance; ~50
+    instances) is walked in every block's own LDS copy (csrc/rt_scene_dev.h trace_persistent, RT_TLAS_LDS read at
+    rt_upload_scene); larger ones and RT_TLAS_LDS=0 keep the records in global memory.  Same hits, same occlusion
+    answers, same frames, and the oracle's."""
     out = {}
     for lds in ("1", "0"):
         monkeypatch.setenv("RT_TLAS_LDS", lds)
