@@ -217,9 +217,10 @@ def roofline_block(args, ha, near, avg_ms, launches_per_step, W, H, spp, world, 
         pj = json.load(open(ppath))
     except Exception:
         pj = None
-    if W * H * spp // world < (100 << 20):
-        rb["note"] = ("per-rank batches below 100 M samples run extend(r + 1) beside connect(r) + light(r) on a second stream (DESIGN.md "
-                      "findings 19, 33): the kernel times of kernel_ms_per_step overlap and do not add up to the step")
+    if os.environ.get("RT_FUSE", "2") != "0":
+        rb["note"] = ("path batches run extend(r + 1) beside connect(r) + light(r) on a second stream (DESIGN.md findings 19, 33): the kernel "
+                      "times of kernel_ms_per_step overlap and do not add up to the step; avg_launch_ms is the extend launches' own duration "
+                      "with that company (RT_FUSE=0: one kernel at a time)")
     usable = (pj is not None and pj.get("kernel_hash") == kernel_hash() and world == 1 and
               pj.get("workload") == [args.workload, W, H, spp])
     rb["pmc"] = {"file": "profiles/roofline_pmc.json", "used": bool(usable), "kernel_hash": kernel_hash(),

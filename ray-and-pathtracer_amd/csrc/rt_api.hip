@@ -56,13 +56,15 @@ struct rt_ctx {
 		hipStream_t stream = nullptr; // pool 0 runs on the context's stream
 		uint* spill = nullptr;
 		hipEvent_t done = nullptr;
+		// the second stream of the two-stream round loop (run_rounds_fused, RT_FUSE=2): connect(r) + light(r) beside extend(r + 1)
+		hipStream_t sideStream = nullptr;
+		uint* sideSpill = nullptr;
+		hipEvent_t sideFork = nullptr, sideJoin = nullptr;
 	};
 	Pool pools[RT_MAX_POOLS];
-	int fuseTraversal = -1;  // one traversal launch per round (run_rounds_fused): -1 for batches under RT_FUSE_MAX samples, RT_FUSE=0 / 1 forces;
-	                         // RT_FUSE=2: the same round structure with extend(r + 1) and connect(r) + light(r) as separate kernels on two streams
-	hipStream_t sideStream = nullptr;
-	uint* sideSpill = nullptr;
-	hipEvent_t sideFork = nullptr, sideJoin = nullptr;
+	int fuseTraversal = -1;  // RT_FUSE: how extend(r + 1) and connect(r) share a round (run_rounds_fused): -1 / 2 two kernels on two
+	                         // streams, 1 one launch (k_traverse), 0 the plain loop (run_rounds)
+
 	int nPoolsWanted = 1; // RT_POOLS; measured: 2 pools overlap their kernels but do not shorten the frame
 	hipEvent_t fork = nullptr;
 	// traversal stack spill of pool 0 and of the batch queries + flags
@@ -331,10 +333,13 @@ void rt_destroy(rt_ctx* c)
 		free_pool(pl.allocs);
 	}
 	if (c->fork) (void)hipEventDestroy(c->fork);
-	if (c->sideStream) { (void)hipStreamSynchronize(c->sideStream); (void)hipStreamDestroy(c->sideStream); }
-	if (c->sideSpill) (void)hipFree(c->sideSpill);
-	if (c->sideFork) (void)hipEventDestroy(c->sideFork);
-	if (c->sideJoin) (void)hipEventDestroy(c->sideJoin);
+	for (int k = 0; k < RT_MAX_POOLS; k++) {
+		rt_ctx::Pool& pl = c->pools[k];
+		if (pl.sideStream) { (void)hipStreamSynchronize(pl.sideStream); (void)hipStreamDestroy(pl.sideStream); }
+		if (pl.sideSpill) (void)hipFree(pl.sideSpill);
+		if (pl.sideFork) (void)hipEventDestroy(pl.sideFork);
+		if (pl.sideJoin) (void)hipEventDestroy(pl.sideJoin);
+	}
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
 	if (c->samples) (void)hipFree(c->samples);
@@ -1193,109 +1198,125 @@ static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRoun
 	return RT_OK;
 }
 
-// Path mode with a slot per sample and one pool: exactly 'rounds' rounds, nothing to resume, no finish pass.  The
-// only consumer of connect(r) is light(r), and extend(r + 1) needs neither, so the two share ONE traversal launch per
-// round: one work list for k_traverse (rt_kernels.h), one drain per round instead of two (a persistent traversal
-// launch ends several hundred microseconds after its queue ran dry, whatever the queue held).  light(r) runs after
-// it and still needs the hit of round r while the launch writes the hits of round r + 1: hitN / hitId are double
-// buffered by round parity like the rays.  Measured (1080p): 8 spp batch 11.3 -> 10.2 ms (10.3 -> 9.7 with the drain
-// change of trace_persistent), 16 spp 17.5 -> 17.1, 32 spp 31.8 -> 31.9, 64 spp batch 60.1 -> 60.7
-// (in full waves the mixed nearest / any-hit lanes cost more than the drains), so it is used for batches under
-// RT_FUSE_MAX samples -- the per-GPU share of a multi-GPU frame.  Not used by counting launches (their tallies are
-// kept per kind of query).
-//   generate | begin extend(0) shade(0) cs(0) | begin ca(1) traverse{extend(1), connect(0)} light(0) shade(1) cs(1) | ...
+// Path mode with a slot per sample: exactly 'rounds' rounds, nothing to resume, no finish pass.  The only consumer of
+// connect(r) is light(r), and extend(r + 1) needs neither, so the two overlap: mode 2 (default) runs connect(r) and
+// light(r) on the pool's second stream beside extend(r + 1) -- each kernel's drain (a persistent traversal launch ends
+// several hundred microseconds after its queue ran dry, whatever the queue held) is covered by the other's work; mode 1
+// puts both kinds of rays into ONE launch over one work list (k_traverse; loses on large batches: waves that mix
+// nearest and any-hit lanes).  light(r) still needs the hit of round r while extend(r + 1) writes the hits of round
+// r + 1: hitN / hitId are double buffered by round parity like the rays.  Not used by counting launches (their
+// tallies are kept per kind of query).  Several pools (RT_POOLS) take turns round by round; measured slower than one.
+//   generate | begin extend(0) shade(0) cs(0) | begin ca(1) {extend(1) || connect(0) light(0)} shade(1) cs(1) | ...
 //   ... | connect(R-1) light(R-1)
-static int run_rounds_fused(rt_ctx* c, const RenderParams& R, int rounds, int mode)
+static int run_rounds_fused(rt_ctx* c, const RenderParams* Rs, int nPools, int rounds, int mode)
 {
-	rt_ctx::Pool& pl = c->pools[0];
 	const float t_min = 0.001f; // renderer.cpp:131
 	const int grid = c->gridBlocks;
-	PathState P = pl.P;
-	P.pend = nullptr, P.pendCount = nullptr;
-	const Queues Q = pl.Q;
-	hipStream_t st = pl.stream;
 	const bool twoStreams = mode == 2;
-	if (twoStreams && !c->sideStream) {
-		HIPCHK(c, hipStreamCreate(&c->sideStream));
-		HIPCHK(c, hipMalloc((void**)&c->sideSpill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
-		HIPCHK(c, hipEventCreateWithFlags(&c->sideFork, hipEventDisableTiming));
-		HIPCHK(c, hipEventCreateWithFlags(&c->sideJoin, hipEventDisableTiming));
+	PathState Ps[RT_MAX_POOLS];
+	// pools start after everything already queued on the context's stream
+	HIPCHK(c, hipEventRecord(c->fork, c->stream));
+	for (int k = 0; k < nPools; k++) {
+		rt_ctx::Pool& pl = c->pools[k];
+		Ps[k] = pl.P;
+		Ps[k].pend = nullptr, Ps[k].pendCount = nullptr;
+		if (k > 0) HIPCHK(c, hipStreamWaitEvent(pl.stream, c->fork, 0));
+		if (twoStreams && !pl.sideStream) {
+			HIPCHK(c, hipStreamCreate(&pl.sideStream));
+			HIPCHK(c, hipMalloc((void**)&pl.sideSpill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
+			HIPCHK(c, hipEventCreateWithFlags(&pl.sideFork, hipEventDisableTiming));
+			HIPCHK(c, hipEventCreateWithFlags(&pl.sideJoin, hipEventDisableTiming));
+		}
+		prof_begin(c, K_GENERATE, pl.stream);
+		hipLaunchKernelGGL(k_generate, dim3((Ps[k].nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, pl.stream, c->S, c->C, Rs[k], Ps[k], pl.Q);
+		prof_end(c, pl.stream);
 	}
-	prof_begin(c, K_GENERATE, st);
-	hipLaunchKernelGGL(k_generate, dim3((P.nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q);
-	prof_end(c, st);
 	for (int round = 0; round <= rounds; round++) {
 		const int parity = round & 1;
-		bool lightDone = false;
-		if (round == 0) {
-			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, P.nSlots, 3);
-			prof_begin(c, K_EXTEND, st);
-			hipLaunchKernelGGL((k_extend<false, true>), dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
-			prof_end(c, st);
-		} else if (round < rounds) {
-			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
-			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
-			if (twoStreams) {
-				// connect(r - 1) and light(r - 1) on the side stream, extend(r) here: two kernels, each with its own kind of lanes
-				hipStream_t sb = c->sideStream;
-				HIPCHK(c, hipEventRecord(c->sideFork, st));
-				HIPCHK(c, hipStreamWaitEvent(sb, c->sideFork, 0));
-				prof_begin(c, K_CONNECT, sb);
-				launch_connect(c, sb, P, Q, 1 - parity, c->sideSpill);
-				prof_end(c, sb);
-				prof_begin(c, K_SHADE, sb);
-				hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, sb, c->S, R, P, Q, 1 - parity);
-				prof_end(c, sb);
-				HIPCHK(c, hipEventRecord(c->sideJoin, sb));
+		for (int k = 0; k < nPools; k++) {
+			rt_ctx::Pool& pl = c->pools[k];
+			const PathState& P = Ps[k];
+			const Queues Q = pl.Q;
+			const RenderParams& R = Rs[k];
+			hipStream_t st = pl.stream;
+			bool lightDone = false;
+			if (round == 0) {
+				hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, P.nSlots, 3);
 				prof_begin(c, K_EXTEND, st);
-				hipLaunchKernelGGL((k_extend<false, false>), dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
+				hipLaunchKernelGGL((k_extend<false, true>), dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
 				prof_end(c, st);
-				HIPCHK(c, hipStreamWaitEvent(st, c->sideJoin, 0));
-				lightDone = true;
+			} else if (round < rounds) {
+				hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
+				hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
+				if (twoStreams) {
+					// connect(r - 1) and light(r - 1) on the side stream, extend(r) here: two kernels, each with its own kind of lanes
+					hipStream_t sb = pl.sideStream;
+					HIPCHK(c, hipEventRecord(pl.sideFork, st));
+					HIPCHK(c, hipStreamWaitEvent(sb, pl.sideFork, 0));
+					prof_begin(c, K_CONNECT, sb);
+					launch_connect(c, sb, P, Q, 1 - parity, pl.sideSpill);
+					prof_end(c, sb);
+					prof_begin(c, K_SHADE, sb);
+					hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, sb, c->S, R, P, Q, 1 - parity);
+					prof_end(c, sb);
+					HIPCHK(c, hipEventRecord(pl.sideJoin, sb));
+					prof_begin(c, K_EXTEND, st);
+					hipLaunchKernelGGL((k_extend<false, false>), dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
+					prof_end(c, st);
+					HIPCHK(c, hipStreamWaitEvent(st, pl.sideJoin, 0));
+					lightDone = true;
+				} else {
+					prof_begin(c, K_EXTEND, st);
+					hipLaunchKernelGGL(k_traverse, dim3(c->gridTraverse), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill);
+					prof_end(c, st);
+				}
 			} else {
-				prof_begin(c, K_EXTEND, st);
-				hipLaunchKernelGGL(k_traverse, dim3(c->gridTraverse), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill);
+				// the shadow rays of the last round have no extend to share a launch with
+				hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
+				prof_begin(c, K_CONNECT, st);
+				launch_connect(c, st, P, Q, 1 - parity, pl.spill);
 				prof_end(c, st);
 			}
-		} else {
-			// the shadow rays of the last round have no extend to share a launch with
-			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
-			prof_begin(c, K_CONNECT, st);
-			launch_connect(c, st, P, Q, 1 - parity, pl.spill);
-			prof_end(c, st);
-		}
-		if (round > 0 && !lightDone) {
-			prof_begin(c, K_SHADE, st);
-			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, R, P, Q, 1 - parity);
-			prof_end(c, st);
-		}
-		if (round < rounds) {
-			prof_begin(c, K_SHADE, st);
-			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q, parity, round == 0 ? 1 : 0);
-			prof_end(c, st);
-			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 0, 0, 2);
-			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
+			if (round > 0 && !lightDone) {
+				prof_begin(c, K_SHADE, st);
+				hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, R, P, Q, 1 - parity);
+				prof_end(c, st);
+			}
+			if (round < rounds) {
+				prof_begin(c, K_SHADE, st);
+				hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q, parity, round == 0 ? 1 : 0);
+				prof_end(c, st);
+				hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 0, 0, 2);
+				hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
+			}
 		}
 	}
-	HIPCHK(c, hipMemcpyAsync(c->hostCounts, Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-	HIPCHK(c, hipStreamSynchronize(st));
-	const int* hc = c->hostCounts;
 	int rc = RT_OK;
-	if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
-	else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
-	else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
-	if (hc[3] != 0) (void)hipMemsetAsync(Q.counts + 3, 0, sizeof(int), st);
+	for (int k = 0; k < nPools; k++) HIPCHK(c, hipMemcpyAsync(c->hostCounts + 16 * k, c->pools[k].Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->pools[k].stream));
+	for (int k = 0; k < nPools; k++) {
+		HIPCHK(c, hipStreamSynchronize(c->pools[k].stream));
+		const int* hc = c->hostCounts + 16 * k;
+		if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+		else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
+		else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
+		if (hc[3] != 0) (void)hipMemsetAsync(c->pools[k].Q.counts + 3, 0, sizeof(int), c->pools[k].stream);
+	}
+	// join: the context's stream continues after every pool
+	for (int k = 1; k < nPools; k++) {
+		(void)hipEventRecord(c->pools[k].done, c->pools[k].stream);
+		(void)hipStreamWaitEvent(c->stream, c->pools[k].done, 0);
+	}
 	if (rc != RT_OK) return rc;
 	HIPCHK(c, hipGetLastError());
 	return RT_OK;
 }
 
 // Which round loop a path batch with a slot per sample takes: 0 the plain one (run_rounds), 1 extend(r + 1) and connect(r)
-// as ONE launch (k_traverse), 2 as two kernels on two streams.  Measured (r02_ab_fuse2.txt): 2 beats 1 at every size
-// (1/8 frame 9.22 -> 9.02 ms) and 0 up to half a frame (32 spp: 29.1 -> 28.5 ms); on the full frame 0 and 2 are level,
-// and 0 keeps the per-kernel times of bench.py's roofline block free of overlap.
-#define RT_FUSE_MAX ((size_t)100 << 20)
-static int fuse_mode(const rt_ctx* c, size_t samples) { return c->counting ? 0 : (c->fuseTraversal < 0 ? (samples < RT_FUSE_MAX ? 2 : 0) : c->fuseTraversal); }
+// as ONE launch (k_traverse), 2 as two kernels on two streams (the default).  Measured (r02_ab_fuse2.txt, r02_ab_fuse3.txt):
+// 2 beats 1 at every size (1/8 frame 9.22 -> 9.02 ms) and 0 up to the full frame (32 spp: 29.1 -> 28.5 ms, 64 spp:
+// 54.4 -> 53.3 ms); config 5's 132 M-sample batches are level (2.96 s either way).  With 2 the kernel times bench.py
+// reports per kind overlap (RT_FUSE=0 for unoverlapped ones).
+static int fuse_mode(const rt_ctx* c, size_t /*samples*/) { return c->counting ? 0 : (c->fuseTraversal < 0 ? 2 : c->fuseTraversal); }
 
 // Split 'total' samples over the pools and size their slots.
 static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& base, RenderParams* Rs, int& nPools, int& maxSlots, bool& slotPerSample)
@@ -1390,7 +1411,7 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		const int maxRounds = (int)((total / nPools + slots) / slots) * seg + seg + 4;
 		const bool direct = mode == RT_MODE_PATH && slotPerSample;
 		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
-		rc = direct && nPools == 1 && fuse_mode(c, total) ? run_rounds_fused(c, Rs[0], seg, fuse_mode(c, total)) : run_rounds(c, Rs, nPools, maxRounds, direct ? seg : 0);
+		rc = direct && fuse_mode(c, total) ? run_rounds_fused(c, Rs, nPools, seg, fuse_mode(c, total)) : run_rounds(c, Rs, nPools, maxRounds, direct ? seg : 0);
 		if (rc != RT_OK) return rc;
 		hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 	}
@@ -1449,7 +1470,7 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 		const int seg = segments_per_sample(mode, depth, c->S.nLights);
 		const bool direct = mode == RT_MODE_PATH && slotPerSample;
 		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
-		if (rc == RT_OK) rc = direct && nPools == 1 && fuse_mode(c, (size_t)n) ? run_rounds_fused(c, Rs[0], seg, fuse_mode(c, (size_t)n)) : run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, direct ? seg : 0);
+		if (rc == RT_OK) rc = direct && fuse_mode(c, (size_t)n) ? run_rounds_fused(c, Rs, nPools, seg, fuse_mode(c, (size_t)n)) : run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, direct ? seg : 0);
 	}
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);
