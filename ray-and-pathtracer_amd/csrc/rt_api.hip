@@ -1057,7 +1057,7 @@ static int ensure_samples(rt_ctx* c, size_t count)
 	return RT_OK;
 }
 
-static int slot_budget();
+static int slot_budget(const rt_ctx* c);
 // Scene::IsOccluded for the shadow queue.  Counting launches walk like the reference; timed launches take the 4-wide
 // walk when the scene has wide nodes, followed by the binary walk over the (normally empty) list of rays the wide
 // walk handed back because they are not clean.
@@ -1328,7 +1328,7 @@ static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& b
 	size_t first = 0;
 	for (int k = 0; k < nPools; k++) {
 		const size_t cnt = first + per <= total ? per : total - first;
-		const size_t budget = (size_t)slot_budget() / nPools;
+		const size_t budget = (size_t)slot_budget(c) / nPools;
 		const int slots = (int)(cnt < budget ? cnt : budget);
 		int rc = ensure_state(c, k, slots > 0 ? slots : 1, pend);
 		if (rc != RT_OK) return rc;
@@ -1341,17 +1341,21 @@ static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& b
 	return RT_OK;
 }
 
-static int slot_budget()
+static int slot_budget(const rt_ctx* c)
 {
 	// slots in flight.  Every round pays a fixed tail: once the work head runs dry the waves of a traversal
-	// launch drain unevenly, and the longest rays finish alone at memory latency per step (measured
-	// ~0.7 ms per traversal launch, ~1.5 ms per round, on the bench scene).  Fewer, larger rounds win until
-	// every sample of the batch has its own slot: 16M -> 64M -> 128M slots took the 1080p x 64 spp frame
-	// from 97.8 to 79.0 to 76.4 ms.  ~216 B of state per slot: 128M slots = 29 GB of the 288 GB.
-	// RT_SLOTS overrides.
+	// launch drain unevenly, and the longest rays finish alone at memory latency per step (0.3-0.8 ms per traversal
+	// launch whatever it held, DESIGN.md finding 38).  Fewer, larger rounds win until every sample of the batch has its
+	// own slot: 16M -> 64M -> 128M slots took the 1080p x 64 spp frame from 97.8 to 79.0 to 76.4 ms (round 1), and
+	// 128M -> 256M takes 1080p x 256 spp from 148 to 138.5 ms and 4K x 1024 spp from 2.96 to 2.88 s (32-frame instead
+	// of 16-frame batches).  ~250 B of state per slot: 256M slots = 67 GB of the 288 GB, allocated for the slots a batch
+	// really has.  The shadow rays of a round are counted in an int: slots x lights stays below 2^31.  RT_SLOTS overrides.
 	const char* e = getenv("RT_SLOTS");
 	long v = e ? atol(e) : 0;
-	return v > 0 ? (int)v : (1 << 27);
+	long b = v > 0 ? v : (1l << 28);
+	const long lights = c && c->S.nLights > 1 ? c->S.nLights : 1;
+	if (b > 0x7FFFFFFFl / lights) b = 0x7FFFFFFFl / lights;
+	return (int)b;
 }
 static int segments_per_sample(int mode, int depth, int nLights)
 {
@@ -1378,13 +1382,14 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 	}
 	// batches of frames: the finished samples of a batch live in a [frame][pixel] buffer (<= 4 GiB)
 	const size_t tilePixels = (size_t)nSlots;
-	int batchFrames = (int)(((size_t)4 << 30) / (tilePixels * sizeof(float4)));
+	const size_t sampleGiB = getenv("RT_SAMPLE_GIB") && atol(getenv("RT_SAMPLE_GIB")) > 0 ? (size_t)atol(getenv("RT_SAMPLE_GIB")) : 4;
+	int batchFrames = (int)((sampleGiB << 30) / (tilePixels * sizeof(float4)));
 	if (batchFrames < 1) batchFrames = 1;
 	if (batchFrames > nframes) batchFrames = nframes;
 	// path mode: keep a batch within the slot budget when a frame fits, so that every sample has its own slot
 	// (exactly depth + 1 rounds, finished samples stored by shade / light, no finish pass; 4K: 16-frame batches)
-	if (mode == RT_MODE_PATH && tilePixels <= (size_t)slot_budget() && (size_t)batchFrames * tilePixels > (size_t)slot_budget())
-		batchFrames = (int)((size_t)slot_budget() / tilePixels);
+	if (mode == RT_MODE_PATH && tilePixels <= (size_t)slot_budget(c) && (size_t)batchFrames * tilePixels > (size_t)slot_budget(c))
+		batchFrames = (int)((size_t)slot_budget(c) / tilePixels);
 	int rc = ensure_samples(c, tilePixels * batchFrames);
 	if (rc != RT_OK) return rc;
 	for (int f = 0; f < nframes; f += batchFrames) {
