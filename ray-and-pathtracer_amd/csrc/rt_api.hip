@@ -51,7 +51,7 @@ struct rt_ctx {
 		PathState P;
 		Queues Q;
 		int stateSlots = 0, stateLights = -1;
-		bool statePend = false;
+		bool statePend = false, stateWide = false;
 		std::vector<void*> allocs;
 		hipStream_t stream = nullptr; // pool 0 runs on the context's stream
 		uint* spill = nullptr;
@@ -258,7 +258,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	memset(&c->S, 0, sizeof(c->S));
 	for (int k = 0; k < RT_MAX_POOLS; k++) memset(&c->pools[k].P, 0, sizeof(PathState)), memset(&c->pools[k].Q, 0, sizeof(Queues));
 	if (getenv("RT_POOLS")) c->nPoolsWanted = atoi(getenv("RT_POOLS"));
-	if (getenv("RT_FUSE")) c->fuseTraversal = atoi(getenv("RT_FUSE")) < 0 ? -1 : (atoi(getenv("RT_FUSE")) > 2 ? 1 : atoi(getenv("RT_FUSE")));
+	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0..2; anything else: the default
 	if (c->nPoolsWanted < 1) c->nPoolsWanted = 1;
 	if (c->nPoolsWanted > RT_MAX_POOLS) c->nPoolsWanted = RT_MAX_POOLS;
 	memset(&c->prof, 0, sizeof(c->prof));
@@ -1011,7 +1011,8 @@ static int ensure_state(rt_ctx* c, int k, int nSlots, bool pend)
 	if (!pl.stream) HIPCHK(c, hipStreamCreate(&pl.stream));
 	if (!pl.done) HIPCHK(c, hipEventCreateWithFlags(&pl.done, hipEventDisableTiming));
 	if (!pl.spill) HIPCHK(c, hipMalloc((void**)&pl.spill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
-	if (pl.stateSlots >= nSlots && pl.stateLights == c->S.nLights && (pl.statePend || !pend)) { pl.P.nSlots = nSlots; return RT_OK; }
+	const bool wide = c->S.wide != nullptr; // the 4-wide occlusion walk hands rays back through Q.leftover: allocated only for scenes that have it
+	if (pl.stateSlots >= nSlots && pl.stateLights == c->S.nLights && (pl.statePend || !pend) && (pl.stateWide || !wide)) { pl.P.nSlots = nSlots; return RT_OK; }
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipStreamSynchronize(pl.stream));
 	free_pool(pl.allocs);
@@ -1037,13 +1038,13 @@ static int ensure_state(rt_ctx* c, int k, int nSlots, bool pend)
 	HIPCHK(c, dalloc(pl.allocs, &Q.active, n));
 	HIPCHK(c, dalloc(pl.allocs, &Q.shadow, n));
 	HIPCHK(c, dalloc(pl.allocs, &Q.ended, n));
-	HIPCHK(c, dalloc(pl.allocs, &Q.leftover, n * (size_t)(c->S.nLights > 0 ? c->S.nLights : 1)));
+	HIPCHK(c, dalloc(pl.allocs, &Q.leftover, wide ? n * (size_t)(c->S.nLights > 0 ? c->S.nLights : 1) : (size_t)4));
 	HIPCHK(c, dalloc(pl.allocs, &Q.counts, 16));
 	HIPCHK(c, dalloc(pl.allocs, &Q.heads, (size_t)2 * RT_HEADS * RT_HEAD_STRIDE));
 	HIPCHK(c, hipMemset(Q.counts, 0, 16 * sizeof(int)));
 	P.nSlots = nSlots;
 	pl.P = P, pl.Q = Q;
-	pl.stateSlots = nSlots, pl.stateLights = c->S.nLights, pl.statePend = pend;
+	pl.stateSlots = nSlots, pl.stateLights = c->S.nLights, pl.statePend = pend, pl.stateWide = wide;
 	return RT_OK;
 }
 static int ensure_samples(rt_ctx* c, size_t count)
@@ -1311,12 +1312,19 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams* Rs, int nPools, int r
 	return RT_OK;
 }
 
-// Which round loop a path batch with a slot per sample takes: 0 the plain one (run_rounds), 1 extend(r + 1) and connect(r)
-// as ONE launch (k_traverse), 2 as two kernels on two streams (the default).  Measured (r02_ab_fuse2.txt, r02_ab_fuse3.txt):
+// Which round loop a path batch with a slot per sample takes, whatever its size: 0 the plain one (run_rounds), 1 extend(r + 1)
+// and connect(r) as ONE launch (k_traverse), 2 as two kernels on two streams (the default).  Measured (r02_ab_fuse2.txt, r02_ab_fuse3.txt):
 // 2 beats 1 at every size (1/8 frame 9.22 -> 9.02 ms) and 0 up to the full frame (32 spp: 29.1 -> 28.5 ms, 64 spp:
 // 54.4 -> 53.3 ms); config 5's 132 M-sample batches are level (2.96 s either way).  With 2 the kernel times bench.py
 // reports per kind overlap (RT_FUSE=0 for unoverlapped ones).
-static int fuse_mode(const rt_ctx* c, size_t /*samples*/) { return c->counting ? 0 : (c->fuseTraversal < 0 ? 2 : c->fuseTraversal); }
+static int fuse_mode(const rt_ctx* c, size_t samples)
+{
+	if (c->counting) return 0;
+	int m = c->fuseTraversal < 0 ? 2 : c->fuseTraversal;
+	// mode 1 indexes rays and shadow rays of a round in ONE int work list: slots * (lights + 1) must stay below 2^31
+	if (m == 1 && samples * (size_t)(c->S.nLights + 1) > (size_t)0x7FFFFFFF) m = 2;
+	return m;
+}
 
 // Split 'total' samples over the pools and size their slots.
 static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& base, RenderParams* Rs, int& nPools, int& maxSlots, bool& slotPerSample)

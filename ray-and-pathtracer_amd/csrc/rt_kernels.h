@@ -698,6 +698,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse(DScene
 	lc.clear();
 	uint rays = 0;
 	const int nActive = Q.counts[0];
+	RT_CHECK((long long)nActive + (long long)Q.counts[2] * S.nLights <= 0x7FFFFFFFll, 15, &Q.counts[3]); // fuse_mode() keeps such batches out of this launch
 	TraversePolicy pol{ { S, P, Q.active, parityExtend, &Q.counts[3] }, { P, Q.shadow, 1 - parityExtend, S.nLights, &Q.counts[3], Q.leftover, &Q.counts[8] }, nActive };
 	trace_persistent<false, false, false, TraversePolicy, true>(S, pol, nActive + Q.counts[2] * S.nLights, Q.heads, t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 }

@@ -298,7 +298,7 @@ public:
 	bool LoadSkyHDR(const char* path, std::string* why = nullptr);
 	// flatten + upload to the device context (must be called before queries / rendering)
 	void Commit(rt_ctx* ctx);
-	void CommitAlso(rt_ctx* other) const; // the same flattened scene to one more context (multi-GPU: every GPU holds a copy)
+	void CommitAlso(rt_ctx* other); // the same flattened scene to one more context (multi-GPU: every GPU holds a copy); SetTime reaches it too
 
 	// template/scene.h:1210: mesh wobble + bvh::Refit, executed on the device (rt_set_time); the
 	// reference runs it only when animOn (raytracer && defaultAnim && !useTLAS)
@@ -338,6 +338,7 @@ public:
 	bool raytracer = true;
 	bool useTLAS = false;
 	rt_ctx* ctx = nullptr;
+	std::vector<rt_ctx*> alsoCtx; // the further contexts the scene was committed to (CommitAlso): SetTime animates every copy
 private:
 	struct Flat;
 	Flat* flat = nullptr;

@@ -51,6 +51,7 @@ void Renderer::Shutdown()
 	for (rt_ctx* c : ctxs) rt_destroy(c);
 	ctxs.clear();
 	ctx = nullptr;
+	scene.ctx = nullptr, scene.alsoCtx.clear(); // the scene's contexts are gone with ours
 	delete[] accumulator;
 	delete[] screenPixels;
 	accumulator = nullptr, screenPixels = nullptr;

@@ -2,6 +2,7 @@
 // (template/scene.h:685-1397) and the flattening of host objects into the rt_scene_desc that
 // rt_upload_scene() consumes.  The three queries forward to the device library.
 #include "rapt.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -378,6 +379,7 @@ static void check(rt_ctx* ctx, int rc)
 void Scene::Commit(rt_ctx* c)
 {
 	ctx = c;
+	alsoCtx.clear(); // a re-commit starts over: Renderer::Commit names the other contexts again
 	check(ctx, rt_upload_scene(ctx, &Describe()));
 	// the accelerator objects learn where they live, for their own Intersect / IsOccluded members
 	if (!useTLAS) { if (b) b->owner = this, b->blasIndex = 0; }
@@ -393,16 +395,20 @@ void Scene::Commit(rt_ctx* c)
 	}
 }
 
-void Scene::CommitAlso(rt_ctx* other) const
+void Scene::CommitAlso(rt_ctx* other)
 {
 	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");
-	check(other, rt_upload_scene(other, &const_cast<Scene*>(this)->Describe()));
+	check(other, rt_upload_scene(other, &Describe()));
+	if (other != ctx && std::find(alsoCtx.begin(), alsoCtx.end(), other) == alsoCtx.end()) alsoCtx.push_back(other);
 }
 
+// every context holds its own copy of the geometry and its own refitted tree: all of them move to time t
+// (a multi-GPU frame interleaves rows rendered from each copy)
 void Scene::SetTime(float t)
 {
 	if (!ctx) throw std::runtime_error("Scene: Commit() has not been called");
 	check(ctx, rt_set_time(ctx, t));
+	for (rt_ctx* o : alsoCtx) check(o, rt_set_time(o, t));
 }
 
 void Scene::FindNearestBatch(int n, const float* O, const float* D, const float* tmax, float t_min, rt_hit* out) const

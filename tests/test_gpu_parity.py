@@ -374,6 +374,23 @@ def test_multi_context_renderer(devices, scenes, oracle_api, host_api):
     for k in range(4):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
     assert a[4] == b[4]
+    # Scene::SetTime must reach every context's copy of the geometry (each GPU refits its own tree): an animated
+    # scene-BVH scene, rows interleaved over the contexts, equals the one-context frame at every time
+    anim = {}
+    for key, devs in (("one", None), ("many", devices)):
+        r = host_api.HostRenderer(w, h, devices=devs)
+        scenes.mixed_small(r.scene)
+        r.commit()
+        out = []
+        for t in (0.0, 1.7, 4.2):
+            r.scene.set_time(t)
+            r.tick()
+            out.append(r.tick_accumulator().copy())
+        anim[key] = out
+        r.close()
+    assert not np.array_equal(anim["one"][0], anim["one"][1])  # the geometry really moved
+    for k in range(3):
+        assert np.array_equal(anim["one"][k].view(np.uint32), anim["many"][k].view(np.uint32)), ("set_time", k)
 
 
 def test_bench_two_ranks_equal_one(host_api):
@@ -934,9 +951,9 @@ def test_fewer_slots_than_samples(slots, name, kw, scenes, oracle_api, host_api,
 @pytest.mark.parametrize("name,kw,w,h,frames", [("pretty_tlas", {"n_instances": 4}, 160, 90, 7), ("mixed_small", {}, 96, 64, 5), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72, 3)])
 def test_fused_traversal_launch_equals_separate_launches(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
     """Path batches with a slot per sample overlap extend(r + 1) with connect(r) + light(r) (csrc/rt_api.hip
-    run_rounds_fused): below 100 M samples as two kernels on two streams (RT_FUSE=2, the default there), optionally as
-    ONE launch over one work list (RT_FUSE=1, k_traverse); larger batches and counting launches keep the plain round
-    loop (RT_FUSE=0).  All three must produce the same accumulator bits, and the oracle's frame."""
+    run_rounds_fused) at every batch size: as two kernels on two streams (RT_FUSE=2, the default), optionally as ONE
+    launch over one work list (RT_FUSE=1, k_traverse); counting launches keep the plain round loop (RT_FUSE=0).  All
+    three must produce the same accumulator bits, and the oracle's frame."""
     out = {}
     for fuse in ("0", "1", "2"):
         monkeypatch.setenv("RT_FUSE", fuse)

@@ -123,7 +123,9 @@ def test_reference_probe_observations(scenes, oracle_api):
       * 9,790 of 240,000 accumulator pixels are +inf (a directly viewed AreaLight, Q7),
       * gprof over two frames (480 k primary rays): 1.04 M bvh::BIntersect calls, 29.3 M Triangle::Intersect calls.
     All three are independent of the (missing) sky texture.  The oracle must reproduce them: the first exactly,
-    the gprof figures to the three digits they were recorded with."""
+    the gprof figures to the three digits they were recorded with.  A fourth observation of the same probe (SURVEY.md
+    8c "Observed"): TLASSceneTest2 (template/scene.h:941-972, BigB.obj x 3 instances through the TLAS) at 600x400 in
+    Whitted mode leaves 0 non-finite accumulator pixels (any finite sky gives the same count)."""
     s = oracle_api.OracleScene()
     scenes.background_scene(s)
     s.set_raytracer(True)
@@ -137,6 +139,15 @@ def test_reference_probe_observations(scenes, oracle_api):
     assert round(2 * cnt["tri_intersect_calls"] / 1e6, 1) == 29.3
     # "~28 triangle tests per traversal" 
     assert round(cnt["tri_intersect_calls"] / cnt["rays_nearest"]) == 28
+    r.close(); s.close()
+    s = oracle_api.OracleScene()
+    scenes.tlas_test2(s, mesh="BigB")
+    s.set_raytracer(True)
+    r = oracle_api.OracleRenderer(s, 600, 400)
+    r.render(0, 1, nthreads=0)
+    a = r.accumulator()[..., :3]
+    assert int((~np.isfinite(a)).sum()) == 0
+    assert (a > 0).any(-1).mean() > 0.9  # and it is a picture, not a black frame
     r.close(); s.close()
 
 
