@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-count", action="store_true", help="profiling runs: skip the untimed counting pass (ray counts and algorithmic bytes are then 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -116,9 +117,10 @@ def main():
         r.synchronize()
 
     # ---- untimed: counting pass (algorithmic work of this rank's rows), then warmup ----
-    r.set_counting(ha.RT_COUNT_EXECUTED)  # the walk the timed kernels make (same results, fewer TLAS / instance visits than the reference's)
     r.counters()
-    step()
+    if not args.no_count:
+        r.set_counting(ha.RT_COUNT_EXECUTED)  # the walk the timed kernels make (same results, fewer TLAS / instance visits than the reference's)
+        step()
     near, occl = r.counters_split()
     r.set_counting(False)
     for _ in range(args.warmup):

@@ -2,6 +2,7 @@
 // Host part: context, repacking of the reference-shaped scene arrays into the HBM traversal layout
 // (rt_scene_dev.h), the round loop of the wavefront pixel loop, batch queries, counters, profiling.
 #include "rt_kernels.h"
+#include "rt_stream.h"
 #include "rt_build.h"
 #include "../../include/rt_amd.h"
 #include <algorithm>
@@ -65,6 +66,19 @@ struct rt_ctx {
 	int fuseTraversal = -1;  // RT_FUSE: how extend(r + 1) and connect(r) share a round (run_rounds_fused): -1 / 2 two kernels on two
 	                         // streams, 1 one launch (k_traverse), 0 the plain loop (run_rounds)
 
+	// the dense path-mode pipeline (rt_stream.h): its state, the second stream for connect + light, and whether it is on
+	StreamState T;
+	std::vector<void*> streamAllocs;
+	int streamCap = 0, streamLights = -1;
+	bool streamWide = false;
+	hipStream_t streamSide = nullptr;
+	uint* streamSideSpill = nullptr;
+	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
+	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
+	int shadeLds = 1;        // RT_SHADE_LDS: the shading kernels keep the material / brute-force primitive tables in LDS
+	int gridShadeS = 0, gridLightS = 0; // resident blocks of the grid-stride shading kernels (a second, partial round of blocks would run at low occupancy)
+	int decideRays = 1;      // RT_DECIDE: producers answer rays whose first traversal step leaves nothing to visit (rt_stream.h ray_decided)
+	int gridExtendS = 0, gridConnectS = 0, gridConnectWideS = 0, gridLeftoverS = 0;
 	int nPoolsWanted = 1; // RT_POOLS; measured: 2 pools overlap their kernels but do not shorten the frame
 	hipEvent_t fork = nullptr;
 	// traversal stack spill of pool 0 and of the batch queries + flags
@@ -77,6 +91,7 @@ struct rt_ctx {
 	int pairAgain = 16; // lanes that must still want a pair step for an iteration to repeat it (RT_PAIRAGAIN); tuning bits 20-26
 	int stepMinAny = 8, pairAgainAny = 16; // the any-hit kernel's RT_STEPMIN / RT_PAIRAGAIN (RT_STEPMIN_ANY, RT_PAIRAGAIN_ANY)
 	int stepMinXform = 0; // RT_STEPMIN_XFORM: lanes that must want an instance entry / exit before it runs (0: the same as RT_STEPMIN)
+	float* gammaLut = nullptr; // DScene::gammaLut
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
 	int counting = 0; // 0 off, 1 the reference's walk (RT_COUNT_REFERENCE), 2 the walk the timed kernels make (RT_COUNT_EXECUTED)
@@ -259,6 +274,10 @@ rt_ctx* rt_create(int device, int width, int height)
 	for (int k = 0; k < RT_MAX_POOLS; k++) memset(&c->pools[k].P, 0, sizeof(PathState)), memset(&c->pools[k].Q, 0, sizeof(Queues));
 	if (getenv("RT_POOLS")) c->nPoolsWanted = atoi(getenv("RT_POOLS"));
 	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0..2; anything else: the default
+	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
+	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
+	if (getenv("RT_SHADE_LDS")) c->shadeLds = atoi(getenv("RT_SHADE_LDS")) != 0;
+	memset(&c->T, 0, sizeof(c->T));
 	if (c->nPoolsWanted < 1) c->nPoolsWanted = 1;
 	if (c->nPoolsWanted > RT_MAX_POOLS) c->nPoolsWanted = RT_MAX_POOLS;
 	memset(&c->prof, 0, sizeof(c->prof));
@@ -280,6 +299,12 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridTraverse = resident((const void*)k_traverse);
 		c->gridConnectWide = resident((const void*)k_connect<false, true>);
 		c->gridLeftover = std::min(resident((const void*)k_connect<false, false, true>), prop.multiProcessorCount); // a short list: one block per CU is plenty
+		c->gridExtendS = std::min(resident((const void*)k_extend_s<false>), resident((const void*)k_extend_s<true>));
+		c->gridConnectS = std::min(resident((const void*)k_connect_s<false>), resident((const void*)k_connect_s<true>));
+		c->gridConnectWideS = resident((const void*)k_connect_s<false, true>);
+		c->gridLeftoverS = std::min(resident((const void*)k_connect_s<false, false, true>), prop.multiProcessorCount);
+		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_shade_s);
+		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
 		const void* qk[8] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true>,
 		                      (const void*)k_query_occluded<false, true>, (const void*)k_query_occluded<false, false, true> };
@@ -304,6 +329,8 @@ rt_ctx* rt_create(int device, int width, int height)
 	ok = ok && hipMalloc((void**)&c->counters, 2 * sizeof(DCounters)) == hipSuccess;
 	ok = ok && hipMemset(c->counters, 0, 2 * sizeof(DCounters)) == hipSuccess;
 	ok = ok && hipHostMalloc((void**)&c->hostCounts, 16 * RT_MAX_POOLS * sizeof(int)) == hipSuccess;
+	ok = ok && hipMalloc((void**)&c->gammaLut, 256 * sizeof(float)) == hipSuccess;
+	if (ok) hipLaunchKernelGGL(k_gamma_lut, dim3(1), dim3(256), 0, c->stream, c->gammaLut);
 	ok = ok && hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess;
 	c->pools[0].stream = c->stream, c->pools[0].spill = c->spill;
 	if (!ok) { fail(nullptr, RT_E_HIP, "rt_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); rt_destroy(c); return nullptr; }
@@ -340,10 +367,16 @@ void rt_destroy(rt_ctx* c)
 		if (pl.sideFork) (void)hipEventDestroy(pl.sideFork);
 		if (pl.sideJoin) (void)hipEventDestroy(pl.sideJoin);
 	}
+	free_pool(c->streamAllocs);
+	if (c->streamSide) { (void)hipStreamSynchronize(c->streamSide); (void)hipStreamDestroy(c->streamSide); }
+	if (c->streamSideSpill) (void)hipFree(c->streamSideSpill);
+	if (c->streamFork) (void)hipEventDestroy(c->streamFork);
+	if (c->streamJoin) (void)hipEventDestroy(c->streamJoin);
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
 	if (c->samples) (void)hipFree(c->samples);
 	if (c->resolveBuf) (void)hipFree(c->resolveBuf);
+	if (c->gammaLut) (void)hipFree(c->gammaLut);
 	if (c->flags) (void)hipFree(c->flags);
 	if (c->counters) (void)hipFree(c->counters);
 	if (c->hostCounts) (void)hipHostFree(c->hostCounts);
@@ -800,7 +833,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	DMaterial* dm = nullptr;
 	HIPCHK(c, dalloc(c->sceneAllocs, &dm, mats.size()));
 	HIPCHK(c, hipMemcpy(dm, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
-	S.mats = dm;
+	S.mats = dm, S.nMats = (int)mats.size();
+	S.gammaLut = getenv("RT_GAMMA_LUT") && atoi(getenv("RT_GAMMA_LUT")) == 0 ? nullptr : c->gammaLut;
 	if (d->sky_pixels && d->sky_w > 0 && d->sky_h > 0 && d->sky_n >= 3) {
 		unsigned char* ds = nullptr;
 		const size_t nbytes = (size_t)d->sky_w * d->sky_h * d->sky_n;
@@ -1312,6 +1346,125 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams* Rs, int nPools, int r
 	return RT_OK;
 }
 
+// ---- the dense path-mode pipeline (rt_stream.h) ------------------------------------------------------
+static int ensure_stream_state(rt_ctx* c, int n)
+{
+	const bool wide = c->S.wide != nullptr;
+	if (!c->streamSide) {
+		HIPCHK(c, hipStreamCreate(&c->streamSide));
+		HIPCHK(c, hipMalloc((void**)&c->streamSideSpill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
+		HIPCHK(c, hipEventCreateWithFlags(&c->streamFork, hipEventDisableTiming));
+		HIPCHK(c, hipEventCreateWithFlags(&c->streamJoin, hipEventDisableTiming));
+	}
+	if (c->streamCap >= n && c->streamLights == c->S.nLights && (c->streamWide || !wide)) return RT_OK;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->streamSide));
+	free_pool(c->streamAllocs);
+	c->streamCap = 0;
+	StreamState T;
+	memset(&T, 0, sizeof(T));
+	// k_assign writes the positions of whole 16-entry vectors and the compactions read whole 16-byte vectors of class bytes
+	const size_t cap = ((size_t)n + 1023) & ~(size_t)1023;
+	const size_t nl = (size_t)(c->S.nLights > 0 ? c->S.nLights : 1);
+	std::vector<void*>& A = c->streamAllocs;
+	for (int b = 0; b < 2; b++) {
+		HIPCHK(c, dalloc(A, &T.O[b], cap)); HIPCHK(c, dalloc(A, &T.D[b], cap));
+		HIPCHK(c, dalloc(A, &T.hitN[b], cap)); HIPCHK(c, dalloc(A, &T.hitId[b], cap));
+		HIPCHK(c, dalloc(A, &T.W[b], cap)); HIPCHK(c, dalloc(A, &T.E[b], cap)); HIPCHK(c, dalloc(A, &T.L[b], cap));
+		HIPCHK(c, dalloc(A, &T.cls[b], cap));
+	}
+	HIPCHK(c, dalloc(A, &T.pos, cap));
+	HIPCHK(c, dalloc(A, &T.shI, cap)); HIPCHK(c, dalloc(A, &T.shN, cap)); HIPCHK(c, dalloc(A, &T.shD, cap)); HIPCHK(c, dalloc(A, &T.shW, cap));
+	HIPCHK(c, dalloc(A, &T.shP, cap * nl));
+	HIPCHK(c, dalloc(A, &T.vis, cap * nl));
+	HIPCHK(c, dalloc(A, &T.traceQ, cap));
+	HIPCHK(c, dalloc(A, &T.leftover, wide ? cap * nl : (size_t)4));
+	HIPCHK(c, dalloc(A, &T.counts, 16));
+	HIPCHK(c, dalloc(A, &T.heads, (size_t)2 * RT_HEADS * RT_HEAD_STRIDE));
+	HIPCHK(c, hipMemset(T.counts, 0, 16 * sizeof(int)));
+	T.cap = (int)cap;
+	c->T = T;
+	c->streamCap = (int)cap, c->streamLights = c->S.nLights, c->streamWide = wide;
+	return RT_OK;
+}
+static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int parity, uint* spill)
+{
+	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27);
+	if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
+	else if (!c->S.wide) hipLaunchKernelGGL((k_connect_s<false>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
+	else {
+		hipLaunchKernelGGL((k_connect_s<false, true>), dim3(c->gridConnectWideS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
+		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, st, T, 4, parity, -1);
+		hipLaunchKernelGGL((k_connect_s<false, false, true>), dim3(c->gridLeftoverS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
+	}
+}
+// Path mode, an entry per sample: 'rounds' = start depth + 1 rounds, no queue length is read back.  connect(r) and light(r)
+// run on the second stream beside compact / extend / assign of round r + 1 (twoStreams; light(r) is the last writer of
+// the E and L that shade(r + 1) reads, so the main stream joins before shade); RT_FUSE=0 keeps one kernel at a time.
+//   generate | begin compact extend(0) assign shade(0) | begin compact extend(1) assign {|| connect(0) light(0)} shade(1) | ...
+static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
+{
+	const float t_min = 0.001f; // renderer.cpp:131
+	const int grid = c->gridBlocks;
+	// measured (profiles/r03_ab_stream_fuse.txt): the second stream pays below ~100 M samples per batch (the drains of the
+	// traversal launches are a larger share: 1/8 frame 9.41 -> 8.62 ms, half frame 27.1 -> 26.8) and costs above (full
+	// frame 49.9 -> 50.5 ms, config 5 2.45 -> 2.50 s: extend and connect want the same units); RT_FUSE = 0 / 2 forces
+	const bool twoStreams = c->fuseTraversal < 0 ? R.nSamples < 100000000u : c->fuseTraversal != 0;
+	const StreamState& T = c->T;
+	hipStream_t st = c->stream, sb = twoStreams ? c->streamSide : c->stream;
+	const int cnt = c->counting ? 1 : 0;
+	const int n = (int)R.nSamples;
+	prof_begin(c, K_GENERATE, st);
+	hipLaunchKernelGGL(k_generate_s, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, rounds == 1 ? 1 : 0, c->decideRays, cnt);
+	prof_end(c, st);
+	bool pendingJoin = false;
+	for (int round = 0; round < rounds; round++) {
+		const int parity = round & 1, last = round + 1 == rounds ? 1 : 0, lastNext = round + 2 == rounds ? 1 : 0;
+		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, st, T, 1, parity, round == 0 ? n : -1);
+		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, parity);
+		prof_begin(c, K_EXTEND, st);
+		if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+		prof_end(c, st);
+		hipLaunchKernelGGL(k_assign, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, parity);
+		if (pendingJoin) { HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0)); pendingJoin = false; }
+		prof_begin(c, K_SHADE, st);
+		hipLaunchKernelGGL(k_shade_s, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, parity, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt);
+		prof_end(c, st);
+		if (twoStreams) {
+			HIPCHK(c, hipEventRecord(c->streamFork, st));
+			HIPCHK(c, hipStreamWaitEvent(sb, c->streamFork, 0));
+		}
+		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, sb, T, 2, parity, -1);
+		prof_begin(c, K_CONNECT, sb);
+		launch_connect_s(c, sb, T, parity, twoStreams ? c->streamSideSpill : c->spill);
+		prof_end(c, sb);
+		prof_begin(c, K_SHADE, sb);
+		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, parity, last, c->shadeLds);
+		prof_end(c, sb);
+		if (twoStreams) { HIPCHK(c, hipEventRecord(c->streamJoin, sb)); pendingJoin = true; }
+	}
+	if (pendingJoin) HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0));
+	if (cnt) hipLaunchKernelGGL(k_fold_decided, dim3(1), dim3(1), 0, st, c->S, T.counts, c->counters);
+	HIPCHK(c, hipMemcpyAsync(c->hostCounts, T.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipStreamSynchronize(st));
+	const int* hc = c->hostCounts;
+	int rc = RT_OK;
+	if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+	else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
+	else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
+	if (hc[3] != 0) (void)hipMemsetAsync(T.counts + 3, 0, sizeof(int), st);
+	if (rc != RT_OK) return rc;
+	HIPCHK(c, hipGetLastError());
+	return RT_OK;
+}
+// the dense pipeline serves path batches with an entry per sample; RT_COUNT_REFERENCE tallies are the slot pipeline's
+// (the reference's walk visits the root pair for every ray, which a producer-side decision skips)
+static bool stream_eligible(const rt_ctx* c, int mode, size_t samples)
+{
+	return c->useStream && mode == RT_MODE_PATH && !c->pathUnsupported && c->counting != RT_COUNT_REFERENCE && samples <= (size_t)slot_budget(c);
+}
+
 // Which round loop a path batch with a slot per sample takes, whatever its size: 0 the plain one (run_rounds), 1 extend(r + 1)
 // and connect(r) as ONE launch (k_traverse), 2 as two kernels on two streams (the default).  Measured (r02_ab_fuse2.txt, r02_ab_fuse3.txt):
 // 2 beats 1 at every size (1/8 frame 9.22 -> 9.02 ms) and 0 up to the full frame (32 spp: 29.1 -> 28.5 ms, 64 spp:
@@ -1415,6 +1568,15 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 			if (rc != RT_OK) return rc;
 			continue;
 		}
+		if (stream_eligible(c, mode, total)) {
+			rc = ensure_stream_state(c, (int)total);
+			if (rc != RT_OK) return rc;
+			R.finishInline = 1;
+			rc = run_rounds_stream(c, R, 4 + 1); // Sample starts at depth 4 (renderer.cpp:278): five hit levels
+			if (rc != RT_OK) return rc;
+			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
+			continue;
+		}
 		RenderParams Rs[RT_MAX_POOLS];
 		int nPools = 1, slots = 1;
 		bool slotPerSample = false;
@@ -1475,6 +1637,10 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 	if (mode == RT_MODE_PATH && c->pathUnsupported) {
 		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
 		rc = check_overflow(c);
+	} else if (stream_eligible(c, mode, (size_t)n)) {
+		rc = ensure_stream_state(c, n);
+		R.finishInline = 1;
+		if (rc == RT_OK) rc = run_rounds_stream(c, R, depth + 1);
 	} else {
 		RenderParams Rs[RT_MAX_POOLS];
 		int nPools = 1, slots = 1;

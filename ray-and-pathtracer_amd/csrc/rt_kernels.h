@@ -157,10 +157,10 @@ __device__ __forceinline__ f3 light_position(const DLight& L, bool raytracer, ui
 	return f3(pos.x + newRad * x_cosf(theta), pos.y + newRad * x_sinf(theta), pos.z);
 }
 
-// Scene::GetSkyColor (template/scene.h:1312-1327)
-__device__ __forceinline__ f3 sky_color(const DScene& S, const f3& D)
+// Scene::GetSkyColor (template/scene.h:1312-1327): the texel the direction D looks at (null without a sky texture)
+__device__ __forceinline__ const unsigned char* sky_texel(const DScene& S, const f3& D)
 {
-	if (!S.sky) return f3(0.0f);
+	if (!S.sky) return nullptr;
 	f3 horizontalProj(D.x, 0, D.z);
 	float cHeight = dot(D, f3(0, -1, 0));
 	f3 nh = normalize(horizontalProj);
@@ -173,8 +173,20 @@ __device__ __forceinline__ f3 sky_color(const DScene& S, const f3& D)
 	if (y >= S.skyH) y = S.skyH - 1;
 	if (y < 0) y = 0;
 	if (x < 0) x = 0;
-	const unsigned char* p = S.sky + (size_t)(x + S.skyW * y) * S.skyN;
+	return S.sky + (size_t)(x + S.skyW * y) * S.skyN;
+}
+__device__ __forceinline__ f3 sky_color(const DScene& S, const f3& D)
+{
+	const unsigned char* p = sky_texel(S, D);
+	if (!p) return f3(0.0f);
 	return f3((float)p[0], (float)p[1], (float)p[2]) / 255;
+}
+// gammaLut[b] = the finished path-mode sample of radiance b / 255 (store_sample: pow(c, GAMMA) per channel, renderer.cpp:279-282)
+__global__ void k_gamma_lut(float* lut)
+{
+	const int b = (int)threadIdx.x;
+	const f3 c = f3((float)b, (float)b, (float)b) / 255;
+	lut[b] = x_powf(c.x * 1, RT_GAMMA);
 }
 
 // diffuse::scatter (template/scene.h:605-620): att out, energy in/out
@@ -209,10 +221,10 @@ __device__ __forceinline__ void wave_range(int nSlots, int& first, int& last)
 // compact: queue <- slots whose status has the (single) bit 'bit', in slot order.  A lane reads 16
 // status bytes at a time (one dwordx4), a wave 1024 slots per iteration; wave w owns a contiguous
 // range (a multiple of 1024 slots), counts it, reserves its queue positions with one atomic, then writes.
-__device__ __forceinline__ uint4 status16(const PathState& P, int slot0, int last, uint bits)
+__device__ __forceinline__ uint4 status16(const unsigned char* status, int slot0, int last, uint bits)
 {
 	if (slot0 >= last) return make_uint4(0, 0, 0, 0);
-	uint4 v = *(const uint4*)(P.status + slot0);
+	uint4 v = *(const uint4*)(status + slot0);
 	v.x &= bits, v.y &= bits, v.z &= bits, v.w &= bits;
 	const int valid = last - slot0; // bytes of this vector that are slots
 	if (valid < 16) {
@@ -227,7 +239,8 @@ __device__ __forceinline__ uint4 status16(const PathState& P, int slot0, int las
 	return v;
 }
 #define RT_COMPACT_BLOCK 512
-__global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int bit, uint* queue, int* count)
+// status[0 .. nSlots) (readable up to the next multiple of 16) -> queue of the entries that have 'bit', *count += their number
+__device__ __forceinline__ void compact_body(const unsigned char* status, int nSlots, int bit, uint* queue, int* count)
 {
 	__shared__ int waveTotal[RT_COMPACT_BLOCK / 64];
 	__shared__ int blockBase;
@@ -236,14 +249,14 @@ __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int b
 	const uint bits = (uint)bit * 0x01010101u;
 	const int waves = (gridDim.x * blockDim.x) >> 6;
 	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	int per = (P.nSlots + waves - 1) / waves;
+	int per = (nSlots + waves - 1) / waves;
 	per = (per + 1023) & ~1023;
 	const long long firstL = (long long)wave * per;
-	const int first = firstL < P.nSlots ? (int)firstL : P.nSlots;
-	const int last = firstL + per < P.nSlots ? (int)(firstL + per) : P.nSlots;
+	const int first = firstL < nSlots ? (int)firstL : nSlots;
+	const int last = firstL + per < nSlots ? (int)(firstL + per) : nSlots;
 	int mine = 0;
 	for (int s0 = first; s0 < last; s0 += 1024) {
-		const uint4 v = status16(P, s0 + (int)lane * 16, last, bits);
+		const uint4 v = status16(status, s0 + (int)lane * 16, last, bits);
 		mine += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
 	}
 	int total = mine;
@@ -265,7 +278,7 @@ __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int b
 	uint* mystage = stage[wib];
 	for (int s0 = first; s0 < last; s0 += 1024) {
 		const int slot0 = s0 + (int)lane * 16;
-		const uint4 v = status16(P, slot0, last, bits);
+		const uint4 v = status16(status, slot0, last, bits);
 		const int c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
 		int incl = c; // inclusive prefix sum over the wave
 		for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
@@ -287,6 +300,10 @@ __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int b
 		__builtin_amdgcn_wave_barrier();
 		base += n;
 	}
+}
+__global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int bit, uint* queue, int* count)
+{
+	compact_body(P.status, P.nSlots, bit, queue, count);
 }
 
 __device__ __forceinline__ void flush_counters(DCounters* g, const LaneCounters& lc, uint nearest, uint occluded)

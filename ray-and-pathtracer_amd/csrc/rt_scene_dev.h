@@ -117,6 +117,7 @@ struct DScene {
 	const DLight* lights;
 	const DMaterial* mats;
 	const unsigned char* sky;
+	const float* gammaLut; // [256] pow(b / 255, GAMMA) for a sky texel byte b (the finished sample of a camera ray that leaves the scene)
 	uint rootLink; // scene BVH root, or the TLAS root in TLAS mode
 	uint tlasBase; // pair index of the first TLAS record
 	float reachOriginMax; // reach[] boxes are inflated for world ray origins with |O|_1 up to this
@@ -127,6 +128,7 @@ struct DScene {
 	int useTLAS;
 	int nBruteSph, nBrutePla;
 	int nLights;
+	int nMats;     // entries of mats[]
 	int skyW, skyH, skyN;
 };
 

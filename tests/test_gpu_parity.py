@@ -950,10 +950,11 @@ def test_fewer_slots_than_samples(slots, name, kw, scenes, oracle_api, host_api,
 
 @pytest.mark.parametrize("name,kw,w,h,frames", [("pretty_tlas", {"n_instances": 4}, 160, 90, 7), ("mixed_small", {}, 96, 64, 5), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72, 3)])
 def test_fused_traversal_launch_equals_separate_launches(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
-    """Path batches with a slot per sample overlap extend(r + 1) with connect(r) + light(r) (csrc/rt_api.hip
-    run_rounds_fused) at every batch size: as two kernels on two streams (RT_FUSE=2, the default), optionally as ONE
-    launch over one work list (RT_FUSE=1, k_traverse); counting launches keep the plain round loop (RT_FUSE=0).  All
-    three must produce the same accumulator bits, and the oracle's frame."""
+    """The slot pipeline (RT_STREAM=0, csrc/rt_kernels.h): path batches with a slot per sample overlap extend(r + 1) with
+    connect(r) + light(r) (csrc/rt_api.hip run_rounds_fused) at every batch size: as two kernels on two streams
+    (RT_FUSE=2, the default), optionally as ONE launch over one work list (RT_FUSE=1, k_traverse); counting launches keep
+    the plain round loop (RT_FUSE=0).  All three must produce the same accumulator bits, and the oracle's frame."""
+    monkeypatch.setenv("RT_STREAM", "0")
     out = {}
     for fuse in ("0", "1", "2"):
         monkeypatch.setenv("RT_FUSE", fuse)
@@ -971,6 +972,53 @@ def test_fused_traversal_launch_equals_separate_launches(name, kw, w, h, frames,
         r.close()
     assert np.array_equal(out["0"].view(np.uint32), out["1"].view(np.uint32))
     assert np.array_equal(out["0"].view(np.uint32), out["2"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name,kw,w,h,frames", [("pretty_tlas", {"n_instances": 4}, 160, 90, 7), ("mixed_small", {}, 96, 64, 5), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72, 3),
+                                               ("tower", {}, 120, 68, 3), ("scene3", {}, 100, 60, 4), ("background", {}, 90, 60, 3)])
+def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
+    """The dense path pipeline (csrc/rt_stream.h, the default: entries of a round are the survivors of the round before,
+    every producer writes to compacted positions; RT_FUSE=0 runs it one kernel at a time) and its producer-side ray
+    decisions (RT_DECIDE: generate / shade answer a ray whose first traversal step leaves nothing to visit) against the
+    slot pipeline (RT_STREAM=0): identical accumulator bits -- per sample the arithmetic is the same, only where the path
+    state lives differs -- the oracle's frame, identical frames from row shards, identical Sample() values for
+    caller-supplied rays at every depth, and the same number of FindNearest / IsOccluded queries."""
+    out, rays = {}, {}
+    pO = pD = None
+    for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_nodecide", {"RT_DECIDE": "0"})):
+        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
+        r.set_counting(host_api.RT_COUNT_EXECUTED); r.counters()
+        r.clear()
+        r.render(host_api.RT_MODE_PATH, 0, frames)
+        near, occl = r.counters_split()
+        r.set_counting(False)
+        rays[key] = (near["rays_nearest"], occl["rays_occluded"], near["light_tests"], near["brute_tests"])
+        counted = r.accumulator().copy()
+        r.clear()
+        r.render(host_api.RT_MODE_PATH, 0, frames)
+        out[key] = r.accumulator().copy()
+        assert np.array_equal(counted.view(np.uint32), out[key].view(np.uint32))  # counting launches render the same frame
+        if key == "stream":
+            check_frames(orr, r, "path", frames, host_api)
+            r.clear()
+            r.render_rows(host_api.RT_MODE_PATH, 0, frames, 0, 2, (h + 1) // 2)
+            r.render_rows(host_api.RT_MODE_PATH, 0, frames, 1, 2, h // 2)
+            assert np.array_equal(r.accumulator().view(np.uint32), out[key].view(np.uint32))
+        if key in ("slot", "stream"):
+            if pO is None:
+                pO, pD = orr.primary_rays()
+                pO, pD = pO[::7].copy(), pD[::7].copy()
+            out[key + "_sample"] = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 99) for depth in (0, 1, 4)]
+        r.close()
+    for key in ("stream", "stream_serial", "stream_nodecide"):
+        assert np.array_equal(out["slot"].view(np.uint32), out[key].view(np.uint32)), key
+        assert rays[key] == rays["slot"], (key, rays[key], rays["slot"])
+    for a, b in zip(out["slot_sample"], out["stream_sample"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_sample_pools_on_separate_streams(scenes, oracle_api, host_api, monkeypatch):
