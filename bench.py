@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true", help="profiling runs: skip the untimed counting pass (ray counts and algorithmic bytes are then 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--emulate-world", type=int, default=0, help="profiling on ONE GPU: render only the rows rank 0 of an N-rank run renders "
+                    "(no process group, no gather): the counters of that share are what rank 0 of the N-GPU run is priced with")
     args = ap.parse_args()
 
     import numpy as np
@@ -95,20 +97,21 @@ def main():
     mode = ha.RT_MODE_PATH
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     r.bind_accumulator(acc.data_ptr())
-    row_first, row_stride, row_count = dpar.shard_rows(H, rank, world)
+    # the shard of this rank and every buffer its gather needs: allocated once, outside the timed region
+    shard = dpar.RowShard(H, W, rank, world, acc.device)
+    if args.emulate_world > 1:
+        if world != 1:
+            raise SystemExit("bench.py: --emulate-world runs on one rank")
+        shard = dpar.RowShard(H, W, 0, 1, acc.device)
+        shard.first, shard.stride, shard.count = dpar.shard_rows(H, 0, args.emulate_world)
+    host_staging = None
+    if world > 1 and backend != "nccl":
+        host_staging = (torch.zeros((H, W, 4), dtype=torch.float32), dpar.RowShard(H, W, rank, world, torch.device("cpu")))
 
     def step():
         acc.zero_()
         torch.cuda.synchronize()
-        r.render_rows(mode, 0, spp, row_first, row_stride, row_count)
-        r.synchronize()
-        if backend == "nccl" or world == 1:
-            dpar.gather_rows(acc, rank, world, 0)
-        else:
-            host = acc.cpu()
-            dpar.gather_rows(host, rank, world, 0)
-            if rank == 0:
-                acc.copy_(host)
+        dpar.render_step(r, acc, mode, 0, spp, shard, host_staging)
 
     def fence():
         if world > 1:
@@ -163,8 +166,9 @@ def main():
                        "rays_definition": "value counts primary pixel samples (reference's Mrays/s, renderer.cpp:300); all_rays counts every FindNearest + IsOccluded query"},
             "all_rays_mrays_per_s": round(rays_all / sec_per_step / 1e6, 3),
             "rays_per_step": {"nearest": int(cnt[0].item()), "occluded": int(cnt[1].item())},
-            "roofline": roofline_block(args, ha, near, avg_ms, launches_per_step, W, H, spp, world,
-                                       {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}),
+            "roofline": roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, args.emulate_world if args.emulate_world > 1 else world,
+                                       {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]},
+                                       r.build_info(), sec_per_step, prof["connect"]),
         }
         out["frame_checksum"] = "%016x" % int(torch.sum(acc.view(torch.int32).to(torch.int64)).item() & 0xFFFFFFFFFFFFFFFF)
         if world == 1 and not args.no_cpu_baseline:
@@ -176,20 +180,24 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_hash():
-    """Hash of the kernel sources: counter files measured on other kernels are ignored (profiles/valu_roofline.py
-    stamps the same hash; .git does not travel to the GPU box, so a commit id cannot be used)."""
+def kernel_hash(build_info=""):
+    """Hash of everything that decides how many instructions / bytes a launch issues: the device sources, rt_api.hip
+    (round loop, launch geometry, tuning defaults), the Makefile, and the library's own account of its compile flags
+    (EXTRA=...) and of the tuning the context resolved from the environment (rt_build_info / rt_tuning_info).  Counter
+    files measured on anything else are ignored (profiles/valu_roofline.py stamps the same hash; .git does not travel to
+    the GPU box, so a commit id cannot be used)."""
     import hashlib
     d = os.path.join(ROOT, "ray-and-pathtracer_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f.endswith(".h") or f == "Makefile":  # the device code (kernels, traversal, arithmetic) and its compile flags; rt_api.hip is host code
+        if f.endswith(".h") or f.endswith(".hip") or f == "Makefile":
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
+    h.update(build_info.encode())
     return h.hexdigest()[:16]
 
 
-def roofline_block(args, ha, near, avg_ms, launches_per_step, W, H, spp, world, kernel_ms):
+def roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, world, kernel_ms, build_info, sec_per_step, prof_connect):
     """Dominant kernel k_extend (Scene::FindNearest).  What binds it, measured (DESIGN.md section 5): neither HBM
     (the scene is a few MB and lives in L1/L2; counter HBM traffic is ~1.6 TB/s) nor MFMA (none on this path) but
     the CUs' vector pipelines -- the VALU with ~43 % of its lanes enabled and the vector-memory (TA/L1) gather
@@ -214,18 +222,34 @@ def roofline_block(args, ha, near, avg_ms, launches_per_step, W, H, spp, world, 
                   "algorithmic_frac_of_hbm_peak": round(alg_per_launch / sec / 8e12, 4) if sec > 0 else None,
                   "note": "algorithmic bytes (SURVEY 8d: every node pair and primitive a ray touches, as if fetched from memory) exceed what HBM delivers because the scene is served from L1/L2: a demand figure, not a roofline"},
           "algorithmic_work_per_step": {k: int(near[k]) for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits", "rays_nearest")}}
+    # the same SURVEY 8(d) figure for the any-hit kernel and for the whole step (both traversal kernels' bytes over the step time;
+    # rank 0's rows when the frame is sharded)
+    bytes_connect = ha.algorithmic_bytes(occl, executed=True)
+    con_launches = max(1.0, prof_connect["launches"] / max(1, args.steps))
+    con_sec = prof_connect["ms"] / max(1, prof_connect["launches"]) * 1e-3
+    rb["hbm"]["connect_algorithmic_bytes_per_launch"] = int(bytes_connect / con_launches)
+    rb["hbm"]["connect_algorithmic_GBps"] = round(bytes_connect / con_launches / con_sec / 1e9, 2) if con_sec > 0 else None
+    rb["hbm"]["step_algorithmic_bytes"] = int(bytes_extend + bytes_connect)
+    rb["hbm"]["step_algorithmic_GBps"] = round((bytes_extend + bytes_connect) / sec_per_step / 1e9, 2) if sec_per_step > 0 else None
+    rb["hbm"]["step_algorithmic_frac_of_hbm_peak"] = round((bytes_extend + bytes_connect) / sec_per_step / 8e12, 4) if sec_per_step > 0 else None
+    rb["build"] = build_info
     ppath = os.path.join(ROOT, "profiles", "roofline_pmc.json")
     try:
         pj = json.load(open(ppath))
     except Exception:
         pj = None
-    if os.environ.get("RT_FUSE", "2") != "0":
-        rb["note"] = ("path batches run extend(r + 1) beside connect(r) + light(r) on a second stream (DESIGN.md findings 19, 33): the kernel "
-                      "times of kernel_ms_per_step overlap and do not add up to the step; avg_launch_ms is the extend launches' own duration "
-                      "with that company (RT_FUSE=0: one kernel at a time)")
-    usable = (pj is not None and pj.get("kernel_hash") == kernel_hash() and world == 1 and
-              pj.get("workload") == [args.workload, W, H, spp])
-    rb["pmc"] = {"file": "profiles/roofline_pmc.json", "used": bool(usable), "kernel_hash": kernel_hash(),
+    rb["note"] = ("batches below 100 M samples (and RT_FUSE=2) run connect(r) + light(r) on a second stream beside extend(r + 1): the kernel times of "
+                  "kernel_ms_per_step then overlap and do not add up to the step, and avg_launch_ms is the extend launches' own duration with that "
+                  "company (RT_FUSE=0: one kernel at a time)")
+    # with N ranks the counter file is used when it was measured on this rank's share: the row shard renders H / N rows of every
+    # frame, the counter file of the 1-GPU share ("--spp S/N": the same number of samples per rank) is the closest committed
+    # stand-in and is NOT used -- frac stays null unless a file for exactly [workload, W, H, spp, world] exists
+    khash = kernel_hash(build_info)
+    if pj is not None and "by_world" in pj:  # one counter set per number of ranks (rank 0's rows of the N-rank shard, measured with --emulate-world N)
+        pj = pj["by_world"].get(str(world))
+    usable = (pj is not None and pj.get("kernel_hash") == khash and
+              pj.get("workload") == [args.workload, W, H, spp] and pj.get("world", 1) == world)
+    rb["pmc"] = {"file": "profiles/roofline_pmc.json", "used": bool(usable), "kernel_hash": khash,
                  "file_kernel_hash": pj.get("kernel_hash") if pj else None}
     if usable and sec > 0:
         k = pj["kernels"]["k_extend"]

@@ -243,6 +243,11 @@ int rt_get_counters_split(rt_ctx* ctx, rt_counters* nearest, rt_counters* occlud
 int rt_set_profiling(rt_ctx* ctx, int profiling);
 int rt_get_profile(rt_ctx* ctx, rt_profile* out, int reset);
 int rt_synchronize(rt_ctx* ctx);
+/* What the library was built with (the -D flags given to the build and the compile-time tuning macros), and the tuning a
+ * context resolved from its environment at rt_create (RT_* variables): measurement files are stamped with both, so that
+ * counters taken on one build / tuning are not priced against timings of another.  Static / context-owned strings. */
+const char* rt_build_info(void);
+const char* rt_tuning_info(rt_ctx* ctx);
 
 #ifdef __cplusplus
 }

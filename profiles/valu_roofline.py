@@ -16,7 +16,7 @@ For the traversal kernel k_extend (all timed variants summed) per step of the be
                       CU: every vector-memory instruction passes through) are busy, averaged over them / for the busiest
   ta_cycles_per_vmem_inst   TA_TA_BUSY_sum / SQ_INSTS_VMEM: addresser-busy cycles per vector-memory instruction
 The file is stamped with a hash of the kernel sources (csrc/); bench.py ignores it when the sources changed.
-Usage: valu_roofline.py <pmc_summary.json> <workload> <width> <height> <spp>   (what the profiled bench.py run rendered)"""
+Usage: valu_roofline.py <pmc_summary.json> <workload> <width> <height> <spp> <kernel_hash of the profiled run's bench line>"""
 import hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,13 +25,9 @@ SIMDS = 1024
 
 
 def kernel_hash():
-    d = os.path.join(ROOT, "ray-and-pathtracer_amd", "csrc")
-    h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith(".h") or f == "Makefile":  # the device code (kernels, traversal, arithmetic) and its compile flags; rt_api.hip is host code
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """bench.py's kernel_hash(): sources + the library's build / tuning account, read from the bench line of the profiled run
+    (its roofline.pmc.kernel_hash), passed as argv[6] -- a hash recomputed here could not know the environment of that run."""
+    return sys.argv[6]
 
 
 def main():

@@ -25,7 +25,7 @@ struct Timer {
 struct rt_ctx {
 	int device = 0, width = 0, height = 0;
 	hipStream_t stream = nullptr;
-	std::string err;
+	std::string err, tuningInfo;
 	// scene
 	DScene S;
 	bool sceneLoaded = false;
@@ -1946,6 +1946,29 @@ int rt_get_profile(rt_ctx* c, rt_profile* out, int reset)
 	if (reset) memset(&c->prof, 0, sizeof(c->prof));
 	return RT_OK;
 }
+#ifndef RT_EXTRA_FLAGS
+#define RT_EXTRA_FLAGS ""
+#endif
+#define RT_STR2(x) #x
+#define RT_STR(x) RT_STR2(x)
+const char* rt_build_info(void)
+{
+	return "flags=[" RT_EXTRA_FLAGS "] RT_PAIR_REPEAT=" RT_STR(RT_PAIR_REPEAT) " RT_CONNECT_REPEAT=" RT_STR(RT_CONNECT_REPEAT) " RT_HEADS=" RT_STR(RT_HEADS)
+	       " RT_HEADS_PROBE=" RT_STR(RT_HEADS_PROBE) " RT_EXTEND_WAVES=" RT_STR(RT_EXTEND_WAVES) " RT_CONNECT_WAVES=" RT_STR(RT_CONNECT_WAVES)
+	       " RT_SHADE_S_WAVES=" RT_STR(RT_SHADE_S_WAVES) " RT_STACK_ROWS_MIN=" RT_STR(RT_STACK_ROWS_MIN) " RT_SHORT_QUEUE_RAYS=" RT_STR(RT_SHORT_QUEUE_RAYS)
+	       " RT_CHUNK_MIN=" RT_STR(RT_CHUNK_MIN) " RT_LDS_WORDS=" RT_STR(RT_LDS_WORDS);
+}
+const char* rt_tuning_info(rt_ctx* c)
+{
+	if (!c) return "";
+	char buf[512];
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d wide=%d tlas_lds=%d stack_rows=%d slots=%d",
+	         c->useStream, c->decideRays, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
+	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->S.wide ? 1 : 0, c->S.tlasLds, c->S.stackRows, slot_budget(c));
+	c->tuningInfo = buf;
+	return c->tuningInfo.c_str();
+}
+
 int rt_synchronize(rt_ctx* c)
 {
 	if (!c) return RT_E_ARG;

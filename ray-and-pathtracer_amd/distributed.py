@@ -6,35 +6,81 @@ The path shards naturally: pixels are independent (one RNG stream per pixel and 
 is read-only, so every rank holds a full copy of the scene and renders rows rank, rank + world, ...
 (rt_render_rows); interleaving balances sky rows against geometry rows.  The only exchange step is
 the final framebuffer gather: W*H*16 B * (world-1)/world into rank 0, e.g. 29 MB at 1080p / 8 ranks.
+xGMI is point to point, so a gather to one rank uses all of that rank's links at once; no ring.
 """
 import torch
 import torch.distributed as dist
 
 
 def shard_rows(height, rank, world):
-    """(row_first, row_stride, row_count) of rank's interleaved shard."""
+    """(row_first, row_stride, row_count) of rank's interleaved shard: the arguments of rt_render_rows."""
     count = len(range(rank, height, world))
     return rank, world, count
 
 
+class RowShard:
+    """The row shard of one rank and the buffers its gather needs, allocated ONCE (nothing is allocated inside a
+    timed step): 'send' holds the rank's rows densely, 'staging' on the destination rank receives every rank's
+    'send' ([world, rows per rank, W, 4]); the rows then go to their places in the frame with one strided copy."""
+
+    def __init__(self, height, width, rank, world, device, dst=0, dtype=torch.float32):
+        self.height, self.width, self.rank, self.world, self.dst = height, width, rank, world, dst
+        self.first, self.stride, self.count = shard_rows(height, rank, world)
+        self.per = (height + world - 1) // world  # rows of the largest shard: shards are padded to it, a plain gather suffices
+        self.send = self.staging = self.parts = None
+        if world > 1:
+            self.send = torch.zeros((self.per, width, 4), dtype=dtype, device=device)
+            if rank == dst:
+                self.staging = torch.zeros((world, self.per, width, 4), dtype=dtype, device=device)
+                self.parts = list(self.staging.unbind(0))  # contiguous views: the gather writes straight into the staging tensor
+
+    def rows(self):
+        """(row_first, row_stride, row_count) for rt_render_rows"""
+        return self.first, self.stride, self.count
+
+    def gather(self, acc):
+        """acc: [H, W, 4] tensor whose rows rank::world were rendered locally.  After the call rank dst holds every row."""
+        if self.world == 1:
+            return acc
+        self.send[: self.count].copy_(acc[self.rank :: self.world])
+        if self.rank == self.dst:
+            dist.gather(self.send, self.parts, dst=self.dst)
+            if self.height % self.world == 0:
+                # row y = k * world + r lives at staging[r, k]: one strided copy for the whole frame (the destination's own
+                # rows come back unchanged from its own 'send')
+                acc.view(self.per, self.world, self.width, 4).copy_(self.staging.permute(1, 0, 2, 3))
+            else:
+                for r in range(self.world):
+                    if r != self.dst:
+                        n = len(range(r, self.height, self.world))
+                        acc[r :: self.world] = self.staging[r, :n]
+        else:
+            dist.gather(self.send, None, dst=self.dst)
+        return acc
+
+
 def gather_rows(acc, rank, world, dst=0):
-    """acc: [H, W, 4] float32 tensor (any device) whose rows rank::world were rendered locally.
-    After the call rank dst holds every row.  Row counts may differ by one between ranks; shards are
-    padded to the largest so a plain gather suffices."""
+    """One-off form of RowShard.gather (allocates its buffers; tests and small tools)."""
     if world == 1:
         return acc
-    height = acc.shape[0]
-    per = (height + world - 1) // world
-    local = acc[rank::world]
-    send = torch.zeros((per,) + tuple(acc.shape[1:]), dtype=acc.dtype, device=acc.device)
-    send[: local.shape[0]] = local
-    if rank == dst:
-        parts = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, parts, dst=dst)
-        for r in range(world):
-            n = len(range(r, height, world))
-            if r != dst:
-                acc[r::world] = parts[r][:n]
+    return RowShard(acc.shape[0], acc.shape[1], rank, world, acc.device, dst, acc.dtype).gather(acc)
+
+
+def render_step(renderer, acc, mode, frame0, frames, shard, host_staging=None):
+    """One bench / Tick step of a rank: render the shard's rows into acc (the tensor bound as the renderer's accumulator),
+    then gather them to the destination rank.  'renderer' is host_api.HostRenderer (render_rows -> rt_render_rows,
+    synchronize -> rt_synchronize) or anything with those two methods.  host_staging: a pinned-size CPU tensor for the
+    gloo rehearsal mode (ranks share a GPU, the gather goes through host memory); its RowShard is host_staging[1]."""
+    first, stride, count = shard.rows()
+    if count > 0:
+        renderer.render_rows(mode, frame0, frames, first, stride, count)
+    renderer.synchronize()
+    if host_staging is None:
+        shard.gather(acc)
     else:
-        dist.gather(send, None, dst=dst)
+        host, host_shard = host_staging
+        host.copy_(acc)
+        host_shard.gather(host)
+        if shard.rank == shard.dst:
+            acc.copy_(host)
     return acc

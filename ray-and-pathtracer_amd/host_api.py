@@ -25,7 +25,7 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
               "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_device_of",
-              "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy"]
+              "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy", "rt_build_info", "rt_tuning_info"]
 
 
 class RtCamera(C.Structure):
@@ -75,6 +75,10 @@ def rt_lib():
         L.rt_create.argtypes = [C.c_int, C.c_int, C.c_int]
         L.rt_last_error.restype = C.c_char_p
         L.rt_last_error.argtypes = [C.c_void_p]
+        L.rt_build_info.restype = C.c_char_p
+        L.rt_build_info.argtypes = []
+        L.rt_tuning_info.restype = C.c_char_p
+        L.rt_tuning_info.argtypes = [C.c_void_p]
         L.rt_accumulator_device_ptr.restype = C.c_void_p
         L.rt_accumulator_device_ptr.argtypes = [C.c_void_p]
         for name in ["rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_set_time", "rt_clear", "rt_synchronize"]:
@@ -496,6 +500,10 @@ class HostRenderer:
         b = np.zeros(8, dtype=np.uint64)
         self._rt(self.rt.rt_get_counters_split(self.ctx, _p(a), _p(b), int(reset)))
         return dict(zip(COUNTER_NAMES, [int(x) for x in a])), dict(zip(COUNTER_NAMES, [int(x) for x in b]))
+
+    def build_info(self):
+        """rt_build_info() + rt_tuning_info(): compile flags / compile-time tuning of the library and the tuning this context resolved"""
+        return self.rt.rt_build_info().decode() + " | " + self.rt.rt_tuning_info(self.ctx).decode()
 
     def set_profiling(self, on):
         self._rt(self.rt.rt_set_profiling(self.ctx, int(on)))

@@ -62,6 +62,66 @@ def test_row_shard_gather_equals_single_process(world, h, tmp_path, scenes, orac
     assert np.array_equal(got.view(np.uint32), r.accumulator().view(np.uint32))
 
 
+class _RowPainter:
+    """Stands where host_api.HostRenderer stands in distributed.render_step (the code bench.py runs per step): checks the
+    row arguments exactly as rt_render_rows does (csrc/rt_api.hip: row_first >= 0, row_stride >= 1, row_count >= 1,
+    last row inside the frame) and paints the rows it is asked for -- y = row_first + k * row_stride, k < row_count, the
+    C ABI's rule (include/rt_amd.h) -- with a value that names the row, the frame range and how often it was painted."""
+
+    def __init__(self, acc):
+        self.acc = acc
+        self.synced = 0
+
+    def render_rows(self, mode, frame0, nframes, row_first, row_stride, row_count):
+        h, w = self.acc.shape[0], self.acc.shape[1]
+        assert not (row_first < 0 or row_stride < 1 or row_count < 1 or row_first + (row_count - 1) * row_stride >= h)
+        for k in range(row_count):
+            y = row_first + k * row_stride
+            self.acc[y, :, 0] += torch.arange(w, dtype=torch.float32) + 1000.0 * y
+            self.acc[y, :, 1] += float(nframes)
+            self.acc[y, :, 2] += 1.0  # painted once
+            self.acc[y, :, 3] = float(frame0)
+
+    def synchronize(self):
+        self.synced += 1
+
+
+def _product_worker(rank, world, port, w, h, out_path):
+    sys.path.insert(0, ROOT)
+    import importlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dpar = importlib.import_module("ray-and-pathtracer_amd.distributed")
+    acc = torch.zeros((h, w, 4), dtype=torch.float32)
+    shard = dpar.RowShard(h, w, rank, world, acc.device)
+    painter = _RowPainter(acc)
+    for _ in range(2):  # two steps through the same preallocated buffers, like bench.py's timed loop
+        acc.zero_()
+        dpar.render_step(painter, acc, 1, 7, 5, shard)
+    assert painter.synced == 2
+    if rank == 0:
+        np.save(out_path, acc.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 20), (2, 21), (3, 20), (3, 24), (4, 9)])
+def test_product_shard_bookkeeping(world, h, tmp_path):
+    """bench.py's step (distributed.render_step: RowShard.rows() -> render_rows -> gather into preallocated buffers) with
+    a renderer that enforces rt_render_rows' argument rules: after the gather rank 0 holds every row exactly once, the
+    right row at the right place, for heights that do and do not divide by the number of ranks."""
+    w = 13
+    out = str(tmp_path / "acc.npy")
+    mp.spawn(_product_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
+    got = np.load(out)
+    want = np.zeros((h, w, 4), np.float32)
+    for y in range(h):
+        want[y, :, 0] = np.arange(w, dtype=np.float32) + 1000.0 * y
+        want[y, :, 1], want[y, :, 2], want[y, :, 3] = 5.0, 1.0, 7.0
+    assert np.array_equal(got, want)
+
+
 def test_shard_rows_partition():
     dpar = __import__("importlib").import_module("ray-and-pathtracer_amd.distributed")
     for h in (1, 7, 8, 1080, 2160):
