@@ -75,6 +75,9 @@ struct rt_ctx {
 	uint* streamSideSpill = nullptr;
 	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
+	int twoRays = 0;         // RT_TWO: the stream pipeline's traversal kernels carry two rays per lane (trace_persistent<TWO>): bit 0 extend, bit 1 connect
+	int gridExtendS2 = 0, gridConnectS2 = 0;
+	uint* spill2 = nullptr; uint* sideSpill2 = nullptr; // their spill columns (two per lane)
 	int shadeLds = 1;        // RT_SHADE_LDS: the shading kernels keep the material / brute-force primitive tables in LDS
 	int gridShadeS = 0, gridLightS = 0; // resident blocks of the grid-stride shading kernels (a second, partial round of blocks would run at low occupancy)
 	int decideRays = 1;      // RT_DECIDE: producers answer rays whose first traversal step leaves nothing to visit (rt_stream.h ray_decided)
@@ -276,6 +279,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0..2; anything else: the default
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
+	if (getenv("RT_TWO")) c->twoRays = atoi(getenv("RT_TWO")) & 3;
 	if (getenv("RT_SHADE_LDS")) c->shadeLds = atoi(getenv("RT_SHADE_LDS")) != 0;
 	memset(&c->T, 0, sizeof(c->T));
 	if (c->nPoolsWanted < 1) c->nPoolsWanted = 1;
@@ -303,6 +307,8 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridConnectS = std::min(resident((const void*)k_connect_s<false>), resident((const void*)k_connect_s<true>));
 		c->gridConnectWideS = resident((const void*)k_connect_s<false, true>);
 		c->gridLeftoverS = std::min(resident((const void*)k_connect_s<false, false, true>), prop.multiProcessorCount);
+		c->gridExtendS2 = std::min(resident((const void*)k_extend_s2<false>), resident((const void*)k_extend_s2<true>));
+		c->gridConnectS2 = std::min(resident((const void*)k_connect_s2<false>), resident((const void*)k_connect_s2<true>));
 		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_shade_s);
 		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
@@ -368,6 +374,8 @@ void rt_destroy(rt_ctx* c)
 		if (pl.sideJoin) (void)hipEventDestroy(pl.sideJoin);
 	}
 	free_pool(c->streamAllocs);
+	if (c->spill2) (void)hipFree(c->spill2);
+	if (c->sideSpill2) (void)hipFree(c->sideSpill2);
 	if (c->streamSide) { (void)hipStreamSynchronize(c->streamSide); (void)hipStreamDestroy(c->streamSide); }
 	if (c->streamSideSpill) (void)hipFree(c->streamSideSpill);
 	if (c->streamFork) (void)hipEventDestroy(c->streamFork);
@@ -653,6 +661,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	}
 	S.useTLAS = d->use_tlas ? 1 : 0;
 	S.stackRows = RT_STACK_ROWS_MAX;
+	S.stackRows2 = RT_LDS_WORDS2 / RT_BLOCK / 2 - 6;
 
 	if (d->use_tlas) {
 		std::vector<DInstance> inst(d->n_instances);
@@ -808,6 +817,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			S.tlasLds = rows >= RT_STACK_ROWS_MIN ? 1 : 0;
 			if (getenv("RT_TLAS_LDS")) S.tlasLds = S.tlasLds && atoi(getenv("RT_TLAS_LDS")) != 0;
 			if (S.tlasLds) S.stackRows = rows < RT_STACK_ROWS_MAX ? rows : RT_STACK_ROWS_MAX;
+			// two rays per lane: two stack columns (+ world-ray rows) per lane beside the same TLAS copy; too few rows: one ray per lane
+			const int rows2 = S.tlasLds ? ((RT_LDS_WORDS2 - ((words + 3) & ~3)) / RT_BLOCK) / 2 - 6 : RT_LDS_WORDS2 / RT_BLOCK / 2 - 6;
+			S.stackRows2 = rows2 >= RT_STACK_ROWS_MIN2 ? rows2 : 0;
 		}
 	}
 	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);
@@ -1356,6 +1368,11 @@ static int ensure_stream_state(rt_ctx* c, int n)
 		HIPCHK(c, hipEventCreateWithFlags(&c->streamFork, hipEventDisableTiming));
 		HIPCHK(c, hipEventCreateWithFlags(&c->streamJoin, hipEventDisableTiming));
 	}
+	if (c->twoRays && !c->spill2) {
+		const size_t words = (size_t)2 * (RT_STACK_MAX - RT_STACK_ROWS_MIN2) * c->gridBlocks * RT_BLOCK;
+		HIPCHK(c, hipMalloc((void**)&c->spill2, words * sizeof(uint)));
+		HIPCHK(c, hipMalloc((void**)&c->sideSpill2, words * sizeof(uint)));
+	}
 	if (c->streamCap >= n && c->streamLights == c->S.nLights && (c->streamWide || !wide)) return RT_OK;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->streamSide));
@@ -1387,10 +1404,13 @@ static int ensure_stream_state(rt_ctx* c, int n)
 	c->streamCap = (int)cap, c->streamLights = c->S.nLights, c->streamWide = wide;
 	return RT_OK;
 }
-static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int parity, uint* spill)
+static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int parity, uint* spill, uint* spillTwo)
 {
 	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27);
-	if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
+	if ((c->twoRays & 2) && c->S.stackRows2 > 0 && !c->S.wide) {
+		if (c->counting) hipLaunchKernelGGL((k_connect_s2<true>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spillTwo, c->counters + 1);
+		else hipLaunchKernelGGL((k_connect_s2<false>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spillTwo, c->counters + 1);
+	} else if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
 	else if (!c->S.wide) hipLaunchKernelGGL((k_connect_s<false>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
 	else {
 		hipLaunchKernelGGL((k_connect_s<false, true>), dim3(c->gridConnectWideS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
@@ -1423,7 +1443,10 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, st, T, 1, parity, round == 0 ? n : -1);
 		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, parity);
 		prof_begin(c, K_EXTEND, st);
-		if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+		if ((c->twoRays & 1) && c->S.stackRows2 > 0) {
+			if (c->counting) hipLaunchKernelGGL((k_extend_s2<true>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
+			else hipLaunchKernelGGL((k_extend_s2<false>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
+		} else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		prof_end(c, st);
 		hipLaunchKernelGGL(k_assign, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, parity);
@@ -1437,7 +1460,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		}
 		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, sb, T, 2, parity, -1);
 		prof_begin(c, K_CONNECT, sb);
-		launch_connect_s(c, sb, T, parity, twoStreams ? c->streamSideSpill : c->spill);
+		launch_connect_s(c, sb, T, parity, twoStreams ? c->streamSideSpill : c->spill, twoStreams ? c->sideSpill2 : c->spill2);
 		prof_end(c, sb);
 		prof_begin(c, K_SHADE, sb);
 		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, parity, last, c->shadeLds);

@@ -267,6 +267,25 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S
 	}
 }
 
+// the same two kernels with two rays per lane (trace_persistent<TWO>, rt_scene_dev.h)
+#ifndef RT_TWO_WAVES
+#define RT_TWO_WAVES 5
+#endif
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_extend_s2(DScene S, StreamState T, int parity, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
+{
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS2];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	StreamExtendPolicy pol{ S, T, parity, last, &T.counts[SC_FLAG] };
+	trace_persistent<false, COUNT, false, StreamExtendPolicy, false, false, RT_PAIR_REPEAT, true>(S, pol, T.counts[SC_TRACE], T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+	if (COUNT) {
+		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
+		flush_counters(counters, lc, rays, 0);
+	}
+}
+
 // assign: pos[e] = (number of CL_CONT entries before e, number of CL_SHADOW entries before e) + the block's bases; the
 // totals become the next round's entry count and this round's shadow count.  Same shape as compact_body: a wave owns a
 // contiguous range, counts it, the block reserves with one atomic per counter, then every lane writes the positions of
@@ -517,6 +536,19 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene
 		trace_persistent<true, COUNT, false, ListedPolicy<StreamConnectPolicy>, false, false, RT_CONNECT_REPEAT>(S, lp, T.counts[SC_LEFTOVER], heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	} else
 		trace_persistent<true, COUNT, false, StreamConnectPolicy, false, WIDE, RT_CONNECT_REPEAT>(S, pol, nShadow * S.nLights, heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+	if (COUNT) flush_counters(counters, lc, 0, rays);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_connect_s2(DScene S, StreamState T, int parity, int refillMin, uint* spill, DCounters* counters)
+{
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS2];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	const int nShadow = T.counts[SC_SHADOW + parity];
+	StreamConnectPolicy pol{ T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] };
+	trace_persistent<true, COUNT, false, StreamConnectPolicy, false, false, RT_CONNECT_REPEAT, true>(S, pol, nShadow * S.nLights, T.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 

@@ -979,14 +979,15 @@ def test_fused_traversal_launch_equals_separate_launches(name, kw, w, h, frames,
 def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
     """The dense path pipeline (csrc/rt_stream.h, the default: entries of a round are the survivors of the round before,
     every producer writes to compacted positions; RT_FUSE=0 runs it one kernel at a time) and its producer-side ray
-    decisions (RT_DECIDE: generate / shade answer a ray whose first traversal step leaves nothing to visit) against the
-    slot pipeline (RT_STREAM=0): identical accumulator bits -- per sample the arithmetic is the same, only where the path
+    decisions (RT_DECIDE: generate / shade answer a ray whose first traversal step leaves nothing to visit), also with two
+    rays per lane in its traversal kernels (RT_TWO, trace_persistent<TWO>), against the slot pipeline (RT_STREAM=0): identical accumulator bits -- per sample the arithmetic is the same, only where the path
     state lives differs -- the oracle's frame, identical frames from row shards, identical Sample() values for
     caller-supplied rays at every depth, and the same number of FindNearest / IsOccluded queries."""
     out, rays = {}, {}
     pO = pD = None
-    for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_nodecide", {"RT_DECIDE": "0"})):
-        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE"):
+    for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
+                     ("stream_two_rays", {"RT_TWO": "3", "RT_FUSE": "2"})):
+        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_TWO"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1014,7 +1015,7 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
                 pO, pD = pO[::7].copy(), pD[::7].copy()
             out[key + "_sample"] = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 99) for depth in (0, 1, 4)]
         r.close()
-    for key in ("stream", "stream_serial", "stream_nodecide"):
+    for key in ("stream", "stream_serial", "stream_nodecide", "stream_two_rays"):
         assert np.array_equal(out["slot"].view(np.uint32), out[key].view(np.uint32)), key
         assert rays[key] == rays["slot"], (key, rays[key], rays["slot"])
     for a, b in zip(out["slot_sample"], out["stream_sample"]):
