@@ -18,5 +18,10 @@ for name, kw, w, h in (("mixed_small", {}, 1920, 1080), ("pretty_tlas", {"n_inst
             for _ in range(n):
                 r.tick()
             dt = (time.perf_counter() - t) / n
-            print("%s %dx%d %s Tick, accumulator mirrored to the host %s: %.2f ms per Tick (%.0f M primary samples/s)" % (name, w, h, "path" if path else "Whitted", "every Tick" if download else "never", dt * 1e3, w * h / dt / 1e6), flush=True)
+            r.set_profiling(True); r.profile()
+            for _ in range(5):
+                r.tick()
+            pr = r.profile(); r.set_profiling(False)
+            kern = ", ".join("%s %.2f" % (k, v["ms"] / 5) for k, v in pr.items() if v["launches"])
+            print("%s %dx%d %s Tick, accumulator mirrored to the host %s: %.2f ms per Tick (%.0f M primary samples/s); kernels per Tick (ms): %s" % (name, w, h, "path" if path else "Whitted", "every Tick" if download else "never", dt * 1e3, w * h / dt / 1e6, kern), flush=True)
             r.close()

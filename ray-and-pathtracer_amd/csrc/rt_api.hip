@@ -3,6 +3,7 @@
 // (rt_scene_dev.h), the round loop of the wavefront pixel loop, batch queries, counters, profiling.
 #include "rt_kernels.h"
 #include "rt_stream.h"
+#include "rt_mega.h"
 #include "rt_build.h"
 #include "../../include/rt_amd.h"
 #include <algorithm>
@@ -75,6 +76,11 @@ struct rt_ctx {
 	uint* streamSideSpill = nullptr;
 	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
+	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
+	MegaState M;
+	std::vector<void*> megaAllocs;
+	int megaLanes = 0, gridMega = 0;
+	int useMega = 1;         // RT_MEGA: 1 Whitted frames as one launch (default), 0 the wavefront rounds of rt_kernels.h
 	int twoRays = 0;         // RT_TWO: the stream pipeline's traversal kernels carry two rays per lane (trace_persistent<TWO>): bit 0 extend, bit 1 connect
 	int gridExtendS2 = 0, gridConnectS2 = 0;
 	uint* spill2 = nullptr; uint* sideSpill2 = nullptr; // their spill columns (two per lane)
@@ -279,6 +285,8 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0..2; anything else: the default
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
+	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
+	memset(&c->M, 0, sizeof(c->M));
 	if (getenv("RT_TWO")) c->twoRays = atoi(getenv("RT_TWO")) & 3;
 	if (getenv("RT_SHADE_LDS")) c->shadeLds = atoi(getenv("RT_SHADE_LDS")) != 0;
 	memset(&c->T, 0, sizeof(c->T));
@@ -309,6 +317,7 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridLeftoverS = std::min(resident((const void*)k_connect_s<false, false, true>), prop.multiProcessorCount);
 		c->gridExtendS2 = std::min(resident((const void*)k_extend_s2<false>), resident((const void*)k_extend_s2<true>));
 		c->gridConnectS2 = std::min(resident((const void*)k_connect_s2<false>), resident((const void*)k_connect_s2<true>));
+		c->gridMega = resident((const void*)k_whitted_mega);
 		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_shade_s);
 		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
@@ -374,6 +383,7 @@ void rt_destroy(rt_ctx* c)
 		if (pl.sideJoin) (void)hipEventDestroy(pl.sideJoin);
 	}
 	free_pool(c->streamAllocs);
+	free_pool(c->megaAllocs);
 	if (c->spill2) (void)hipFree(c->spill2);
 	if (c->sideSpill2) (void)hipFree(c->sideSpill2);
 	if (c->streamSide) { (void)hipStreamSynchronize(c->streamSide); (void)hipStreamDestroy(c->streamSide); }
@@ -1358,6 +1368,55 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams* Rs, int nPools, int r
 	return RT_OK;
 }
 
+// ---- Whitted frames as one persistent launch (rt_mega.h) -----------------------------------------------
+static int run_whitted_mega(rt_ctx* c, const RenderParams& R0)
+{
+	RenderParams R = R0;
+	// deal the frame out in tiles of 64 pixels from all over it (rt_mega.h sample_of): the multiplier nearest nTiles / 61 that is coprime to nTiles
+	if (R.nSamples >= 16384 && !(getenv("RT_MEGA_PERM") && atoi(getenv("RT_MEGA_PERM")) == 0)) {
+		auto gcd = [](unsigned a, unsigned b) { while (b) { const unsigned t = a % b; a = b; b = t; } return a; };
+		R.permShift = getenv("RT_MEGA_TILE") ? (unsigned)atoi(getenv("RT_MEGA_TILE")) : 3; // tiles of 8 pixels (profiles/r03_tick_mega.txt)
+		if (R.permShift > 8) R.permShift = 8;
+		const unsigned nTiles = (R.nSamples + (1u << R.permShift) - 1) >> R.permShift;
+		unsigned p = nTiles / 61 | 1;
+		while (gcd(p, nTiles) != 1) p += 2;
+		R.permMul = p;
+	}
+	const int lanes = c->gridMega * RT_BLOCK;
+	if (c->megaLanes < lanes) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		free_pool(c->megaAllocs);
+		MegaState M;
+		memset(&M, 0, sizeof(M));
+		std::vector<void*>& A = c->megaAllocs;
+		const size_t n = (size_t)lanes;
+		HIPCHK(c, dalloc(A, &M.O, n)); HIPCHK(c, dalloc(A, &M.D, n)); HIPCHK(c, dalloc(A, &M.W, n)); HIPCHK(c, dalloc(A, &M.E, n)); HIPCHK(c, dalloc(A, &M.L, n));
+		HIPCHK(c, dalloc(A, &M.hI, n)); HIPCHK(c, dalloc(A, &M.hN, n)); HIPCHK(c, dalloc(A, &M.hA, n)); HIPCHK(c, dalloc(A, &M.hS, n));
+		HIPCHK(c, dalloc(A, &M.pend, n * RT_PEND_CAP * 4));
+		M.lanes = lanes;
+		c->M = M, c->megaLanes = lanes;
+	}
+	int grid = ((int)R.nSamples + RT_SHORT_QUEUE_RAYS * 64 - 1) / (RT_SHORT_QUEUE_RAYS * 64) + 1; // a short queue does not need the whole grid
+	if (grid > c->gridMega) grid = c->gridMega;
+	(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
+	prof_begin(c, K_EXTEND);
+	// a flush runs the body of Trace for the lanes that finished a query: it waits for more of them than a plain store does (RT_REFILL_MEGA, 32: 5.0 -> 4.85 ms)
+	const int refillMega = getenv("RT_REFILL_MEGA") && atoi(getenv("RT_REFILL_MEGA")) > 0 && atoi(getenv("RT_REFILL_MEGA")) <= 64 ? atoi(getenv("RT_REFILL_MEGA")) : 32;
+	hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
+	prof_end(c);
+	int f = 0;
+	HIPCHK(c, hipMemcpyAsync(c->hostCounts, c->flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	f = c->hostCounts[0];
+	if (f != 0) (void)hipMemsetAsync(c->flags, 0, 2 * sizeof(int), c->stream);
+	if (f == 2) return fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
+	if (f == 199) return fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
+	if (f >= 100) return fail(c, RT_E_STATE, "debug check %d failed in the Whitted kernel (RT_DEBUG_CHECKS build)", f - 100);
+	if (f) return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+	HIPCHK(c, hipGetLastError());
+	return RT_OK;
+}
+
 // ---- the dense path-mode pipeline (rt_stream.h) ------------------------------------------------------
 static int ensure_stream_state(rt_ctx* c, int n)
 {
@@ -1591,6 +1650,12 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 			if (rc != RT_OK) return rc;
 			continue;
 		}
+		if (mode == RT_MODE_WHITTED && c->useMega && !c->counting) {
+			rc = run_whitted_mega(c, R);
+			if (rc != RT_OK) return rc;
+			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
+			continue;
+		}
 		if (stream_eligible(c, mode, total)) {
 			rc = ensure_stream_state(c, (int)total);
 			if (rc != RT_OK) return rc;
@@ -1660,6 +1725,8 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 	if (mode == RT_MODE_PATH && c->pathUnsupported) {
 		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
 		rc = check_overflow(c);
+	} else if (mode == RT_MODE_WHITTED && c->useMega && !c->counting) {
+		rc = run_whitted_mega(c, R);
 	} else if (stream_eligible(c, mode, (size_t)n)) {
 		rc = ensure_stream_state(c, n);
 		R.finishInline = 1;

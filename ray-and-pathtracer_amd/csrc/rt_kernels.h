@@ -66,6 +66,8 @@ struct RenderParams {
 	// rt_trace_batch: caller rays instead of camera rays, raw radiance out instead of accumulation
 	const float* customO; const float* customD; float4* customOut; int customDepth;
 	float customE[3];  // rt_trace_batch_energy: the 'energy' argument of Trace / Sample
+	uint permShift;    // rt_mega.h: log2 of the tile the permutation deals out
+	uint permMul;      // rt_mega.h: work item w is sample (w * permMul) % nSamples (0: w itself), see run_whitted_mega
 	int finishInline;  // path mode with a slot per sample: nothing to resume and no sample to pull when a segment ends,
 	                   // so shade / light store the finished sample themselves and the round has no finish pass
 };

@@ -1,0 +1,232 @@
+// Renderer::Trace (Whitted, renderer.cpp:21-126) as ONE persistent launch per frame: the reference's interactive mode is one
+// frame per Tick, and a frame of the wavefront (rt_kernels.h) is 16 rounds x (extend + connect + four streaming kernels)
+// whose every traversal launch ends in a drain of 0.3-0.5 ms whatever it held (DESIGN.md finding 38): 8.7 of a Tick's 9 ms on
+// the instanced glass / metal scene.  Here a lane keeps its pixel: when a query ends, the lane's flush runs the body of
+// Trace at the hit right there (trace_persistent's advance hook) and goes on with the next query of the same pixel -- the
+// refracted ray, a shadow ray of the light loop, the most recent pending branch -- until the pixel's tree is done; only
+// then does it take another pixel from the queue.  One launch, one drain.  Traversal is the same lane-granular machine
+// (nearest-hit and any-hit lanes side by side, MIXED); per-pixel state lives in [field][lane of the grid] arrays, the
+// pending branches of glass (reflection waits while refraction runs) and of shiny diffuse hits on a per-lane stack.
+// Per pixel the segments run in the reference's depth-first order and every term is added to the radiance in the order the
+// wavefront kernels add it (shade: sky / light; light: W * direct after the light loop), so the frame is theirs bit for bit.
+#pragma once
+#include "rt_kernels.h"
+
+namespace rtd {
+
+struct MegaState { // [field][lane of the grid]
+	float4* O;   // current segment's ray, world space: origin
+	float4* D;   //                                     direction
+	float4* W;   // path weight xyz, w = depth (int)
+	float4* E;   // energy xyz, w = pending branches (int)
+	float4* L;   // radiance xyz
+	float4* hI;  // diffuse hit whose light loop is running: ray.IntersectionPoint() xyz, w = material
+	float4* hN;  //   normal xyz, w = light being tested (int)
+	float4* hA;  //   diffuse::scatter's value for that light xyz
+	float4* hS;  //   direct light so far xyz
+	float4* pend; // [lane][RT_PEND_CAP][4] {O,depth} {D,-} {W,-} {E,-}
+	int lanes;
+};
+
+struct WhittedMegaPolicy {
+	static constexpr bool kAdvance = true;
+	const DScene& S;
+	const DCamera& C;
+	const RenderParams& R;
+	const MegaState& M;
+	int gl;     // this lane's column in M
+	int* flag;
+
+	__device__ __forceinline__ bool any_of(int) const { return false; } // a pixel starts with Scene::FindNearest
+	// Work item -> sample.  Consecutive work items are handed to the lanes of one wave, and a pixel's cost is its tree: 1 segment
+	// for the sky, up to 15 glass segments of ~50 steps each for a pixel on a glass mesh.  In pixel order the waves that draw a
+	// piece of the glass region run long after the others have left (measured: a Tick of the instanced glass / metal scene 7.7 ms
+	// for ~2 ms of work).  So TILES of 64 consecutive pixels are dealt out in a multiplicative permutation (tile * P mod nTiles, P
+	// coprime to nTiles and about nTiles / 61): a wave's lanes still hold neighbouring pixels (coherent primary rays: permuting
+	// single pixels costs the scene-BVH test scene 13 %), but consecutive chunks of the queue come from all over the frame.
+	// Work items beyond the last sample (the last tile may be short) are nothing to trace.
+	__device__ __forceinline__ bool sample_of(int work, uint& sid) const
+	{
+		uint w = (uint)work;
+		if (R.permMul) {
+			const uint sh = R.permShift, nTiles = (R.nSamples + (1u << sh) - 1) >> sh;
+			w = ((uint)(((unsigned long long)(w >> sh) * R.permMul) % nTiles) << sh) + (w & ((1u << sh) - 1));
+		}
+		sid = R.sampleFirst + w;
+		return w < R.nSamples;
+	}
+	// head tests of Scene::FindNearest on a new nearest-hit ray (as emit_ray); the ray itself goes to M for the shading at its hit
+	__device__ __forceinline__ void new_segment(const f3& O, const f3& D, float& tmax, HitRef& head) const
+	{
+		float rayT = 1e34f;
+		head.kind = -1, head.inst = -1, head.prim = 0, head.t = 0;
+		LaneCounters unused;
+		find_nearest_head<false>(S, O, D, (float)1e-6, rayT, head, unused); // renderer.cpp:24
+		M.O[gl] = mk4(O, 0.0f), M.D[gl] = mk4(D, 0.0f);
+		tmax = rayT;
+	}
+	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
+	{
+		uint sid;
+		if (!sample_of(work, sid)) return false;
+		f3 E(1.0f);
+		if (R.customO) {
+			O = f3(R.customO[3 * sid], R.customO[3 * sid + 1], R.customO[3 * sid + 2]);
+			D = f3(R.customD[3 * sid], R.customD[3 * sid + 1], R.customD[3 * sid + 2]);
+			E = f3(R.customE[0], R.customE[1], R.customE[2]);
+		} else {
+			uint seed;
+			sample_primary(C, R, sid, O, D, seed);
+		}
+		M.W[gl] = make_float4(1, 1, 1, __int_as_float(start_depth(R)));
+		M.E[gl] = mk4(E, __int_as_float(0));
+		M.L[gl] = make_float4(0, 0, 0, 0);
+		new_segment(O, D, tmax, head);
+		return true;
+	}
+	__device__ __forceinline__ void push(int& np, const f3& O, const f3& D, const f3& W, const f3& E, int depth) const
+	{
+		if (np >= RT_PEND_CAP) { *flag = 2; return; }
+		float4* e = M.pend + ((size_t)gl * RT_PEND_CAP + np) * 4;
+		e[0] = mk4(O, __int_as_float(depth)), e[1] = mk4(D, 0.0f), e[2] = mk4(W, 0.0f), e[3] = mk4(E, 0.0f);
+		np++;
+	}
+	// the shadow ray of light i for the diffuse hit kept in M (renderer.cpp:93-99; as ConnectPolicy::load); false: no light left
+	__device__ __forceinline__ bool light_step(int i, const f3& I, const f3& normal, const f3& rayD, const DMaterial& m, f3& E, int np, const f3& direct,
+	                                           f3& O, f3& D, float& tmax, bool& nextAny) const
+	{
+		if (i >= S.nLights) return false;
+		uint unusedSeed = 0;
+		const f3 pickedPos = light_position(S.lights[i], true, unusedSeed);
+		f3 dir = pickedPos - I;
+		const float len2 = dot(dir, dir);
+		dir = normalize(dir);
+		// scatter first: the energy changes even when the light turns out to be occluded (renderer.cpp:95-96)
+		const f3 att = diffuse_scatter(m, rayD, dir, light_intensity(S.lights[i], I, normal, pickedPos), normal, E);
+		M.E[gl] = mk4(E, __int_as_float(np));
+		M.hN[gl] = mk4(normal, __int_as_float(i));
+		M.hA[gl] = mk4(att, 0.0f);
+		M.hS[gl] = mk4(direct, 0.0f);
+		O = I + dir * 1e-4f, D = dir, tmax = sqrtf(len2), nextAny = true;
+		return true;
+	}
+	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
+	{
+		const float4 w4 = M.W[gl], e4 = M.E[gl], l4 = M.L[gl];
+		f3 W = xyz(w4), E = xyz(e4), Lsum = xyz(l4);
+		const int depth = __float_as_int(w4.w);
+		int np = __float_as_int(e4.w);
+		const f3 rayO = xyz(M.O[gl]), rayD = xyz(M.D[gl]);
+		bool segmentEnds = true;
+		nextAny = false;
+		if (!wasAny) {
+			// ---- Trace at the hit of this segment (renderer.cpp:25-122; k_shade's Whitted branch) ----
+			int objIdx, matId;
+			f3 normal;
+			resolve_hit(S, res, rayO, rayD, objIdx, matId, normal);
+			const float t = res.t;
+			const f3 I = rayO + t * rayD;
+			const int nDepth = depth - 1;
+			const bool childTraces = nDepth > 0; // Trace(depth <= 0) = 0 (renderer.cpp:23)
+			f3 nO(0.0f), nD(0.0f), nW(0.0f);
+			if (objIdx == -1) Lsum = Lsum + W * sky_color(S, rayD);
+			else if (objIdx >= 11 && objIdx < 11 + S.nLights) Lsum = Lsum + W * light_intensity(S.lights[objIdx - 11], I, normal, I);
+			else {
+				const DMaterial m = S.mats[matId];
+				const f3 col(m.col[0], m.col[1], m.col[2]);
+				if (m.type == 3) { // GLASS, renderer.cpp:45-80: refraction now, reflection waits
+					const float kr = glass_fresnel(normalize(rayD), normalize(normal), m.ir);
+					const bool outside = dot(rayD, normal) < 0;
+					const f3 bias = 0.0001f * normal;
+					const f3 norm = outside ? normal : -normal;
+					const float r = !outside ? m.ir : (1 / m.ir);
+					if (outside) {
+						E.x *= x_expf(m.absorption[0] * -t);
+						E.y *= x_expf(m.absorption[1] * -t);
+						E.z *= x_expf(m.absorption[2] * -t);
+					}
+					const bool takeRefr = kr < 1;
+					f3 refrO(0.0f), refrD(0.0f), refrW(0.0f);
+					if (takeRefr) {
+						refrD = normalize(glass_refract(rayD, norm, r));
+						refrO = outside ? I - bias : I + bias;
+						const f3 tempCol = col * E;
+						refrW = W * (tempCol * (1 - kr));
+					}
+					const f3 reflD = normalize(reflect(rayD, norm));
+					const f3 reflO = outside ? I + bias : I - bias;
+					const f3 reflW = W * (col * kr);
+					if (childTraces) {
+						if (takeRefr) {
+							push(np, reflO, reflD, reflW, E, nDepth);
+							nO = refrO, nD = refrD, nW = refrW;
+						} else nO = reflO, nD = reflD, nW = reflW;
+						segmentEnds = false;
+					}
+				} else if (m.type == 2) { // METAL, renderer.cpp:81-86
+					nO = I + normal * 0.001f, nD = reflect(rayD, normal);
+					nW = W * (col * E);
+					if (childTraces) segmentEnds = false;
+				} else if (S.nLights > 0) { // DIFFUSE, renderer.cpp:87-122: the light loop, one shadow query at a time
+					M.hI[gl] = mk4(I, __int_as_float(matId));
+					M.L[gl] = mk4(Lsum, 0.0f);
+					if (light_step(0, I, normal, rayD, m, E, np, f3(0.0f), O, D, tmax, nextAny)) return true;
+				}
+			}
+			if (!segmentEnds) {
+				M.W[gl] = mk4(nW, __int_as_float(nDepth));
+				M.E[gl] = mk4(E, __int_as_float(np));
+				M.L[gl] = mk4(Lsum, 0.0f);
+				O = nO, D = nD;
+				new_segment(O, D, tmax, head);
+				return true;
+			}
+		} else {
+			// ---- the occlusion answer for light i of the diffuse hit (k_light's Whitted branch) ----
+			const float4 i4 = M.hI[gl], n4 = M.hN[gl], a4 = M.hA[gl], s4 = M.hS[gl];
+			const f3 I = xyz(i4), normal = xyz(n4), att = xyz(a4);
+			f3 direct = xyz(s4);
+			const int i = __float_as_int(n4.w);
+			const DMaterial m = S.mats[__float_as_int(i4.w)];
+			const f3 col(m.col[0], m.col[1], m.col[2]);
+			if (res.kind != 1) { // visible
+				if (m.shinieness != 0 && depth - 1 > 0) // renderer.cpp:101-102: a mirror branch per visible light
+					push(np, I, reflect(rayD, normal), W * ((m.shinieness * col) * E), E, depth - 1);
+				direct = direct + (1 - m.shinieness) * col * att * E;
+			}
+			if (light_step(i + 1, I, normal, rayD, m, E, np, direct, O, D, tmax, nextAny)) return true;
+			Lsum = Lsum + W * direct;
+		}
+		// ---- the segment is over: the most recent pending branch, or the pixel is done (k_finish) ----
+		if (np > 0) {
+			np--;
+			const float4* pe = M.pend + ((size_t)gl * RT_PEND_CAP + np) * 4;
+			const float4 o = pe[0], d = pe[1], w = pe[2], en = pe[3];
+			M.W[gl] = make_float4(w.x, w.y, w.z, o.w);
+			M.E[gl] = make_float4(en.x, en.y, en.z, __int_as_float(np));
+			M.L[gl] = mk4(Lsum, 0.0f);
+			O = xyz(o), D = xyz(d);
+			new_segment(O, D, tmax, head);
+			return true;
+		}
+		uint sid;
+		sample_of(work, sid);
+		store_sample(R, sid, Lsum);
+		return false;
+	}
+};
+
+#ifndef RT_MEGA_WAVES
+#define RT_MEGA_WAVES 4 // measured: 3 waves (no spill) and 5 are slower, profiles/r03_tick_mega.txt
+#endif
+__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, uint* spill, int* work)
+{
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	WhittedMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1] };
+	trace_persistent<false, false, false, WhittedMegaPolicy, true>(S, pol, (int)(((R.nSamples + (1u << R.permShift) - 1) >> R.permShift) << R.permShift), work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+}
+
+} // namespace rtd

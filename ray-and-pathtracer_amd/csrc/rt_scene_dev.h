@@ -335,6 +335,14 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // WIDE == true (occlusion queries only, never counting launches): inside a BLAS / the scene BVH the walk uses the
 // 4-wide nodes (wide[], see the layout notes above); a ray that is not clean is given back through
 // pol.leftover(work) for the binary walk.  The TLAS level keeps its pair records and reach test.
+// A policy with 'static constexpr bool kAdvance = true' keeps its lane when a query ends: instead of store(), the flush calls
+//   bool advance(int work, bool wasAny, const HitRef& result, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny)
+// with the finished query's result (nearest: result.t / kind / prim / inst; any-hit: result.kind == 1 means occluded); true:
+// the lane goes on with the world-space ray (O, D, tmax, head candidate) as a nearest-hit or (nextAny) any-hit query of the
+// SAME work item; false: the work item is complete and the lane is free.  Needs MIXED (the lane's kind of query changes).
+template <class P, class = void> struct pol_advances { static constexpr bool value = false; };
+template <class P> struct pol_advances<P, decltype((void)P::kAdvance)> { static constexpr bool value = P::kAdvance; };
+
 // TWO == true: every lane carries TWO rays (contexts A and B).  All step code works on context A; before a step kind runs,
 // a lane whose A does not want that kind while its B does swaps the two (v_swap_b32 on the ~19 registers of a context), so
 // that a step kind finds a taker in nearly every lane instead of in the 35 of 64 a pair step has with one ray per lane
@@ -506,12 +514,35 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 					nsteps = 0, nenter = 0;
 #endif
 					// results are written here, many lanes at a time, not one lane per iteration
-					if constexpr (MIXED) {
-						if (laneAny) pol.store(work, hit.kind == 1);
+					if constexpr (pol_advances<Policy>::value) {
+						static_assert(MIXED && !TWO && !WIDE, "an advancing policy changes its lane's kind of query");
+						HitRef res = hit;
+						res.t = rayT;
+						float tmax = 0;
+						bool nextAny = false;
+						hit.kind = -1, hit.prim = 0, hit.inst = -1;
+						if (pol.advance(work, laneAny, res, O, D, tmax, hit, nextAny)) {
+							laneAny = nextAny, rayT = tmax;
+							st.sp = 0, inst = -1;
+							rD = rcp3(D);
+							clean = ray_is_clean(O, D, rD);
+							link = S.rootLink;
+							if (link == RT_EMPTY) link = RT_LINK_DONE;
+							rays++;
+						} else work = -1;
+					} else {
+						if constexpr (MIXED) {
+							if (laneAny) pol.store(work, hit.kind == 1);
+							else { hit.t = rayT; pol.store(work, hit, O, D); }
+						} else if constexpr (ANY) pol.store(work, hit.kind == 1);
 						else { hit.t = rayT; pol.store(work, hit, O, D); }
-					} else if constexpr (ANY) pol.store(work, hit.kind == 1);
-					else { hit.t = rayT; pol.store(work, hit, O, D); }
-					work = -1;
+						work = -1;
+					}
+				}
+				int cntFree = cnt; // lanes to hand new work to
+				if constexpr (pol_advances<Policy>::value) {
+					freeMask = __ballot(work < 0); // a lane that went on with its work item is not free
+					cntFree = __popcll(freeMask);
 				}
 				if (!exhausted) {
 					while (chunkNext >= chunkEnd && !exhausted) {
@@ -555,7 +586,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 							rays++;
 							if constexpr (WIDE) { if (!clean) { pol.leftover(mine); work = -1; } } // the binary walk answers this one
 						}
-						chunkNext += cnt < avail ? cnt : avail;
+						chunkNext += cntFree < avail ? cntFree : avail;
 					}
 				}
 				RT_SEC_WAIT();

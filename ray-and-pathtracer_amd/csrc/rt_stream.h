@@ -436,9 +436,12 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 					const f3 norm = outside ? normal : -normal;
 					const float r = !outside ? m.ir : (1 / m.ir);
 					if (outside) {
-						E.x *= x_expf(m.absorption[0] * -t);
-						E.y *= x_expf(m.absorption[1] * -t);
-						E.z *= x_expf(m.absorption[2] * -t);
+						// exp(+-0) is exactly 1 and x * 1 is x: a glass without absorption (every glass of the reference's scenes
+						// but one) skips three double-precision exp calls; NaN / inf exponents still take them
+						const float ax = m.absorption[0] * -t, ay = m.absorption[1] * -t, az = m.absorption[2] * -t;
+						if (ax != 0) E.x *= x_expf(ax);
+						if (ay != 0) E.y *= x_expf(ay);
+						if (az != 0) E.z *= x_expf(az);
 					}
 					const bool refr = kr < RandomFloat(seed);
 					if (refr) {

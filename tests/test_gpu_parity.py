@@ -1022,6 +1022,35 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("name,kw,w,h", [("mixed_small", {}, 96, 64), ("pretty_tlas", {"n_instances": 4}, 160, 90), ("scene3", {"force_diffuse": False}, 96, 54),
+                                         ("background", {}, 120, 80), ("tower", {}, 120, 68), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72)])
+def test_whitted_single_launch_equals_rounds(name, kw, w, h, scenes, oracle_api, host_api, monkeypatch):
+    """Renderer::Trace as ONE persistent launch per frame (csrc/rt_mega.h, the default: a lane keeps its pixel and runs the
+    body of Trace at each hit inside the traversal kernel's flush) against the wavefront rounds (RT_MEGA=0, csrc/rt_kernels.h):
+    the same accumulator bits (segments in the same depth-first order, terms added in the same order), the oracle's frame,
+    row shards equal to the frame, and identical Trace() values for caller-supplied rays at every depth."""
+    out = {}
+    for mega in ("0", "1"):
+        monkeypatch.setenv("RT_MEGA", mega)
+        o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
+        if mega == "1":
+            check_frames(orr, r, "whitted", 1, host_api)
+        r.clear()
+        r.render(host_api.RT_MODE_WHITTED, 0, 1)
+        out[mega] = [r.accumulator().copy()]
+        r.clear()
+        r.render_rows(host_api.RT_MODE_WHITTED, 0, 1, 0, 2, (h + 1) // 2)
+        r.render_rows(host_api.RT_MODE_WHITTED, 0, 1, 1, 2, h // 2)
+        assert np.array_equal(r.accumulator().view(np.uint32), out[mega][0].view(np.uint32))
+        pO, pD = orr.primary_rays()
+        pO, pD = pO[::5].copy(), pD[::5].copy()
+        for depth in (1, 2, 4, 6):
+            out[mega].append(r.trace_batch(host_api.RT_MODE_WHITTED, pO, pD, depth, 7, energy=(0.9, 0.8, 0.7)))
+        r.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_sample_pools_on_separate_streams(scenes, oracle_api, host_api, monkeypatch):
     """RT_POOLS > 1 splits a batch of >= 1M samples over independent pools that run on their own streams
     (csrc/rt_api.hip run_rounds); the frame must be the one a single pool renders, bit for bit.  A new
