@@ -79,7 +79,9 @@ struct rt_ctx {
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
 	std::vector<void*> megaAllocs;
-	int megaLanes = 0, gridMega = 0;
+	int megaLanes = 0, gridMega = 0, gridMegaPath = 0;
+	int megaPathMax = 0;     // RT_MEGA_PATH_MAX: path batches up to this many samples run as one launch too (k_path_mega).  Off: measured slower than
+	                         // the five rounds of rt_stream.h at every size (1080p x 1: 3.33 against 3.01 ms, x 2: 4.92 / 3.88; profiles/r03_tick_time.txt)
 	int useMega = 1;         // RT_MEGA: 1 Whitted frames as one launch (default), 0 the wavefront rounds of rt_kernels.h
 	int twoRays = 0;         // RT_TWO: the stream pipeline's traversal kernels carry two rays per lane (trace_persistent<TWO>): bit 0 extend, bit 1 connect
 	int gridExtendS2 = 0, gridConnectS2 = 0;
@@ -286,6 +288,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
+	if (getenv("RT_MEGA_PATH_MAX")) c->megaPathMax = atoi(getenv("RT_MEGA_PATH_MAX"));
 	memset(&c->M, 0, sizeof(c->M));
 	if (getenv("RT_TWO")) c->twoRays = atoi(getenv("RT_TWO")) & 3;
 	if (getenv("RT_SHADE_LDS")) c->shadeLds = atoi(getenv("RT_SHADE_LDS")) != 0;
@@ -318,6 +321,7 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridExtendS2 = std::min(resident((const void*)k_extend_s2<false>), resident((const void*)k_extend_s2<true>));
 		c->gridConnectS2 = std::min(resident((const void*)k_connect_s2<false>), resident((const void*)k_connect_s2<true>));
 		c->gridMega = resident((const void*)k_whitted_mega);
+		c->gridMegaPath = resident((const void*)k_path_mega);
 		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_shade_s);
 		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
@@ -1369,7 +1373,7 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams* Rs, int nPools, int r
 }
 
 // ---- Whitted frames as one persistent launch (rt_mega.h) -----------------------------------------------
-static int run_whitted_mega(rt_ctx* c, const RenderParams& R0)
+static int run_mega(rt_ctx* c, const RenderParams& R0)
 {
 	RenderParams R = R0;
 	// deal the frame out in tiles of 64 pixels from all over it (rt_mega.h sample_of): the multiplier nearest nTiles / 61 that is coprime to nTiles
@@ -1382,7 +1386,8 @@ static int run_whitted_mega(rt_ctx* c, const RenderParams& R0)
 		while (gcd(p, nTiles) != 1) p += 2;
 		R.permMul = p;
 	}
-	const int lanes = c->gridMega * RT_BLOCK;
+	const int gridMax = R.mode == RT_MODE_WHITTED ? c->gridMega : c->gridMegaPath;
+	const int lanes = std::max(c->gridMega, c->gridMegaPath) * RT_BLOCK;
 	if (c->megaLanes < lanes) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		free_pool(c->megaAllocs);
@@ -1397,12 +1402,13 @@ static int run_whitted_mega(rt_ctx* c, const RenderParams& R0)
 		c->M = M, c->megaLanes = lanes;
 	}
 	int grid = ((int)R.nSamples + RT_SHORT_QUEUE_RAYS * 64 - 1) / (RT_SHORT_QUEUE_RAYS * 64) + 1; // a short queue does not need the whole grid
-	if (grid > c->gridMega) grid = c->gridMega;
+	if (grid > gridMax) grid = gridMax;
 	(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 	prof_begin(c, K_EXTEND);
 	// a flush runs the body of Trace for the lanes that finished a query: it waits for more of them than a plain store does (RT_REFILL_MEGA, 32: 5.0 -> 4.85 ms)
 	const int refillMega = getenv("RT_REFILL_MEGA") && atoi(getenv("RT_REFILL_MEGA")) > 0 && atoi(getenv("RT_REFILL_MEGA")) <= 64 ? atoi(getenv("RT_REFILL_MEGA")) : 32;
-	hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
+	if (R.mode == RT_MODE_WHITTED) hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
+	else hipLaunchKernelGGL(k_path_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
 	prof_end(c);
 	int f = 0;
 	HIPCHK(c, hipMemcpyAsync(c->hostCounts, c->flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1650,8 +1656,8 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 			if (rc != RT_OK) return rc;
 			continue;
 		}
-		if (mode == RT_MODE_WHITTED && c->useMega && !c->counting) {
-			rc = run_whitted_mega(c, R);
+		if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && total <= (size_t)c->megaPathMax))) {
+			rc = run_mega(c, R);
 			if (rc != RT_OK) return rc;
 			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 			continue;
@@ -1725,8 +1731,8 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 	if (mode == RT_MODE_PATH && c->pathUnsupported) {
 		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
 		rc = check_overflow(c);
-	} else if (mode == RT_MODE_WHITTED && c->useMega && !c->counting) {
-		rc = run_whitted_mega(c, R);
+	} else if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && n <= c->megaPathMax))) {
+		rc = run_mega(c, R);
 	} else if (stream_eligible(c, mode, (size_t)n)) {
 		rc = ensure_stream_state(c, n);
 		R.finishInline = 1;

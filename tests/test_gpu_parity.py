@@ -199,7 +199,10 @@ def test_whitted_frame(name, kw, w, h, scenes, oracle_api, host_api):
 
 @pytest.mark.parametrize("name,kw,w,h", RENDER_SCENES)
 @pytest.mark.parametrize("frames", [1, 4, 16])
-def test_path_frames(name, kw, w, h, frames, scenes, oracle_api, host_api):
+@pytest.mark.parametrize("pipeline", ["one_launch", "stream"])
+def test_path_frames(name, kw, w, h, frames, pipeline, scenes, oracle_api, host_api, monkeypatch):
+    # "stream": the dense wavefront (csrc/rt_stream.h, the default); "one_launch": a lane keeps its sample for all hit levels (csrc/rt_mega.h k_path_mega, opt-in)
+    monkeypatch.setenv("RT_MEGA_PATH_MAX", "0" if pipeline == "stream" else "4194304")
     o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
     check_frames(orr, r, "path", frames, host_api)
     r.close()
@@ -980,15 +983,17 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
     """The dense path pipeline (csrc/rt_stream.h, the default: entries of a round are the survivors of the round before,
     every producer writes to compacted positions; RT_FUSE=0 runs it one kernel at a time) and its producer-side ray
     decisions (RT_DECIDE: generate / shade answer a ray whose first traversal step leaves nothing to visit), also with two
-    rays per lane in its traversal kernels (RT_TWO, trace_persistent<TWO>), against the slot pipeline (RT_STREAM=0): identical accumulator bits -- per sample the arithmetic is the same, only where the path
+    rays per lane in its traversal kernels (RT_TWO, trace_persistent<TWO>), and the opt-in one-launch form
+    (csrc/rt_mega.h k_path_mega, RT_MEGA_PATH_MAX: a lane keeps its sample for all hit levels), against the slot pipeline (RT_STREAM=0): identical accumulator bits -- per sample the arithmetic is the same, only where the path
     state lives differs -- the oracle's frame, identical frames from row shards, identical Sample() values for
     caller-supplied rays at every depth, and the same number of FindNearest / IsOccluded queries."""
     out, rays = {}, {}
     pO = pD = None
     for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
-                     ("stream_two_rays", {"RT_TWO": "3", "RT_FUSE": "2"})):
+                     ("stream_two_rays", {"RT_TWO": "3", "RT_FUSE": "2"}), ("one_launch", {"RT_MEGA_PATH_MAX": "4194304"})):
         for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_TWO"):
             monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("RT_MEGA_PATH_MAX", "0")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
@@ -1009,17 +1014,18 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
             r.render_rows(host_api.RT_MODE_PATH, 0, frames, 0, 2, (h + 1) // 2)
             r.render_rows(host_api.RT_MODE_PATH, 0, frames, 1, 2, h // 2)
             assert np.array_equal(r.accumulator().view(np.uint32), out[key].view(np.uint32))
-        if key in ("slot", "stream"):
+        if key in ("slot", "stream", "one_launch"):
             if pO is None:
                 pO, pD = orr.primary_rays()
                 pO, pD = pO[::7].copy(), pD[::7].copy()
             out[key + "_sample"] = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 99) for depth in (0, 1, 4)]
         r.close()
-    for key in ("stream", "stream_serial", "stream_nodecide", "stream_two_rays"):
+    for key in ("stream", "stream_serial", "stream_nodecide", "stream_two_rays", "one_launch"):
         assert np.array_equal(out["slot"].view(np.uint32), out[key].view(np.uint32)), key
         assert rays[key] == rays["slot"], (key, rays[key], rays["slot"])
-    for a, b in zip(out["slot_sample"], out["stream_sample"]):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for other in ("stream_sample", "one_launch_sample"):
+        for a, b in zip(out["slot_sample"], out[other]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), other
 
 
 @pytest.mark.parametrize("name,kw,w,h", [("mixed_small", {}, 96, 64), ("pretty_tlas", {"n_instances": 4}, 160, 90), ("scene3", {"force_diffuse": False}, 96, 54),
