@@ -1469,18 +1469,18 @@ static int ensure_stream_state(rt_ctx* c, int n)
 	c->streamCap = (int)cap, c->streamLights = c->S.nLights, c->streamWide = wide;
 	return RT_OK;
 }
-static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int parity, uint* spill, uint* spillTwo)
+static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int round, uint* spill, uint* spillTwo)
 {
 	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27);
 	if ((c->twoRays & 2) && c->S.stackRows2 > 0 && !c->S.wide) {
-		if (c->counting) hipLaunchKernelGGL((k_connect_s2<true>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spillTwo, c->counters + 1);
-		else hipLaunchKernelGGL((k_connect_s2<false>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spillTwo, c->counters + 1);
-	} else if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
-	else if (!c->S.wide) hipLaunchKernelGGL((k_connect_s<false>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
+		if (c->counting) hipLaunchKernelGGL((k_connect_s2<true>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spillTwo, c->counters + 1);
+		else hipLaunchKernelGGL((k_connect_s2<false>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spillTwo, c->counters + 1);
+	} else if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
+	else if (!c->S.wide) hipLaunchKernelGGL((k_connect_s<false>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
 	else {
-		hipLaunchKernelGGL((k_connect_s<false, true>), dim3(c->gridConnectWideS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
-		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, st, T, 4, parity, -1);
-		hipLaunchKernelGGL((k_connect_s<false, false, true>), dim3(c->gridLeftoverS), dim3(RT_BLOCK), 0, st, c->S, T, parity, tun, spill, c->counters + 1);
+		hipLaunchKernelGGL((k_connect_s<false, true>), dim3(c->gridConnectWideS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
+		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, st, T);
+		hipLaunchKernelGGL((k_connect_s<false, false, true>), dim3(c->gridLeftoverS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
 	}
 }
 // Path mode, an entry per sample: 'rounds' = start depth + 1 rounds, no queue length is read back.  connect(r) and light(r)
@@ -1505,8 +1505,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	bool pendingJoin = false;
 	for (int round = 0; round < rounds; round++) {
 		const int parity = round & 1, last = round + 1 == rounds ? 1 : 0, lastNext = round + 2 == rounds ? 1 : 0;
-		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, st, T, 1, parity, round == 0 ? n : -1);
-		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, parity);
+		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 		prof_begin(c, K_EXTEND, st);
 		if ((c->twoRays & 1) && c->S.stackRows2 > 0) {
 			if (c->counting) hipLaunchKernelGGL((k_extend_s2<true>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
@@ -1514,21 +1513,20 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		} else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		prof_end(c, st);
-		hipLaunchKernelGGL(k_assign, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, parity);
+		hipLaunchKernelGGL(k_assign, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 		if (pendingJoin) { HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0)); pendingJoin = false; }
 		prof_begin(c, K_SHADE, st);
-		hipLaunchKernelGGL(k_shade_s, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, parity, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt);
+		hipLaunchKernelGGL(k_shade_s, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt);
 		prof_end(c, st);
 		if (twoStreams) {
 			HIPCHK(c, hipEventRecord(c->streamFork, st));
 			HIPCHK(c, hipStreamWaitEvent(sb, c->streamFork, 0));
 		}
-		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, sb, T, 2, parity, -1);
 		prof_begin(c, K_CONNECT, sb);
-		launch_connect_s(c, sb, T, parity, twoStreams ? c->streamSideSpill : c->spill, twoStreams ? c->sideSpill2 : c->spill2);
+		launch_connect_s(c, sb, T, round, twoStreams ? c->streamSideSpill : c->spill, twoStreams ? c->sideSpill2 : c->spill2);
 		prof_end(c, sb);
 		prof_begin(c, K_SHADE, sb);
-		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, parity, last, c->shadeLds);
+		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, round, last, c->shadeLds);
 		prof_end(c, sb);
 		if (twoStreams) { HIPCHK(c, hipEventRecord(c->streamJoin, sb)); pendingJoin = true; }
 	}

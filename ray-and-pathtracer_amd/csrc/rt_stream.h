@@ -44,10 +44,10 @@ namespace rtd {
 #define CL_SHADOW 8 // diffuse hit with lights: shade writes a shadow record at pos.y
 
 // counts[] of a StreamState
-#define SC_N 0       // [2] entries of the round, by round parity
-#define SC_TRACE 2   // length of the traversal queue
+#define SC_N 0       // [3] entries of round r at [r % 3]
 #define SC_FLAG 3    // overflow / debug flag (as Queues::counts[3])
-#define SC_SHADOW 4  // [2] shadow records of the round, by round parity
+#define SC_SHADOW 4  // [3] shadow records of round r at [r % 3]
+#define SC_TRACE 7   // length of the traversal queue
 #define SC_LEFTOVER 8 // shadow rays the 4-wide walk handed back
 #define SC_DECIDED 9 // rays answered by their producer (counting launches)
 
@@ -162,26 +162,31 @@ __global__ void k_fold_decided(DScene S, int* counts, DCounters* counters)
 	if (S.useTLAS) counters->brute_tests += nd * (unsigned)(S.nBruteSph + S.nBrutePla);
 }
 
-// round bookkeeping: which & 1 the main stream's side of round 'parity' (traversal queue, next round's entry count, this
-// round's shadow count, extend's heads); which & 2 the connect side (connect's heads, leftover count)
-__global__ void k_stream_begin(StreamState T, int which, int parity, int n0)
+// Round bookkeeping without launches of its own.  Round r reads its entry count at counts[SC_N + r % 3]; assign(r) adds up the
+// next round's at [(r + 1) % 3] and this round's shadow records at [SC_SHADOW + r % 3].  Whatever round r + 1 needs zeroed is
+// zeroed by ONE thread of shade(r) (and by generate for round 0): the traversal queue's length and extend's work heads
+// (compact(r) and extend(r) are over), the entry count of round r + 2 (its slot last held round r - 1's, which nobody reads any
+// more), the shadow count of round r + 1 (its slot held round r - 2's: connect / light of that round ended before shade(r - 1)
+// was allowed to start), and connect's heads for connect(r) (connect(r - 1) ended before this kernel was allowed to start).
+__device__ __forceinline__ void prepare_round(const StreamState& T, int next /* the round being prepared */, int n0)
 {
-	if (which & 1) {
-		if (n0 >= 0) T.counts[SC_N + parity] = n0; // first round: the batch's samples
-		T.counts[SC_TRACE] = 0, T.counts[SC_N + 1 - parity] = 0, T.counts[SC_SHADOW + parity] = 0;
-		for (int h = 0; h < RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
-	}
-	if (which & 2) {
-		T.counts[SC_LEFTOVER] = 0;
-		for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
-	}
-	if (which & 4) // connect's work heads only: the leftover launch walks its own list with them
-		for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	if (n0 >= 0) T.counts[SC_N + next % 3] = n0; // generate: the batch's samples are round 0's entries
+	T.counts[SC_TRACE] = 0, T.counts[SC_N + (next + 1) % 3] = 0, T.counts[SC_SHADOW + next % 3] = 0;
+	for (int h = 0; h < RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
+	// connect of the round before 'next' (it starts after the kernel this runs in)
+	T.counts[SC_LEFTOVER] = 0;
+	for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
+}
+// connect's work heads alone: the leftover launch of the 4-wide walk goes through its own list with them
+__global__ void k_stream_begin(StreamState T)
+{
+	for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
 }
 
-__global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact_s(StreamState T, int parity)
+__global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact_s(StreamState T, int round)
 {
-	compact_body(T.cls[parity], T.counts[SC_N + parity], CL_TRACE, T.traceQ, &T.counts[SC_TRACE]);
+	compact_body(T.cls[round & 1], T.counts[SC_N + round % 3], CL_TRACE, T.traceQ, &T.counts[SC_TRACE]);
 }
 
 // generate: camera sample e of the batch (renderer.cpp:263-278) -> entry e of round 0.  A sample whose camera ray
@@ -191,6 +196,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_s(DScene S, DCamera C, Re
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
 	const bool valid = e < (int)R.nSamples;
 	bool decided = false;
+	prepare_round(T, 0, (int)R.nSamples);
 	if (valid) {
 		const uint sid = R.sampleFirst + (uint)e;
 		f3 O, D;
@@ -290,12 +296,13 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_extend_s2(DScene S, 
 // totals become the next round's entry count and this round's shadow count.  Same shape as compact_body: a wave owns a
 // contiguous range, counts it, the block reserves with one atomic per counter, then every lane writes the positions of
 // its 16 entries (128 contiguous bytes).  Blocks reserve in arrival order, so entry order is by block, in order within.
-__global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_assign(StreamState T, int parity)
+__global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_assign(StreamState T, int round)
 {
+	const int parity = round & 1;
 	__shared__ int waveC[RT_COMPACT_BLOCK / 64], waveS[RT_COMPACT_BLOCK / 64];
 	__shared__ int baseC, baseS;
 	const unsigned char* status = T.cls[parity];
-	const int n = T.counts[SC_N + parity];
+	const int n = T.counts[SC_N + round % 3];
 	const uint lane = threadIdx.x & 63;
 	const int waves = (gridDim.x * blockDim.x) >> 6;
 	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -319,8 +326,8 @@ __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_assign(StreamState T, int 
 	if (threadIdx.x == 0) {
 		int sc = 0, ss = 0;
 		for (int w = 0; w < RT_COMPACT_BLOCK / 64; w++) sc += waveC[w], ss += waveS[w];
-		baseC = sc > 0 ? atomicAdd(&T.counts[SC_N + 1 - parity], sc) : 0;
-		baseS = ss > 0 ? atomicAdd(&T.counts[SC_SHADOW + parity], ss) : 0;
+		baseC = sc > 0 ? atomicAdd(&T.counts[SC_N + (round + 1) % 3], sc) : 0;
+		baseS = ss > 0 ? atomicAdd(&T.counts[SC_SHADOW + round % 3], ss) : 0;
 	}
 	__syncthreads();
 	int bc = baseC, bs = baseS;
@@ -382,14 +389,16 @@ __device__ __forceinline__ void load_tables(DScene& S, ShadeTables& L, int enabl
 #ifndef RT_SHADE_S_WAVES
 #define RT_SHADE_S_WAVES 5
 #endif
-__global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S0, DCamera C, RenderParams R, StreamState T, int parity, int fresh, int last, int lastNext, int decide, int ldsTables, int counting)
+__global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S0, DCamera C, RenderParams R, StreamState T, int round, int fresh, int last, int lastNext, int decide, int ldsTables, int counting)
 {
 	__shared__ ShadeTables tables;
 	uint nDecided = 0;
+	const int parity = round & 1;
+	prepare_round(T, round + 1, -1);
 	DScene S = S0;
 	load_tables(S, tables, ldsTables);
 	const int pout = 1 - parity;
-	const int n = T.counts[SC_N + parity];
+	const int n = T.counts[SC_N + round % 3];
 	const size_t cap = (size_t)T.cap;
 	const int nIter = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
 	for (int it = 0; it < nIter; it++) {
@@ -525,13 +534,13 @@ struct StreamConnectPolicy {
 	__device__ __forceinline__ void leftover(int work) const { T.leftover[atomicAdd(&T.counts[SC_LEFTOVER], 1)] = (uint)work; }
 };
 template <bool COUNT, bool WIDE = false, bool LISTED = false>
-__global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene S, StreamState T, int parity, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene S, StreamState T, int round, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	const int nShadow = T.counts[SC_SHADOW + parity];
+	const int nShadow = T.counts[SC_SHADOW + round % 3];
 	StreamConnectPolicy pol{ T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] };
 	int* heads = T.heads + RT_HEADS * RT_HEAD_STRIDE;
 	if constexpr (LISTED) {
@@ -543,13 +552,13 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_connect_s2(DScene S, StreamState T, int parity, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_connect_s2(DScene S, StreamState T, int round, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS2];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	const int nShadow = T.counts[SC_SHADOW + parity];
+	const int nShadow = T.counts[SC_SHADOW + round % 3];
 	StreamConnectPolicy pol{ T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] };
 	trace_persistent<true, COUNT, false, StreamConnectPolicy, false, false, RT_CONNECT_REPEAT, true>(S, pol, nShadow * S.nLights, T.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
@@ -557,13 +566,13 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_connect_s2(DScene S,
 
 // light: the direct-light terms of a diffuse hit, in light order (renderer.cpp:158-176: occlusion test first, scatter
 // only when visible), added to the radiance of the path's continuation entry; in the last round the sample is complete.
-__global__ void RT_LIGHT_BOUNDS k_light_s(DScene S0, RenderParams R, StreamState T, int parity, int last, int ldsTables)
+__global__ void RT_LIGHT_BOUNDS k_light_s(DScene S0, RenderParams R, StreamState T, int round, int last, int ldsTables)
 {
 	__shared__ ShadeTables tables;
 	DScene S = S0;
 	load_tables(S, tables, ldsTables);
-	const int pout = 1 - parity;
-	const int n = T.counts[SC_SHADOW + parity];
+	const int pout = 1 - (round & 1);
+	const int n = T.counts[SC_SHADOW + round % 3];
 	const size_t cap = (size_t)T.cap;
 	for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
 		const float4 i4 = T.shI[s], n4 = T.shN[s], d4 = T.shD[s], w4 = T.shW[s];
