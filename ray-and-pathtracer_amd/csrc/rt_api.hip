@@ -36,7 +36,7 @@ struct rt_ctx {
 	// animation (rt_set_time): original leaf records of the scene BVH and its pair records by level
 	float4* primsOrig = nullptr;
 	float4* pairsMut = nullptr; float4* primsMut = nullptr;
-	std::vector<uint> blasRoot, blasRootWide; int nInstances = 0; // roots for the scoped queries (rt_intersect_scope)
+	std::vector<uint> blasRoot, blasRootWide, blasRootWide8; int nInstances = 0; // roots for the scoped queries (rt_intersect_scope)
 	float4* wideMut = nullptr; int wideNodes = 0; // 4-wide nodes: their boxes follow the pair records after a refit
 	uint* refitOrder = nullptr; int* refitLevelStart = nullptr;
 	int refitLevels = 0, animSlots = 0;
@@ -89,7 +89,7 @@ struct rt_ctx {
 	int shadeLds = 1;        // RT_SHADE_LDS: the shading kernels keep the material / brute-force primitive tables in LDS
 	int gridShadeS = 0, gridLightS = 0; // resident blocks of the grid-stride shading kernels (a second, partial round of blocks would run at low occupancy)
 	int decideRays = 1;      // RT_DECIDE: producers answer rays whose first traversal step leaves nothing to visit (rt_stream.h ray_decided)
-	int gridExtendS = 0, gridConnectS = 0, gridConnectWideS = 0, gridLeftoverS = 0;
+	int gridExtendS = 0, gridConnectS = 0, gridConnectWideS = 0, gridLeftoverS = 0, gridConnectWide8S = 0;
 	int nPoolsWanted = 1; // RT_POOLS; measured: 2 pools overlap their kernels but do not shorten the frame
 	hipEvent_t fork = nullptr;
 	// traversal stack spill of pool 0 and of the batch queries + flags
@@ -318,6 +318,7 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridConnectS = std::min(resident((const void*)k_connect_s<false>), resident((const void*)k_connect_s<true>));
 		c->gridConnectWideS = resident((const void*)k_connect_s<false, true>);
 		c->gridLeftoverS = std::min(resident((const void*)k_connect_s<false, false, true>), prop.multiProcessorCount);
+		c->gridConnectWide8S = resident((const void*)k_connect_s<false, false, false, true>);
 		c->gridExtendS2 = std::min(resident((const void*)k_extend_s2<false>), resident((const void*)k_extend_s2<true>));
 		c->gridConnectS2 = std::min(resident((const void*)k_connect_s2<false>), resident((const void*)k_connect_s2<true>));
 		c->gridMega = resident((const void*)k_whitted_mega);
@@ -325,9 +326,9 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_shade_s);
 		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
-		const void* qk[8] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true>,
-		                      (const void*)k_query_occluded<false, true>, (const void*)k_query_occluded<false, false, true> };
-		for (int i = 0; i < 8; i++) { const int r = resident(qk[i]); if (r < q) q = r; }
+		const void* qk[9] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true>,
+		                      (const void*)k_query_occluded<false, true>, (const void*)k_query_occluded<false, false, true>, (const void*)k_query_occluded<false, false, false, true> };
+		for (int i = 0; i < 9; i++) { const int r = resident(qk[i]); if (r < q) q = r; }
 		c->gridQuery = q;
 	}
 	if (getenv("RT_REFILL")) c->refillMin = atoi(getenv("RT_REFILL"));
@@ -591,6 +592,106 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		}
 		if (!wideOK) wide.clear();
 	}
+	// 8-wide nodes with quantised child boxes (rt_scene_dev.h, wide8[] / leafBox[]): the same collapse, up to eight
+	// children, each child's box rounded outwards onto the node's 8-bit grid.  All or nothing.  RT_WIDE8=1 / 0 forces; default: see below.
+	std::vector<uint> wide8;     // 32 uints per node
+	std::vector<float> leafBox;  // 8 floats per leaf: {min.xyz, first slot}{max.xyz, -}
+	std::vector<uint> rootWide8(d->n_blas);
+	bool wide8OK = getenv("RT_WIDE8") ? atoi(getenv("RT_WIDE8")) != 0 : false;
+	{
+		size_t primBase = 0;
+		for (uint k = 0; k < d->n_blas && wide8OK; k++) {
+			const rt_blas& b = d->blas[k];
+			const uint primOff = (uint)primBase;
+			primBase += b.n_prims;
+			rootWide8[k] = RT_EMPTY;
+			if (b.n_prims == 0) continue;
+			// nested and bounded?  (outward rounding needs finite boxes; a plane's +-1e30 slab has no useful grid)
+			for (uint i = 0; i < b.nodes_used && wide8OK; i++) {
+				if (i == 1) continue;
+				for (int a = 0; a < 3; a++)
+					if (!(fabsf(b.nodes[i].aabb_min[a]) < 1e29f) || !(fabsf(b.nodes[i].aabb_max[a]) < 1e29f) || !(b.nodes[i].aabb_min[a] <= b.nodes[i].aabb_max[a])) wide8OK = false;
+				if (b.nodes[i].prim_count > 0) continue;
+				for (uint ci = b.nodes[i].left_first; ci < b.nodes[i].left_first + 2; ci++)
+					for (int a = 0; a < 3; a++)
+						if (!(b.nodes[ci].aabb_min[a] >= b.nodes[i].aabb_min[a]) || !(b.nodes[ci].aabb_max[a] <= b.nodes[i].aabb_max[a])) wide8OK = false;
+			}
+			if (!wide8OK) break;
+			auto area = [&](uint i) { const rt_bvh_node& n = b.nodes[i]; const double ex = (double)n.aabb_max[0] - n.aabb_min[0], ey = (double)n.aabb_max[1] - n.aabb_min[1], ez = (double)n.aabb_max[2] - n.aabb_min[2]; return ex * ey + ey * ez + ez * ex; };
+			auto leaf_link = [&](uint node) {
+				const rt_bvh_node& n = b.nodes[node];
+				const uint li = (uint)(leafBox.size() / 8);
+				const uint slot = primOff + n.left_first;
+				float rec[8] = { n.aabb_min[0], n.aabb_min[1], n.aabb_min[2], 0, n.aabb_max[0], n.aabb_max[1], n.aabb_max[2], 0 };
+				memcpy(&rec[3], &slot, 4);
+				leafBox.insert(leafBox.end(), rec, rec + 8);
+				return RT_BOX_BIT | li;
+			};
+			if (b.nodes[0].prim_count > 0) { rootWide8[k] = leaf_link(0); continue; } // the root is a leaf
+			std::vector<std::pair<uint, uint>> todo; // (binary inner node, wide8 record)
+			auto reserve = [&]() { const uint w = (uint)(wide8.size() / 32); wide8.resize(wide8.size() + 32, 0u); return w; };
+			const uint rootRec = reserve();
+			rootWide8[k] = rootRec;
+			todo.push_back({ 0u, rootRec });
+			while (!todo.empty() && wide8OK) {
+				const uint node = todo.back().first, rec = todo.back().second;
+				todo.pop_back();
+				uint ch[8];
+				int n = 2;
+				ch[0] = b.nodes[node].left_first, ch[1] = ch[0] + 1;
+				while (n < 8) {
+					int best = -1;
+					double bestA = -1;
+					for (int j = 0; j < n; j++)
+						if (b.nodes[ch[j]].prim_count == 0 && area(ch[j]) > bestA) best = j, bestA = area(ch[j]);
+					if (best < 0) break;
+					const uint lf = b.nodes[ch[best]].left_first;
+					for (int j = n; j > best + 1; j--) ch[j] = ch[j - 1];
+					ch[best] = lf, ch[best + 1] = lf + 1;
+					n++;
+				}
+				uint links[8];
+				for (int j = 0; j < 8; j++) {
+					links[j] = RT_EMPTY;
+					if (j >= n) continue;
+					if (b.nodes[ch[j]].prim_count > 0) links[j] = leaf_link(ch[j]);
+					else { links[j] = reserve(); todo.push_back({ ch[j], links[j] }); }
+				}
+				uint* r = &wide8[(size_t)rec * 32];
+				unsigned char q[6][8]; // qlo.x qlo.y qlo.z qhi.x qhi.y qhi.z
+				uint exps = 0;
+				for (int a = 0; a < 3 && wide8OK; a++) {
+					float org = b.nodes[ch[0]].aabb_min[a], top = b.nodes[ch[0]].aabb_max[a];
+					for (int j = 1; j < n; j++) org = std::min(org, b.nodes[ch[j]].aabb_min[a]), top = std::max(top, b.nodes[ch[j]].aabb_max[a]);
+					const double extent = (double)top - (double)org;
+					int e = extent > 0 ? (int)std::ceil(std::log2(extent / 255.0)) : -100;
+					if (e < -100) e = -100;
+					for (bool again = true; again && wide8OK;) {
+						again = false;
+						if (e > 100) { wide8OK = false; break; }
+						const float sc = std::ldexp(1.0f, e);
+						for (int j = 0; j < 8 && !again; j++) {
+							if (j >= n) { q[a][j] = 255, q[3 + a][j] = 0; continue; } // inverted: never hit (and the link says empty)
+							const float lo = b.nodes[ch[j]].aabb_min[a], hi = b.nodes[ch[j]].aabb_max[a];
+							int ql = (int)std::floor(((double)lo - (double)org) / (double)sc), qh = (int)std::ceil(((double)hi - (double)org) / (double)sc);
+							ql = std::max(0, std::min(255, ql)), qh = std::max(0, std::min(255, qh));
+							// the device's own expression must contain the box: fma(q, 2^e, origin)
+							while (ql > 0 && std::fmaf((float)ql, sc, org) > lo) ql--;
+							while (qh < 255 && std::fmaf((float)qh, sc, org) < hi) qh++;
+							if (std::fmaf((float)ql, sc, org) > lo || std::fmaf((float)qh, sc, org) < hi) { e++; again = true; break; } // a coarser grid
+							q[a][j] = (unsigned char)ql, q[3 + a][j] = (unsigned char)qh;
+						}
+					}
+					memcpy(&r[a], &org, 4);
+					exps |= (uint)(e + 128) << (8 * a);
+				}
+				r[3] = exps;
+				for (int a = 0; a < 6; a++) memcpy(&r[4 + 2 * a], q[a], 8);
+				memcpy(&r[16], links, 32);
+			}
+		}
+		if (!wide8OK) wide8.clear(), leafBox.clear();
+	}
 	// TLAS inner nodes -> pair records appended to the BLAS pairs (children boxes inside the parent's
 	// record; child A = leftRight & 0xFFFF, the one tlas::Intersect tests first)
 	uint tlasRoot = RT_EMPTY;
@@ -644,6 +745,16 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		S.rootWide = rootWide[0];
 		c->wideMut = (float4*)dp, c->wideNodes = (int)(wide.size() / 32);
 	} else c->wideMut = nullptr, c->wideNodes = 0;
+	S.wide8 = nullptr, S.leafBox = nullptr, S.rootWide8 = RT_EMPTY;
+	if (wide8OK && !wide8.empty()) {
+		uint* dw = nullptr;
+		float* dl = nullptr;
+		HIPCHK(c, dalloc(c->sceneAllocs, &dw, wide8.size() + 32));
+		HIPCHK(c, hipMemcpy(dw, wide8.data(), wide8.size() * 4, hipMemcpyHostToDevice));
+		HIPCHK(c, dalloc(c->sceneAllocs, &dl, leafBox.size() + 8));
+		if (!leafBox.empty()) HIPCHK(c, hipMemcpy(dl, leafBox.data(), leafBox.size() * 4, hipMemcpyHostToDevice));
+		S.wide8 = (const uint4*)dw, S.leafBox = (const float4*)dl, S.rootWide8 = rootWide8[0];
+	}
 	c->pairsMut = (float4*)S.pairs, c->primsMut = (float4*)S.prims;
 	c->primsOrig = nullptr, c->refitLevels = 0, c->animSlots = 0;
 	if (!d->use_tlas && d->blas[0].n_prims > 0) {
@@ -686,6 +797,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			memcpy(inst[i].invT, in.inv_transform, 48), memcpy(inst[i].T, in.transform, 48);
 			inst[i].rootLink = rootLink[in.blas];
 			inst[i].rootWide = rootWide[in.blas];
+			inst[i].rootWide8 = wide8OK ? rootWide8[in.blas] : RT_EMPTY;
 		}
 		DInstance* di = nullptr;
 		HIPCHK(c, dalloc(c->sceneAllocs, &di, inst.size()));
@@ -869,6 +981,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		S.sky = ds, S.skyW = d->sky_w, S.skyH = d->sky_h, S.skyN = d->sky_n;
 	}
 	c->S = S;
+	c->blasRootWide8 = rootWide8;
 	c->blasRoot = rootLink, c->blasRootWide = wideOK ? rootWide : rootLink, c->nInstances = d->use_tlas ? (int)d->n_instances : 0;
 	c->sceneLoaded = true;
 	return RT_OK;
@@ -1031,6 +1144,7 @@ int rt_build_tlas(rt_ctx* c, const float* bounds6, uint32_t n, rt_tlas_node* nod
 
 int rt_set_time(rt_ctx* c, float t)
 {
+	if (c) c->S.wide8 = nullptr; // the quantised boxes were rounded around the uploaded geometry: a refitted tree is walked through the exact nodes
 	if (!c) return RT_E_ARG;
 	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_set_time: no scene uploaded");
 	if (c->S.useTLAS) return fail(c, RT_E_UNSUPPORTED, "rt_set_time: the reference animates only without the TLAS (animOn, template/scene.h:1389)");
@@ -1426,7 +1540,7 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 // ---- the dense path-mode pipeline (rt_stream.h) ------------------------------------------------------
 static int ensure_stream_state(rt_ctx* c, int n)
 {
-	const bool wide = c->S.wide != nullptr;
+	const bool wide = c->S.wide != nullptr || c->S.wide8 != nullptr;
 	if (!c->streamSide) {
 		HIPCHK(c, hipStreamCreate(&c->streamSide));
 		HIPCHK(c, hipMalloc((void**)&c->streamSideSpill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
@@ -1476,7 +1590,12 @@ static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, in
 		if (c->counting) hipLaunchKernelGGL((k_connect_s2<true>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spillTwo, c->counters + 1);
 		else hipLaunchKernelGGL((k_connect_s2<false>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spillTwo, c->counters + 1);
 	} else if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
-	else if (!c->S.wide) hipLaunchKernelGGL((k_connect_s<false>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
+	else if (c->S.wide8) {
+		// the 8-wide quantised walk, then the binary walk over the rays it handed back (not clean: normally none)
+		hipLaunchKernelGGL((k_connect_s<false, false, false, true>), dim3(c->gridConnectWide8S), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
+		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, st, T);
+		hipLaunchKernelGGL((k_connect_s<false, false, true>), dim3(c->gridLeftoverS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
+	} else if (!c->S.wide) hipLaunchKernelGGL((k_connect_s<false>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
 	else {
 		hipLaunchKernelGGL((k_connect_s<false, true>), dim3(c->gridConnectWideS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
 		hipLaunchKernelGGL(k_stream_begin, dim3(1), dim3(1), 0, st, T);
@@ -1847,7 +1966,7 @@ static int scoped_scene(rt_ctx* c, int scope, int index, DScene& S, const char* 
 	if (scope == RT_SCOPE_SCENE || scope == RT_SCOPE_ACCEL) return RT_OK;
 	if (scope == RT_SCOPE_BLAS) {
 		if (index < 0 || index >= (int)c->blasRoot.size()) return fail(c, RT_E_ARG, "%s: blas %d of %d", who, index, (int)c->blasRoot.size());
-		S.useTLAS = 0, S.tlasLds = 0, S.rootLink = c->blasRoot[(size_t)index], S.rootWide = c->blasRootWide[(size_t)index], S.nBruteSph = S.nBrutePla = 0;
+		S.useTLAS = 0, S.tlasLds = 0, S.rootLink = c->blasRoot[(size_t)index], S.rootWide = c->blasRootWide[(size_t)index], S.rootWide8 = S.wide8 ? c->blasRootWide8[(size_t)index] : RT_EMPTY, S.nBruteSph = S.nBrutePla = 0;
 		return RT_OK;
 	}
 	if (scope == RT_SCOPE_INSTANCE) {
@@ -1941,7 +2060,8 @@ int rt_occluded_scope(rt_ctx* c, int scope, int index, int n, const float* O, co
 	unsigned char* dR = nullptr;
 	uint* dL = nullptr;
 	int rc = RT_OK;
-	const bool wideWalk = !c->counting && c->S.wide;
+	const bool wide8Walk = !c->counting && S.wide8;
+	const bool wideWalk = !c->counting && (c->S.wide || wide8Walk);
 	hipError_t e = dalloc(tmp, &dO, (size_t)3 * n);
 	if (e == hipSuccess) e = dalloc(tmp, &dD, (size_t)3 * n);
 	if (e == hipSuccess && tmax) e = dalloc(tmp, &dT, (size_t)n);
@@ -1958,7 +2078,8 @@ int rt_occluded_scope(rt_ctx* c, int scope, int index, int n, const float* O, co
 		else {
 			// the 4-wide walk, then the binary walk over the rays it handed back (not clean: normally none)
 			(void)hipMemsetAsync(c->flags + 2, 0, sizeof(int), c->stream);
-			hipLaunchKernelGGL((k_query_occluded<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+			if (wide8Walk) hipLaunchKernelGGL((k_query_occluded<false, false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+			else hipLaunchKernelGGL((k_query_occluded<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
 			(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream);
 			hipLaunchKernelGGL((k_query_occluded<false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
 		}

@@ -1064,7 +1064,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, con
 }
 
 // work[0] unused, work[1] overflow flag, work[2] rays handed back by the wide walk; LISTED: the items are leftover[0 .. work[2])
-template <bool COUNT, bool WIDE = false, bool LISTED = false>
+template <bool COUNT, bool WIDE = false, bool LISTED = false, bool WIDE8 = false>
 __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax, int refillMin,
                                                              unsigned char* out, uint* spill, int* work, DCounters* counters, uint* leftover)
 {
@@ -1077,7 +1077,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, co
 		ListedPolicy<OccludedQueryPolicy> lp{ pol, leftover };
 		trace_persistent<true, COUNT, false>(S, lp, work[2], work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	} else
-		trace_persistent<true, COUNT, false, OccludedQueryPolicy, false, WIDE>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+		trace_persistent<true, COUNT, false, OccludedQueryPolicy, false, WIDE, RT_PAIR_REPEAT, false, WIDE8>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 

@@ -45,6 +45,17 @@
 //            visited leaves are exactly those whose own box passes, whichever ancestors a walk tests on the way.  Order
 //            is free (a boolean).  Rays that are not clean, in world or in an instance's object space, are handed to the
 //            binary walk (leftover list).  Half as many dependent fetches per ray, and each fetch is one L1 line.
+//   wide8[]  8-wide nodes with QUANTISED child boxes, the re-thought form of the reference's QBVH, for occlusion
+//            queries.  One 128-byte record (96 used, six dwordx4): {origin.xyz, exponents} {qlo.x[8] qlo.y[8]} {qlo.z[8] qhi.x[8]}
+//            {qhi.y[8] qhi.z[8]} {link[0..3]} {link[4..7]}; a child's box is origin + q * 2^e per axis (one fma, the expression
+//            the builder checked), rounded OUTWARDS at upload so that it contains the binary node's box it stands for; built
+//            by collapsing the reference's binary tree (largest surface first, up to eight children).  Exactness: the argument
+//            of wide[] needs the boxes a walk tests on the way to a leaf only to CONTAIN the leaf's own box (for a clean ray a
+//            box that passes implies every box containing it passes), and the leaf's own, exact box to decide whether the leaf
+//            is visited.  So inner entries may be quantised as long as they contain, and a leaf entry names a leafBox[] record
+//            -- the reference's exact box + the first primitive slot -- that is tested (exact slab test) before any primitive:
+//            visited leaves are exactly those whose own box passes, as in bvh::BIsOccluded.  A third of the dependent fetches
+//            of the binary walk, half its load instructions per ray.
 // All of it is read-only and a few MB at most: every XCD's 4 MiB L2 ends up holding its own copy.
 #pragma once
 #include "rt_dmath.h"
@@ -104,7 +115,8 @@ struct DInstance {
 	float T[12];
 	uint rootLink;
 	uint rootWide; // the same BLAS entered through its 4-wide nodes (== rootLink when the root is a leaf)
-	uint pad[6];
+	uint rootWide8; // ... through its 8-wide quantised nodes
+	uint pad[5];
 };
 struct DScene {
 	const float4* pairs;
@@ -114,6 +126,9 @@ struct DScene {
 	const float4* reach; // TLAS mode: per TLAS pair, the boxes its children's geometry can actually occupy (see below)
 	const float4* wide;  // 4-wide nodes of every BLAS (any-hit queries of clean rays), 128-byte records; null when a tree is not nested
 	uint rootWide;       // scene BVH root through the wide nodes (unused in TLAS mode: instances carry theirs)
+	const uint4* wide8;  // 8-wide nodes with quantised child boxes (any-hit queries of clean rays), 128-byte records, see below; null: not built
+	const float4* leafBox; // exact box + first primitive slot of every leaf the 8-wide nodes name, 32-byte records
+	uint rootWide8;
 	const DLight* lights;
 	const DMaterial* mats;
 	const unsigned char* sky;
@@ -274,6 +289,7 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // drain per round instead of two (a launch ends when its longest ray does, several hundred microseconds after the
 // queue ran dry, whatever the queue held).
 #define RT_INST_BIT 0x40000000u // link names an instance (TLAS leaf)
+#define RT_BOX_BIT 0x20000000u  // 8-wide walk: link names a leafBox[] record (the leaf's exact box is tested before its primitives)
 #define RT_LINK_EXIT 0xFFFFFFFCu // leave the current instance (the sentinel was popped)
 #define RT_LINK_DONE 0xFFFFFFFBu // this ray is finished; its result is written at the next refill
 #define RT_CHUNK 256 // queue entries a wave reserves per atomic on a work head (upper bound)
@@ -353,12 +369,14 @@ template <class P> struct pol_advances<P, decltype((void)P::kAdvance)> { static 
 #define RT_LDS_WORDS2 8192 // 32 KB per block: five blocks per CU
 #endif
 #define RT_STACK_ROWS_MIN2 6 // fewer LDS stack rows per context than this: the scene keeps one ray per lane
-template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false, bool WIDE = false, int REPEAT = RT_PAIR_REPEAT, bool TWO = false>
+template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false, bool WIDE = false, int REPEAT = RT_PAIR_REPEAT, bool TWO = false, bool WIDE8 = false>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
 	static_assert(!WIDE || (ANY && !COUNT && !MIXED), "the wide walk is exact for any-hit queries only");
 	static_assert(!TWO || (!MIXED && !WIDE && !RT_FETCH_STEP), "two contexts per lane: the plain binary walks only");
+	static_assert(!WIDE8 || (ANY && !COUNT && !MIXED && !WIDE && !TWO), "the 8-wide walk is exact for any-hit queries only");
+	constexpr bool ANYWIDE = WIDE || WIDE8; // a wide walk: rays that are not clean go back to the binary walk
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
 	const int refillMin = tuning & 0xFF, stepMinBusy = (tuning >> 8) & 0xFF, pairAgainBusy = (tuning >> 20) & 0x7F;
 	const int stepMinXformBusy = ((tuning >> 27) & 0xF) ? ((tuning >> 27) & 0xF) : stepMinBusy; // entry / exit: arithmetic and LDS only when the TLAS is in LDS
@@ -393,7 +411,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			tlasL[i] = v;
 		}
 		lds_uint* const roots = (lds_uint*)(tlasL + nP + nR + nI);
-		for (int i = (int)threadIdx.x; i < S.nInst; i += RT_BLOCK) roots[i] = WIDE ? S.inst[i].rootWide : S.inst[i].rootLink;
+		for (int i = (int)threadIdx.x; i < S.nInst; i += RT_BLOCK) roots[i] = WIDE8 ? S.inst[i].rootWide8 : (WIDE ? S.inst[i].rootWide : S.inst[i].rootLink);
 		__syncthreads();
 	}
 #ifdef RT_TAIL_PROBE
@@ -485,7 +503,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	// (the texture addresser spends ~16 cycles per dwordx4 instruction whatever the number of enabled lanes).  It loses:
 	// the triangle arithmetic then runs in every pair step for the ~5 lanes that happen to be at a leaf instead of every
 	// few iterations for ~13 (extend 27.6 -> 32.3 ms, connect 10.3 -> 12.5 ms).
-	constexpr bool FETCH = RT_FETCH_STEP && !WIDE;
+	constexpr bool FETCH = RT_FETCH_STEP && !ANYWIDE;
 
 	while (true) {
 		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
@@ -581,10 +599,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 							if (!ANY && HEAD) find_nearest_head<COUNT>(S, O, D, t_min, rayT, hit, lc);
 							rD = rcp3(D);
 							clean = ray_is_clean(O, D, rD);
-							link = WIDE && !S.useTLAS ? S.rootWide : S.rootLink;
+							link = ANYWIDE && !S.useTLAS ? (WIDE8 ? S.rootWide8 : S.rootWide) : S.rootLink;
 							if (link == RT_EMPTY) link = RT_LINK_DONE;
 							rays++;
-							if constexpr (WIDE) { if (!clean) { pol.leftover(mine); work = -1; } } // the binary walk answers this one
+							if constexpr (ANYWIDE) { if (!clean) { pol.leftover(mine); work = -1; } } // the binary walk answers this one
 						}
 						chunkNext += cntFree < avail ? cntFree : avail;
 					}
@@ -656,6 +674,40 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				// mode, of the TLAS (tlas.cpp:77-91 / :106-120) -- same test, same ordering rule
 				if (COUNT && wantPair) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
 				const bool atTlas = wantPair && S.useTLAS && inst < 0;
+				if (WIDE8 && !atTlas) {
+					if (lk & RT_BOX_BIT) {
+						// a leaf the 8-wide nodes named: its own, exact box decides whether bvh::BIsOccluded visits it
+						const float4* bx = S.leafBox + 2 * (size_t)(lk & ~RT_BOX_BIT);
+						const float4 lo = bx[0], hi = bx[1];
+						const float dl = intersect_aabb_clean(O, rD, rayT, xyz(lo), xyz(hi));
+						if (dl != 1e30f) link = RT_LEAF_BIT | __float_as_uint(lo.w);
+						else pop_next();
+						continue;
+					}
+					// one 8-wide node: every child whose (outward-rounded) box the ray passes is visited; the nearest one next
+					const uint4* w = S.wide8 + 8 * (size_t)lk;
+					const uint4 h4 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], l0 = w[4], l1 = w[5];
+					const f3 org(__uint_as_float(h4.x), __uint_as_float(h4.y), __uint_as_float(h4.z));
+					const f3 sc(__uint_as_float(((h4.w & 0xFF) - 1u) << 23), __uint_as_float((((h4.w >> 8) & 0xFF) - 1u) << 23), __uint_as_float((((h4.w >> 16) & 0xFF) - 1u) << 23));
+					const uint qlx[2] = { q1.x, q1.y }, qly[2] = { q1.z, q1.w }, qlz[2] = { q2.x, q2.y }, qhx[2] = { q2.z, q2.w }, qhy[2] = { q3.x, q3.y }, qhz[2] = { q3.z, q3.w };
+					const uint cl[8] = { l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w };
+					float best = 1e30f;
+					uint bestLink = 0;
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						const int sh = 8 * (j & 3);
+						const f3 blo(__fmaf_rn((float)((qlx[j >> 2] >> sh) & 0xFF), sc.x, org.x), __fmaf_rn((float)((qly[j >> 2] >> sh) & 0xFF), sc.y, org.y), __fmaf_rn((float)((qlz[j >> 2] >> sh) & 0xFF), sc.z, org.z));
+						const f3 bhi(__fmaf_rn((float)((qhx[j >> 2] >> sh) & 0xFF), sc.x, org.x), __fmaf_rn((float)((qhy[j >> 2] >> sh) & 0xFF), sc.y, org.y), __fmaf_rn((float)((qhz[j >> 2] >> sh) & 0xFF), sc.z, org.z));
+						float dj = intersect_aabb_clean(O, rD, rayT, blo, bhi);
+						if (cl[j] == RT_EMPTY) dj = 1e30f;
+						if (dj < best) {
+							if (best != 1e30f) st.push(bestLink);
+							best = dj, bestLink = cl[j];
+						} else if (dj != 1e30f) st.push(cl[j]);
+					}
+					if (best != 1e30f) link = bestLink; else pop_next();
+					continue;
+				}
 				if (WIDE && !atTlas) {
 					// one 4-wide node: every child whose box the ray passes is visited, in any order (a boolean query)
 					const float4* w = S.wide + 8 * (size_t)lk;
@@ -833,7 +885,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				const DInstance* I = S.inst + inst;
 #pragma unroll
 				for (int k = 0; k < 12; k++) invT[k] = I->invT[k];
-				rootB = I->rootLink, rootW = I->rootWide;
+				rootB = I->rootLink, rootW = WIDE8 ? I->rootWide8 : I->rootWide;
 			}
 			worldRay[0 * RT_BLOCK] = __float_as_uint(O.x), worldRay[1 * RT_BLOCK] = __float_as_uint(O.y), worldRay[2 * RT_BLOCK] = __float_as_uint(O.z);
 			worldRay[3 * RT_BLOCK] = __float_as_uint(D.x), worldRay[4 * RT_BLOCK] = __float_as_uint(D.y), worldRay[5 * RT_BLOCK] = __float_as_uint(D.z);
@@ -841,10 +893,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			const f3 Do = xform_vec(invT, D);
 			O = Oo, D = Do, rD = rcp3(Do);
 			clean = ray_is_clean(O, D, rD);
-			link = WIDE ? rootW : rootB;
+			link = ANYWIDE ? rootW : rootB;
 			if (link == RT_EMPTY) link = RT_LINK_EXIT;
 			else st.push(RT_SENTINEL);
-			if constexpr (WIDE) { if (!clean) { pol.leftover(work); work = -1; link = RT_LINK_DONE; } } // not clean in object space: the binary walk redoes this ray
+			if constexpr (ANYWIDE) { if (!clean) { pol.leftover(work); work = -1; link = RT_LINK_DONE; } } // not clean in object space: the binary walk redoes this ray
 			RT_SEC_WAIT();
 			RT_SEC_ADD(5, secT);
 		}

@@ -533,7 +533,7 @@ struct StreamConnectPolicy {
 	}
 	__device__ __forceinline__ void leftover(int work) const { T.leftover[atomicAdd(&T.counts[SC_LEFTOVER], 1)] = (uint)work; }
 };
-template <bool COUNT, bool WIDE = false, bool LISTED = false>
+template <bool COUNT, bool WIDE = false, bool LISTED = false, bool WIDE8 = false>
 __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene S, StreamState T, int round, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene
 		ListedPolicy<StreamConnectPolicy> lp{ pol, T.leftover };
 		trace_persistent<true, COUNT, false, ListedPolicy<StreamConnectPolicy>, false, false, RT_CONNECT_REPEAT>(S, lp, T.counts[SC_LEFTOVER], heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	} else
-		trace_persistent<true, COUNT, false, StreamConnectPolicy, false, WIDE, RT_CONNECT_REPEAT>(S, pol, nShadow * S.nLights, heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+		trace_persistent<true, COUNT, false, StreamConnectPolicy, false, WIDE, RT_CONNECT_REPEAT, false, WIDE8>(S, pol, nShadow * S.nLights, heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 

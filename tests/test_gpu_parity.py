@@ -91,10 +91,13 @@ def test_wide_walk_equals_binary_walk(name, kw, scenes, oracle_api, host_api, mo
     take the wide walk, the others (axis-aligned directions here) are handed back to the binary walk -- and a path
     frame whose shadow rays took it must equal the default frame bit for bit."""
     frames = {}
-    for wide in ("0", "1"):
-        monkeypatch.setenv("RT_WIDE", wide)
+    for wide in ("0", "1", "8"):
+        # "8": the 8-wide nodes with quantised child boxes (wide8[] / leafBox[], RT_WIDE8=1): inner boxes rounded outwards, the
+        # leaf's own exact box tested before its primitives -- the same flags for every ray, the same frames
+        monkeypatch.setenv("RT_WIDE", "0" if wide == "8" else wide)
+        monkeypatch.setenv("RT_WIDE8", "1" if wide == "8" else "0")
         o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 96, 54, **kw)
-        if wide == "1":
+        if wide != "0":
             O, D = random_rays(40000, 9, center=(0.0, 1.0, 3.0), spread=6.0)
             pO, pD = orr.primary_rays()
             O, D = np.concatenate([O, pO]), np.concatenate([D, pD])
@@ -114,13 +117,17 @@ def test_wide_walk_equals_binary_walk(name, kw, scenes, oracle_api, host_api, mo
         r.render(host_api.RT_MODE_WHITTED, 0, 1)
         frames[wide + "w"] = r.accumulator().copy()
         r.close()
-    assert np.array_equal(frames["0"].view(np.uint32), frames["1"].view(np.uint32))
-    assert np.array_equal(frames["0w"].view(np.uint32), frames["1w"].view(np.uint32))
+    for wide in ("1", "8"):
+        assert np.array_equal(frames["0"].view(np.uint32), frames[wide].view(np.uint32)), wide
+        assert np.array_equal(frames["0w"].view(np.uint32), frames[wide + "w"].view(np.uint32)), wide
 
 
-def test_wide_walk_after_refit(scenes, oracle_api, host_api, monkeypatch):
-    """rt_set_time deforms and refits the scene BVH; the wide nodes' boxes must follow (k_wide_sync)."""
+@pytest.mark.parametrize("wide8", ["0", "1"])
+def test_wide_walk_after_refit(wide8, scenes, oracle_api, host_api, monkeypatch):
+    """rt_set_time deforms and refits the scene BVH; the wide nodes' boxes must follow (k_wide_sync); the quantised 8-wide
+    nodes were rounded around the uploaded geometry and are dropped for the 4-wide ones."""
     monkeypatch.setenv("RT_WIDE", "1")
+    monkeypatch.setenv("RT_WIDE8", wide8)
     o, orr, r, d = make_pair(scenes.mixed_small, oracle_api, host_api, 48, 32)
     O, D = random_rays(20000, 3)
     for t in (0.7, 3.1, 0.0):
@@ -875,8 +882,10 @@ def test_reach_cull_fuzz_gpu_vs_gpu(name, kw, total, scenes, oracle_api, host_ap
     misses are dropped, DESIGN.md section 4 finding 8) against the same kernels walking like the reference
     (RT_COUNT_REFERENCE: no culling) -- GPU against GPU, because this one equivalence needs volume, not an oracle.
     Hit ids, t, materials and normals of Scene::FindNearest and the flags of Scene::IsOccluded must be bit-identical."""
-    if name != "pretty_tlas":
-        monkeypatch.setenv("RT_WIDE", "1")  # the two smaller runs also put the 4-wide occlusion walk against the binary one
+    if name == "bigb_instanced":
+        monkeypatch.setenv("RT_WIDE", "1")  # the two smaller runs also put the wide occlusion walks against the binary one: 4-wide exact boxes ...
+    if name == "tlas_test2":
+        monkeypatch.setenv("RT_WIDE8", "1")  # ... and 8-wide quantised boxes
     o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 16, 8, **kw)
     rng = np.random.default_rng(20260)
     n_inst = o.n_instances
