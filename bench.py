@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true", help="profiling runs: skip the untimed counting pass (ray counts and algorithmic bytes are then 0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--qlearn", type=int, default=0, metavar="FRAMES", help="Q-learning guided sampling (rt_qlearn_*, Dahm & Keller 2017; the reference has no code for it: "
+                    "PARITY UNPINNED): the step renders its spp in batches of FRAMES frames and folds the rewards into the table between them "
+                    "(with N ranks the integer reward sums are all-reduced first, so every rank learns the same table)")
     ap.add_argument("--emulate-world", type=int, default=0, help="profiling on ONE GPU: render only the rows rank 0 of an N-rank run renders "
                     "(no process group, no gather): the counters of that share are what rank 0 of the N-GPU run is priced with")
     args = ap.parse_args()
@@ -97,6 +100,7 @@ def main():
     mode = ha.RT_MODE_PATH
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     r.bind_accumulator(acc.data_ptr())
+    red_dev_early = "cuda" if backend == "nccl" else "cpu"
     # the shard of this rank and every buffer its gather needs: allocated once, outside the timed region
     shard = dpar.RowShard(H, W, rank, world, acc.device)
     if args.emulate_world > 1:
@@ -108,10 +112,33 @@ def main():
     if world > 1 and backend != "nccl":
         host_staging = (torch.zeros((H, W, 4), dtype=torch.float32), dpar.RowShard(H, W, rank, world, torch.device("cpu")))
 
+    qbox = cfg.get("qbox", ((-12.0, -2.0, -8.0), (12.0, 10.0, 16.0)))
+
     def step():
         acc.zero_()
         torch.cuda.synchronize()
-        dpar.render_step(r, acc, mode, 0, spp, shard, host_staging)
+        if not args.qlearn:
+            dpar.render_step(r, acc, mode, 0, spp, shard, host_staging)
+            return
+        # every step learns from scratch, so that the K timed steps do the same work
+        r.qlearn_enable(16, qbox[0], qbox[1], 0.3, 0.2, 1.0)
+        first, stride, count = shard.rows()
+        for f0 in range(0, spp, args.qlearn):
+            r.render_rows(mode, f0, min(args.qlearn, spp - f0), first, stride, count)
+            if world > 1:  # the one exchange step this sampler adds: integer sums, so the order of the reduction does not matter
+                sums, cnts = r.qlearn_sums()
+                ts, tc = torch.from_numpy(sums).to(red_dev_early), torch.from_numpy(cnts.astype(np.int64)).to(red_dev_early)
+                dist.all_reduce(ts), dist.all_reduce(tc)
+                r.qlearn_set_sums(ts.cpu().numpy(), tc.cpu().numpy().astype(np.uint32))
+            r.qlearn_apply()
+        r.synchronize()
+        if host_staging is None:
+            shard.gather(acc)
+        else:
+            host_staging[0].copy_(acc)
+            host_staging[1].gather(host_staging[0])
+            if rank == 0:
+                acc.copy_(host_staging[0])
 
     def fence():
         if world > 1:
@@ -163,6 +190,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s, %dx%d, %d spp, path integrator" % (args.workload, cfg["name"], W, H, spp),
                        "parallelism": "row-interleaved pixel shard x%d + accumulator gather to rank 0" % world,
+                       "sampler": ("Q-learning guided indirect bounce (Dahm & Keller 2017; no reference code: PARITY UNPINNED), 16^3 cells x 64 patches, "
+                                   "table updated every %d frames" % args.qlearn) if args.qlearn else "uniform hemisphere (renderer.cpp:181)",
                        "rays_definition": "value counts primary pixel samples (reference's Mrays/s, renderer.cpp:300); all_rays counts every FindNearest + IsOccluded query"},
             "all_rays_mrays_per_s": round(rays_all / sec_per_step / 1e6, 3),
             "rays_per_step": {"nearest": int(cnt[0].item()), "occluded": int(cnt[1].item())},

@@ -208,6 +208,27 @@ int rt_trace_batch(rt_ctx* ctx, int mode, int n, const float* O, const float* D,
 /* The same with Trace / Sample's third argument: energy[3] instead of float3(1) */
 int rt_trace_batch_energy(rt_ctx* ctx, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, const float* energy, float* rgb_out);
 
+/* ---- Q-learning guided sampling ("next" row N4) ------------------------------------------------------
+ * The reference snapshot has no code for it: README.md:36-42 names Dahm & Keller 2017, "Learning Light Transport
+ * the Reinforced Way", and lists "initialize sampling positions; pick sampling direction according to the QValue of neighboring
+ * points; store and update directions with a corresponding probability per sampling point".  These calls are this library's
+ * statement of that scheme (csrc/rt_qlearn.h; PARITY UNPINNED: there is nothing in the reference to compare with).
+ * rt_qlearn_enable: path-mode batches draw the indirect bounce of every diffuse hit from a table of grid^3 cells over the box
+ *   [lo, hi] x 64 direction patches, P(patch) = (1 - epsilon) Q / sum Q + epsilon / 64, and collect rewards (integer sums);
+ *   the table starts at q_init everywhere.  params == NULL switches the sampler off and frees the table.  Batches larger than
+ *   the slot budget, and scenes that need the general path kernel, return RT_E_UNSUPPORTED while it is on.
+ * rt_qlearn_apply: Q <- (1 - alpha) Q + alpha * mean reward, for every (cell, patch) that received one; call it BETWEEN
+ *   batches (within a batch the table is read-only, so a frame does not depend on scheduling or sharding).
+ * rt_qlearn_get_sums / rt_qlearn_set_sums: the pending rewards (int64 sums in 48.16 fixed point, uint32 counts, grid^3 * 64
+ *   each) -- with several ranks the sums are all-reduced between the ranks before every rank applies them.
+ * rt_qlearn_get_table: Q as grid^3 * 64 floats (cell-major, patch = 8 * band + sector). */
+typedef struct { int32_t grid; float lo[3], hi[3]; float alpha, epsilon, q_init; } rt_qlearn_params;
+int rt_qlearn_enable(rt_ctx* ctx, const rt_qlearn_params* params);
+int rt_qlearn_apply(rt_ctx* ctx);
+int rt_qlearn_get_sums(rt_ctx* ctx, int64_t* sums_out, uint32_t* counts_out);
+int rt_qlearn_set_sums(rt_ctx* ctx, const int64_t* sums, const uint32_t* counts);
+int rt_qlearn_get_table(rt_ctx* ctx, float* q_out);
+
 /* ---- acceleration structure build ("next" row N1) ------------------------------------------------ */
 /* bvh::Build() with splitMethod BINNEDSAH (bvh.cpp:18-56; FindBestSplitPlane :116-193, Subdivide :223-333,
  * separatePlanes :202-221, Refit :556-594) on the device.  The result is the reference's tree bit for bit: node

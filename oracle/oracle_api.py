@@ -268,6 +268,24 @@ class OracleRenderer:
         self.L.orc_get_accumulator(self.h, _p(out))
         return out
 
+    # ---- Q-learning guided sampler (orc_qlearn.h; no reference code: parity unpinned) ----
+    def qlearn_enable(self, grid, lo, hi, alpha=0.3, epsilon=0.2, q_init=1.0):
+        self._qgrid = grid
+        self.L.orc_qlearn_enable(self.h, grid, _f3(lo), _f3(hi), C.c_float(alpha), C.c_float(epsilon), C.c_float(q_init))
+
+    def qlearn_disable(self):
+        self.L.orc_qlearn_enable(self.h, 0, _f3((0, 0, 0)), _f3((1, 1, 1)), C.c_float(1), C.c_float(0), C.c_float(1))
+
+    def qlearn_apply(self):
+        self.L.orc_qlearn_apply(self.h)
+
+    def qlearn_state(self):
+        """(sums int64, counts uint32, table float32), each [grid^3, 64]"""
+        n = self._qgrid ** 3
+        sums, cnts, tab = np.zeros((n, 64), np.int64), np.zeros((n, 64), np.uint32), np.zeros((n, 64), np.float32)
+        self.L.orc_qlearn_get(self.h, _p(sums), _p(cnts), _p(tab))
+        return sums, cnts, tab
+
     def resolve(self, it=1):
         out = np.zeros((self.hgt, self.w), dtype=np.uint32)
         self.L.orc_resolve(self.h, it, _p(out))

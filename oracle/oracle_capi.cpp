@@ -342,6 +342,22 @@ int orc_render(void* h, unsigned frame0, int nframes, unsigned seedBase, int y0,
 	counters_out(total, counters);
 	return 0;
 }
+// Q-learning guided sampler (orc_qlearn.h): grid == 0 switches it off
+void orc_qlearn_enable(void* h, int grid, const float* lo, const float* hi, float alpha, float eps, float qInit)
+{
+	QLearn& q = ((OrcRenderer*)h)->r.ql;
+	if (grid <= 0) { q = QLearn(); return; }
+	q.enable(grid, lo, hi, alpha, eps, qInit);
+}
+void orc_qlearn_apply(void* h) { ((OrcRenderer*)h)->r.ql.apply(); }
+void orc_qlearn_get(void* h, long long* sums, unsigned* counts, float* table)
+{
+	const QLearn& q = ((OrcRenderer*)h)->r.ql;
+	const size_t cells = (size_t)q.grid * q.grid * q.grid;
+	if (sums) memcpy(sums, q.sum.data(), cells * 64 * 8);
+	if (counts) memcpy(counts, q.cnt.data(), cells * 64 * 4);
+	if (table) for (size_t c = 0; c < cells; c++) memcpy(table + c * 64, &q.q[c * 72 + 8], 64 * 4);
+}
 // Renderer::Tick: one frame with the reference's iteration bookkeeping; *camChanged in/out
 int orc_tick(void* h, int* camChanged, unsigned frame, unsigned seedBase, int nthreads, unsigned* pixels)
 {

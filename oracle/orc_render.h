@@ -7,6 +7,7 @@
 // every call that draws, instead of one process-global state (see orc_math.h).
 #pragma once
 #include "orc_bvh.h"
+#include "orc_qlearn.h"
 
 namespace orc {
 
@@ -77,6 +78,7 @@ struct Renderer {
 	std::vector<float4> accumulator; // renderer.cpp:8
 	int iterationNumber = 1;          // Scene::iterationNumber (template/scene.h:1381)
 	int max_depth_trace = 4;          // renderer.cpp:269; tests may lower it ("primary rays only")
+	mutable QLearn ql;                // the Q-learning guided sampler (orc_qlearn.h; no reference code: parity unpinned), off by default
 
 	void Init(int w, int h) // :5-11
 	{
@@ -177,20 +179,32 @@ struct Renderer {
 	}
 
 	// Renderer::Sample (:128-236)
-	float3 Sample(Ray& ray, int depth, float3 energy, uint& seed, Counters& cnt) const
+	// prevKey (Q-learning only): 1 + cell * 64 + patch of the scattering that sent this ray, 0 for none
+	float3 Sample(Ray& ray, int depth, float3 energy, uint& seed, Counters& cnt, uint prevKey = 0) const
 	{
 		const Scene& sc = *scene;
 		if (depth < 0) return float3(0.05f);
 		float3 totCol = float3(0);
 		float t_min = 0.001f;
 		sc.FindNearest(ray, t_min, cnt);
-		if (ray.objIdx == -1) return sc.GetSkyColor(ray);
-		if (isLight(ray.objIdx))
-			return sc.lights[ray.objIdx - 11].GetLightIntensityAt(ray.IntersectionPoint(), ray.hitNormal, ray.IntersectionPoint());
+		if (ray.objIdx == -1) {
+			const float3 sky = sc.GetSkyColor(ray);
+			if (ql.on && prevKey) ql.reward(prevKey, QLearn::lum(sky));
+			return sky;
+		}
+		if (isLight(ray.objIdx)) {
+			const float3 li = sc.lights[ray.objIdx - 11].GetLightIntensityAt(ray.IntersectionPoint(), ray.hitNormal, ray.IntersectionPoint());
+			if (ql.on && prevKey) ql.reward(prevKey, QLearn::lum(li));
+			return li;
+		}
 		float3 intersectionPoint = ray.IntersectionPoint();
 		float3 normal = ray.hitNormal;
 		const Material& m = sc.materials[ray.mat];
 		float3 f = m.col;
+		if (ql.on && prevKey) {
+			const bool dif = m.type == DIFFUSE;
+			ql.reward(prevKey, ql.expected(ql.cell(intersectionPoint), normal, dif ? QLearn::lum(m.col * m.albedo) : QLearn::lum(m.col), dif));
+		}
 		if (sc.raytracer) { // :143-153, unreachable from Tick (which calls Sample only when raytracer is clear)
 			double p = f.x > f.y && f.x > f.z ? f.x : f.y > f.z ? f.y : f.z;
 			if (depth < 5 || !p) {
@@ -218,6 +232,23 @@ struct Renderer {
 				directLightning += (1 - m.shinieness) * m.col * attenuation * energy;
 			}
 			float3 indirectLightning = float3(0);
+			if (ql.on) {
+				// guided: the direction from the Q table of this cell; 1 / (16 P) = 1 / (pi pdf) stands where the uniform hemisphere has 2
+				float P;
+				int patch;
+				const int cell = ql.cell(intersectionPoint);
+				const float3 d = ql.sample(cell, seed, P, patch);
+				const float c = dot(d, normal);
+				float fq = 0;
+				if (c > 0) {
+					float3 cos_i = float3(c);
+					Ray next(intersectionPoint, d);
+					indirectLightning += m.col * cos_i * Sample(next, depth - 1, energy, seed, cnt, 1u + (uint)cell * 64 + (uint)patch);
+					fq = 1.0f / (16.0f * P);
+				} else ql.reward(1u + (uint)cell * 64 + (uint)patch, 0.0f); // below the surface: nothing to trace, the patch learns 0
+				totCol = (directLightning * INVPI + fq * indirectLightning) * m.albedo;
+				break;
+			}
 			int N = 1;
 			for (int i = 0; i < N; ++i) {
 				float3 rayToHemi = RandomInHemisphere(seed, normal);

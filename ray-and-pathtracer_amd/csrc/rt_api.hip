@@ -83,6 +83,9 @@ struct rt_ctx {
 	int megaPathMax = 0;     // RT_MEGA_PATH_MAX: path batches up to this many samples run as one launch too (k_path_mega).  Off: measured slower than
 	                         // the five rounds of rt_stream.h at every size (1080p x 1: 3.33 against 3.01 ms, x 2: 4.92 / 3.88; profiles/r03_tick_time.txt)
 	int useMega = 1;         // RT_MEGA: 1 Whitted frames as one launch (default), 0 the wavefront rounds of rt_kernels.h
+	// Q-learning guided sampling (rt_qlearn.h)
+	QTable Qt;
+	std::vector<void*> qAllocs;
 	int twoRays = 0;         // RT_TWO: the stream pipeline's traversal kernels carry two rays per lane (trace_persistent<TWO>): bit 0 extend, bit 1 connect
 	int gridExtendS2 = 0, gridConnectS2 = 0;
 	uint* spill2 = nullptr; uint* sideSpill2 = nullptr; // their spill columns (two per lane)
@@ -290,6 +293,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
 	if (getenv("RT_MEGA_PATH_MAX")) c->megaPathMax = atoi(getenv("RT_MEGA_PATH_MAX"));
 	memset(&c->M, 0, sizeof(c->M));
+	memset(&c->Qt, 0, sizeof(c->Qt));
 	if (getenv("RT_TWO")) c->twoRays = atoi(getenv("RT_TWO")) & 3;
 	if (getenv("RT_SHADE_LDS")) c->shadeLds = atoi(getenv("RT_SHADE_LDS")) != 0;
 	memset(&c->T, 0, sizeof(c->T));
@@ -323,7 +327,7 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridConnectS2 = std::min(resident((const void*)k_connect_s2<false>), resident((const void*)k_connect_s2<true>));
 		c->gridMega = resident((const void*)k_whitted_mega);
 		c->gridMegaPath = resident((const void*)k_path_mega);
-		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_shade_s);
+		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : std::min(resident((const void*)k_shade_s<false>), resident((const void*)k_shade_s<true>));
 		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
 		const void* qk[9] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true>,
@@ -389,6 +393,7 @@ void rt_destroy(rt_ctx* c)
 	}
 	free_pool(c->streamAllocs);
 	free_pool(c->megaAllocs);
+	free_pool(c->qAllocs);
 	if (c->spill2) (void)hipFree(c->spill2);
 	if (c->sideSpill2) (void)hipFree(c->sideSpill2);
 	if (c->streamSide) { (void)hipStreamSynchronize(c->streamSide); (void)hipStreamDestroy(c->streamSide); }
@@ -1635,7 +1640,8 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		hipLaunchKernelGGL(k_assign, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 		if (pendingJoin) { HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0)); pendingJoin = false; }
 		prof_begin(c, K_SHADE, st);
-		hipLaunchKernelGGL(k_shade_s, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt);
+		if (c->Qt.on) hipLaunchKernelGGL(k_shade_s<true>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt, c->Qt);
+		else hipLaunchKernelGGL(k_shade_s<false>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt, c->Qt);
 		prof_end(c, st);
 		if (twoStreams) {
 			HIPCHK(c, hipEventRecord(c->streamFork, st));
@@ -1667,7 +1673,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 // (the reference's walk visits the root pair for every ray, which a producer-side decision skips)
 static bool stream_eligible(const rt_ctx* c, int mode, size_t samples)
 {
-	return c->useStream && mode == RT_MODE_PATH && !c->pathUnsupported && c->counting != RT_COUNT_REFERENCE && samples <= (size_t)slot_budget(c);
+	return (c->useStream || c->Qt.on) && mode == RT_MODE_PATH && !c->pathUnsupported && c->counting != RT_COUNT_REFERENCE && samples <= (size_t)slot_budget(c);
 }
 
 // Which round loop a path batch with a slot per sample takes, whatever its size: 0 the plain one (run_rounds), 1 extend(r + 1)
@@ -1773,7 +1779,9 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 			if (rc != RT_OK) return rc;
 			continue;
 		}
-		if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && total <= (size_t)c->megaPathMax))) {
+		if (mode == RT_MODE_PATH && c->Qt.on && !stream_eligible(c, mode, total))
+			return fail(c, RT_E_UNSUPPORTED, "rt_render: the Q-learning sampler needs a path batch with an entry per sample (within the slot budget, no RT_COUNT_REFERENCE)");
+		if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && !c->Qt.on && total <= (size_t)c->megaPathMax))) {
 			rc = run_mega(c, R);
 			if (rc != RT_OK) return rc;
 			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
@@ -1848,7 +1856,7 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 	if (mode == RT_MODE_PATH && c->pathUnsupported) {
 		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
 		rc = check_overflow(c);
-	} else if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && n <= c->megaPathMax))) {
+	} else if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && !c->Qt.on && n <= c->megaPathMax))) {
 		rc = run_mega(c, R);
 	} else if (stream_eligible(c, mode, (size_t)n)) {
 		rc = ensure_stream_state(c, n);
@@ -2161,6 +2169,74 @@ int rt_get_profile(rt_ctx* c, rt_profile* out, int reset)
 	if (reset) memset(&c->prof, 0, sizeof(c->prof));
 	return RT_OK;
 }
+int rt_qlearn_enable(rt_ctx* c, const rt_qlearn_params* p)
+{
+	if (!c) return RT_E_ARG;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	free_pool(c->qAllocs);
+	memset(&c->Qt, 0, sizeof(c->Qt));
+	if (!p) return RT_OK;
+	if (p->grid < 1 || p->grid > 64) return fail(c, RT_E_ARG, "rt_qlearn_enable: grid %d (1..64)", p->grid);
+	for (int a = 0; a < 3; a++)
+		if (!(p->hi[a] > p->lo[a])) return fail(c, RT_E_ARG, "rt_qlearn_enable: empty box on axis %d", a);
+	if (!(p->alpha > 0 && p->alpha <= 1) || !(p->epsilon >= 0 && p->epsilon <= 1) || !(p->q_init > 0)) return fail(c, RT_E_ARG, "rt_qlearn_enable: alpha in (0, 1], epsilon in [0, 1], q_init > 0");
+	if (c->pathUnsupported) return fail(c, RT_E_UNSUPPORTED, "rt_qlearn_enable: this scene's path mode runs the general kernel (%s)", c->pathUnsupportedWhy.c_str());
+	QTable Q;
+	memset(&Q, 0, sizeof(Q));
+	const size_t cells = (size_t)p->grid * p->grid * p->grid;
+	float4* centre = nullptr;
+	HIPCHK(c, dalloc(c->qAllocs, &Q.q, cells * RT_Q_ROW));
+	HIPCHK(c, dalloc(c->qAllocs, &Q.sum, cells * RT_Q_PATCHES));
+	HIPCHK(c, dalloc(c->qAllocs, &Q.cnt, cells * RT_Q_PATCHES));
+	HIPCHK(c, dalloc(c->qAllocs, &centre, (size_t)RT_Q_PATCHES));
+	Q.centre = centre, Q.grid = p->grid, Q.on = 1;
+	for (int a = 0; a < 3; a++) Q.lo[a] = p->lo[a], Q.inv[a] = (float)p->grid / (p->hi[a] - p->lo[a]);
+	Q.eps = p->epsilon, Q.alpha = p->alpha, Q.qMin = 1e-4f;
+	const int threads = (int)std::max(cells, (size_t)RT_Q_PATCHES);
+	hipLaunchKernelGGL(k_q_init, dim3((threads + 255) / 256), dim3(256), 0, c->stream, Q, p->q_init, centre);
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->Qt = Q;
+	return RT_OK;
+}
+int rt_qlearn_apply(rt_ctx* c)
+{
+	if (!c || !c->Qt.on) return fail(c, RT_E_STATE, "rt_qlearn_apply: the sampler is off");
+	HIPCHK(c, hipSetDevice(c->device));
+	const int cells = c->Qt.grid * c->Qt.grid * c->Qt.grid;
+	hipLaunchKernelGGL(k_q_apply, dim3((cells + 255) / 256), dim3(256), 0, c->stream, c->Qt);
+	HIPCHK(c, hipGetLastError());
+	return RT_OK;
+}
+int rt_qlearn_get_sums(rt_ctx* c, int64_t* sums, uint32_t* counts)
+{
+	if (!c || !c->Qt.on || !sums || !counts) return fail(c, RT_E_STATE, "rt_qlearn_get_sums: the sampler is off, or a null argument");
+	const size_t n = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemcpy(sums, c->Qt.sum, n * 8, hipMemcpyDeviceToHost));
+	HIPCHK(c, hipMemcpy(counts, c->Qt.cnt, n * 4, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+int rt_qlearn_set_sums(rt_ctx* c, const int64_t* sums, const uint32_t* counts)
+{
+	if (!c || !c->Qt.on || !sums || !counts) return fail(c, RT_E_STATE, "rt_qlearn_set_sums: the sampler is off, or a null argument");
+	const size_t n = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemcpy(c->Qt.sum, sums, n * 8, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->Qt.cnt, counts, n * 4, hipMemcpyHostToDevice));
+	return RT_OK;
+}
+int rt_qlearn_get_table(rt_ctx* c, float* q_out)
+{
+	if (!c || !c->Qt.on || !q_out) return fail(c, RT_E_STATE, "rt_qlearn_get_table: the sampler is off, or a null argument");
+	const size_t cells = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid;
+	std::vector<float> rows(cells * RT_Q_ROW);
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemcpy(rows.data(), c->Qt.q, rows.size() * 4, hipMemcpyDeviceToHost));
+	for (size_t v = 0; v < cells; v++) memcpy(q_out + v * RT_Q_PATCHES, &rows[v * RT_Q_ROW + 8], RT_Q_PATCHES * 4);
+	return RT_OK;
+}
+
 #ifndef RT_EXTRA_FLAGS
 #define RT_EXTRA_FLAGS ""
 #endif

@@ -1,0 +1,155 @@
+// Q-learning guided sampling of the indirect bounce (BASELINE config 5 "Q-learning sampler on").
+// The reference snapshot holds NO code for it -- only README.md:36-42: "use QLearning to influence the sampling
+// direction (Dahm & Keller 2017, Learning Light Transport the Reinforced Way) ... initialize sampling positions; pick sampling
+// direction according to the QValue of neighboring points; store and update directions with a corresponding probability per
+// sampling point".  What follows is therefore this repository's own statement of that paper's scheme (parity unpinned; the
+// CPU checker of the test tier states the same definition, and the two are held bit against bit on the table and within 1e-4
+// on the frames):
+//   sampling positions   the cells of a G x G x G grid over a caller-given box ("voxel" of a hit point)
+//   directions           64 equal-area patches of the sphere per cell: 8 bands in z x 8 sectors in phi (pi / 16 sr each)
+//   Q[cell][patch]       a scalar (luminance) estimate of the radiance arriving at the cell from the patch
+//   pick                 at a DIFFUSE hit the scattered direction's patch is drawn with P = (1 - eps) Q / sum(Q) + eps / 64
+//                        (every direction keeps a positive density: unbiased), the direction uniformly inside the patch; the
+//                        estimator's factor 2 = 1 / (pi pdf) of the uniform hemisphere becomes 1 / (16 P); a direction
+//                        below the surface contributes nothing and teaches the patch a reward of 0
+//   update (eq. 8)       when the scattered ray's hit y is shaded: reward = what y emits towards x (sky, light) or, for a
+//                        surface, the expected reflected Q at y: rho / 16 * sum_p Q[cell(y)][p] max(0, n_y . d_p) (diffuse),
+//                        luminance(col) * mean Q[cell(y)] (specular).  Rewards are summed as 48.16 fixed-point INTEGERS with a
+//                        count per (cell, patch); rt_qlearn_apply folds them into Q <- (1 - alpha) Q + alpha mean between
+//                        batches.  Within a batch Q is read-only.
+// Why integers: sums of integers do not depend on the order in which lanes, waves or GPUs add them, so a frame is
+// reproducible, equals the CPU statement's, and -- with the sums all-reduced between ranks before the apply (bench.py) -- does
+// not depend on how the rows were sharded.  The rule this picks for "per-pixel streams must stay independent of sharding":
+// learning happens BETWEEN batches, never inside one.
+#pragma once
+#include "rt_kernels.h"
+
+namespace rtd {
+
+#define RT_Q_PATCHES 64
+#define RT_Q_ROW 72 // floats per cell: 8 band sums, then 64 values (band-major)
+struct QTable {
+	float* q;            // [cells][RT_Q_ROW]
+	long long* sum;      // [cells][64] rewards of the current batch, 48.16 fixed point
+	uint* cnt;           // [cells][64]
+	const float4* centre; // [64] patch centre directions
+	int grid, on;
+	float lo[3], inv[3]; // cell = (int)((x - lo) * inv), clamped
+	float eps, alpha, qMin;
+};
+
+__device__ __forceinline__ float q_lum(const f3& c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
+__device__ __forceinline__ int q_cell(const QTable& Q, const f3& x)
+{
+	int i[3];
+	const float f[3] = { (x.x - Q.lo[0]) * Q.inv[0], (x.y - Q.lo[1]) * Q.inv[1], (x.z - Q.lo[2]) * Q.inv[2] };
+	for (int a = 0; a < 3; a++) {
+		int k = f[a] > 0 ? (f[a] < (float)Q.grid ? (int)f[a] : Q.grid - 1) : 0; // NaN -> 0
+		i[a] = k < Q.grid ? k : Q.grid - 1;
+	}
+	return (i[2] * Q.grid + i[1]) * Q.grid + i[0];
+}
+// direction of patch (band i, sector j) at (u1, u2) in [0, 1)^2
+__device__ __forceinline__ f3 q_direction(int i, int j, float u1, float u2)
+{
+	const float z = -1 + ((float)i + u1) * 0.25f;
+	const float phi = ((float)j + u2) * (RT_TWOPI * 0.125f);
+	const float s = sqrtf(t_fmaxf(0.f, 1 - z * z));
+	return f3(s * x_cosf(phi), s * x_sinf(phi), z);
+}
+__global__ void k_q_init(QTable Q, float qInit, float4* centre)
+{
+	const int cells = Q.grid * Q.grid * Q.grid;
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < RT_Q_PATCHES) centre[t] = mk4(q_direction(t >> 3, t & 7, 0.5f, 0.5f), 0.0f);
+	if (t >= cells) return;
+	float* row = Q.q + (size_t)t * RT_Q_ROW;
+	for (int p = 0; p < RT_Q_PATCHES; p++) row[8 + p] = qInit, Q.sum[(size_t)t * RT_Q_PATCHES + p] = 0, Q.cnt[(size_t)t * RT_Q_PATCHES + p] = 0;
+	for (int i = 0; i < 8; i++) {
+		float b = 0;
+		for (int j = 0; j < 8; j++) b = b + row[8 + 8 * i + j];
+		row[i] = b;
+	}
+}
+// fold the batch's rewards into the table: one thread per cell
+__global__ void k_q_apply(QTable Q)
+{
+	const int cells = Q.grid * Q.grid * Q.grid;
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= cells) return;
+	float* row = Q.q + (size_t)t * RT_Q_ROW;
+	for (int p = 0; p < RT_Q_PATCHES; p++) {
+		const size_t k = (size_t)t * RT_Q_PATCHES + p;
+		const uint n = Q.cnt[k];
+		if (n) {
+			const float mean = (float)((double)Q.sum[k] / ((double)n * 65536.0));
+			row[8 + p] = t_fmaxf((1 - Q.alpha) * row[8 + p] + Q.alpha * mean, Q.qMin);
+			Q.sum[k] = 0, Q.cnt[k] = 0;
+		}
+	}
+	for (int i = 0; i < 8; i++) {
+		float b = 0;
+		for (int j = 0; j < 8; j++) b = b + row[8 + 8 * i + j];
+		row[i] = b;
+	}
+}
+
+// the reward a scattered ray brings back to (cell, patch) = key - 1
+__device__ __forceinline__ void q_reward(const QTable& Q, uint key, float R)
+{
+	R = (R >= 0) ? (R < 64.0f ? R : 64.0f) : 0.0f; // a directly seen light is +inf in the reference (Q7); NaN teaches nothing
+	atomicAdd((unsigned long long*)&Q.sum[key - 1], (unsigned long long)__float2ll_rn(R * 65536.0f));
+	atomicAdd(&Q.cnt[key - 1], 1u);
+}
+// expected reflected Q at a surface hit (the integral of eq. 8 over the 64 patches)
+__device__ __forceinline__ float q_expected(const QTable& Q, int cell, const f3& normal, float rho, bool diffuse)
+{
+	const float* row = Q.q + (size_t)cell * RT_Q_ROW;
+	if (!diffuse) {
+		float T = 0;
+		for (int i = 0; i < 8; i++) T = T + row[i];
+		return rho * (T * (1.0f / 64));
+	}
+	float s = 0;
+	for (int p = 0; p < RT_Q_PATCHES; p++) {
+		const float c = dot(xyz(Q.centre[p]), normal);
+		s = s + row[8 + p] * t_fmaxf(0.f, c);
+	}
+	return rho * (s * (1.0f / 16));
+}
+// the guided pick at a diffuse hit: four draws (mixture, patch, two inside the patch)
+__device__ __forceinline__ f3 q_sample(const QTable& Q, int cell, uint& seed, float& P, int& patch)
+{
+	const float* row = Q.q + (size_t)cell * RT_Q_ROW;
+	float b[8];
+	float T = 0;
+	for (int i = 0; i < 8; i++) b[i] = row[i], T = T + b[i];
+	const float uSel = RandomFloat(seed), uPick = RandomFloat(seed), u1 = RandomFloat(seed), u2 = RandomFloat(seed);
+	int i = 0, j = 0;
+	float qp;
+	if (uSel < Q.eps || !(T > 0)) {
+		patch = (int)(uPick * 64);
+		if (patch > 63) patch = 63;
+		i = patch >> 3, j = patch & 7;
+		qp = row[8 + patch];
+	} else {
+		const float x = uPick * T;
+		float acc = 0;
+		for (i = 0; i < 7; i++) {
+			if (x < acc + b[i]) break;
+			acc = acc + b[i];
+		}
+		const float x2 = x - acc;
+		float acc2 = 0;
+		for (j = 0; j < 7; j++) {
+			if (x2 < acc2 + row[8 + 8 * i + j]) break;
+			acc2 = acc2 + row[8 + 8 * i + j];
+		}
+		patch = 8 * i + j;
+		qp = row[8 + patch];
+	}
+	P = T > 0 ? (1 - Q.eps) * (qp / T) + Q.eps * (1.0f / 64) : 1.0f / 64;
+	return q_direction(i, j, u1, u2);
+}
+
+} // namespace rtd

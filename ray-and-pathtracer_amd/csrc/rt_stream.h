@@ -35,6 +35,7 @@
 // The step is the one trace_persistent makes, on the same operands, so results are identical by construction.
 #pragma once
 #include "rt_kernels.h"
+#include "rt_qlearn.h"
 
 namespace rtd {
 
@@ -389,7 +390,10 @@ __device__ __forceinline__ void load_tables(DScene& S, ShadeTables& L, int enabl
 #ifndef RT_SHADE_S_WAVES
 #define RT_SHADE_S_WAVES 5
 #endif
-__global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S0, DCamera C, RenderParams R, StreamState T, int round, int fresh, int last, int lastNext, int decide, int ldsTables, int counting)
+// QL: the indirect bounce of a diffuse hit is drawn from the Q table (rt_qlearn.h) and every hit pays its reward to the
+// (cell, patch) that sent the ray; W.w of an entry carries that key (0: none).
+template <bool QL>
+__global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S0, DCamera C, RenderParams R, StreamState T, int round, int fresh, int last, int lastNext, int decide, int ldsTables, int counting, QTable Qt)
 {
 	__shared__ ShadeTables tables;
 	uint nDecided = 0;
@@ -430,14 +434,26 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 			const bool childTraces = !last; // Sample(depth - 1 < 0) = 0.05 (renderer.cpp:129)
 			bool segmentEnds = true, wantShadow = false;
 			f3 nO(0.0f), nD(0.0f), nW(0.0f);
+			uint nextKey = 0;       // QL: (cell, patch) + 1 of the ray this hit scatters
+			bool deadSample = false; // QL: the guided direction points below the surface: nothing to trace
+			const uint prevKey = QL ? __float_as_uint(w4.w) : 0u;
 
 			if (id.x == -1) {
-				Lsum = Lsum + W * sky_color(S, D); // renderer.cpp:134
+				const f3 sky = sky_color(S, D);
+				Lsum = Lsum + W * sky; // renderer.cpp:134
+				if (QL && prevKey) q_reward(Qt, prevKey, q_lum(sky));
 			} else if (id.x >= 11 && id.x < 11 + S.nLights) {
-				Lsum = Lsum + W * light_intensity(S.lights[id.x - 11], I, normal, I); // :135-137
+				const f3 li = light_intensity(S.lights[id.x - 11], I, normal, I);
+				Lsum = Lsum + W * li; // :135-137
+				if (QL && prevKey) q_reward(Qt, prevKey, q_lum(li));
 			} else {
 				const DMaterial m = S.mats[id.y];
 				const f3 col(m.col[0], m.col[1], m.col[2]);
+				if (QL && prevKey) {
+					const bool dif = m.type != 3 && m.type != 2;
+					const f3 albedoQ(m.albedo[0], m.albedo[1], m.albedo[2]);
+					q_reward(Qt, prevKey, q_expected(Qt, q_cell(Qt, I), normal, dif ? q_lum(col * albedoQ) : q_lum(col), dif));
+				}
 				if (m.type == 3) { // GLASS, renderer.cpp:198-233
 					const float kr = glass_fresnel(normalize(D), normalize(normal), m.ir);
 					const bool outside = dot(D, normal) < 0;
@@ -477,10 +493,28 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 						T.shP[(size_t)i * cap + (size_t)p.y] = mk4(pickedPos, 0.0f);
 					}
 					const f3 albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
-					const f3 rayToHemi = RandomInHemisphere(seed, normal);
-					const f3 cos_i(dot(rayToHemi, normal));
-					nO = I, nD = rayToHemi;
-					nW = W * ((2 * (col * cos_i)) * albedo); // child coefficient of (direct*INVPI + 2*indirect) * albedo
+					if constexpr (QL) {
+						// the scattered direction from the Q table of this cell instead of the uniform hemisphere
+						float P;
+						int patch;
+						const int cell = q_cell(Qt, I);
+						const f3 dirQ = q_sample(Qt, cell, seed, P, patch);
+						const float c = dot(dirQ, normal);
+						nO = I, nD = dirQ;
+						if (c > 0) {
+							const f3 cos_i(c);
+							nW = W * (((1.0f / (16.0f * P)) * (col * cos_i)) * albedo); // 1 / (pi pdf) in the place of the uniform hemisphere's 2
+							nextKey = 1u + (uint)cell * RT_Q_PATCHES + (uint)patch;
+						} else {
+							deadSample = true; // below the surface: the patch learns a reward of 0, the path carries no weight on
+							q_reward(Qt, 1u + (uint)cell * RT_Q_PATCHES + (uint)patch, 0.0f);
+						}
+					} else {
+						const f3 rayToHemi = RandomInHemisphere(seed, normal);
+						const f3 cos_i(dot(rayToHemi, normal));
+						nO = I, nD = rayToHemi;
+						nW = W * ((2 * (col * cos_i)) * albedo); // child coefficient of (direct*INVPI + 2*indirect) * albedo
+					}
 					if (childTraces) segmentEnds = false;
 					else Lsum = Lsum + nW * f3(0.05f);
 				}
@@ -496,9 +530,15 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 			if (!segmentEnds || wantShadow) {
 				T.E[pout][p.x] = mk4(E, __uint_as_float(seed));
 				T.L[pout][p.x] = mk4(Lsum, l4.w);
-				if (!segmentEnds) {
+				if (!segmentEnds && deadSample) {
+					// the entry the class byte promised, as a ray that hits nothing and weighs nothing: the next shade adds 0 and ends it
+					T.O[pout][p.x] = mk4(nO, 1e34f), T.D[pout][p.x] = mk4(nD, 0.0f);
+					T.hitN[pout][p.x] = make_float4(0, 0, 0, 1e34f), T.hitId[pout][p.x] = make_int2(-1, -1);
+					T.W[pout][p.x] = make_float4(0, 0, 0, 0);
+					T.cls[pout][p.x] = CL_LIVE;
+				} else if (!segmentEnds) {
 					const NewRay nr = emit_ray_s(S, T, pout, p.x, nO, nD, mode_t_min(1), lastNext, false, decide != 0);
-					T.W[pout][p.x] = mk4(nW, 0.0f);
+					T.W[pout][p.x] = mk4(nW, __uint_as_float(nextKey));
 					T.cls[pout][p.x] = nr.cls;
 					nDecided += nr.decided ? 1u : 0u;
 				}

@@ -249,6 +249,12 @@ int rth_renderer_sync_camera(void* h) { RthRenderer* r = (RthRenderer*)h; GUARD(
 void rth_renderer_set_download(void* h, int on) { ((RthRenderer*)h)->r->downloadEachTick = on != 0; }
 int rth_renderer_iteration(void* h) { return ((RthRenderer*)h)->r->scene.GetIterationNumber(); }
 int rth_renderer_tick(void* h) { RthRenderer* r = (RthRenderer*)h; GUARD(r, r->r->Tick(0.0f)); return 0; }
+int rth_renderer_qlearning(void* h, int grid, const float* lo, const float* hi, float alpha, float eps, float qInit)
+{
+	RthRenderer* r = (RthRenderer*)h;
+	GUARD(r, if (grid > 0) r->r->EnableQLearning(grid, float3(lo[0], lo[1], lo[2]), float3(hi[0], hi[1], hi[2]), alpha, eps, qInit); else r->r->DisableQLearning());
+	return 0;
+}
 const float* rth_renderer_accumulator(void* h) { return &((RthRenderer*)h)->r->accumulator[0].x; }
 const unsigned* rth_renderer_pixels(void* h) { return ((RthRenderer*)h)->r->screenPixels; }
 int rth_renderer_trace(void* h, int path, const float* O, const float* D, int depth, const float* energy, float* rgb)

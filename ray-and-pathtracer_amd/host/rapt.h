@@ -363,6 +363,14 @@ public:
 	float3 Sample(Ray& ray, int depth, float3 energy);     // renderer.cpp:128
 	void Tick(float deltaTime);                            // renderer.cpp:240
 	void Shutdown();
+	// Q-learning guided sampling of the indirect bounce in path mode (README.md:36-42 of the reference names Dahm & Keller 2017;
+	// the snapshot holds no code for it, so this is the library's own statement: rt_qlearn_*, PARITY UNPINNED).  Tick folds the
+	// frame's rewards into the table after every path frame; with several contexts their integer reward sums are added first, so
+	// every GPU learns the same table and the frame does not depend on how its rows were sharded.
+	void EnableQLearning(int grid, float3 lo, float3 hi, float alpha = 0.3f, float epsilon = 0.2f, float qInit = 1.0f);
+	void DisableQLearning();
+	bool qlearning = false;
+	int qgrid = 0;
 	float4* accumulator = nullptr; // host copy, refreshed by Tick
 	uint32_t* screenPixels = nullptr; // Surface::pixels analogue (template/precomp.h:134)
 	Scene scene;

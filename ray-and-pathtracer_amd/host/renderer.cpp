@@ -5,6 +5,7 @@
 #include <exception>
 #include <stdexcept>
 #include <thread>
+#include <vector>
 
 namespace rapt {
 
@@ -115,11 +116,41 @@ void Renderer::Tick(float /*deltaTime*/)
 			if (count > 0) check(ctx, rt_gather_rows(ctx, ctxs[k], k, n, count));
 		}
 	}
+	if (!scene.raytracer && qlearning) {
+		// learning happens between frames: add the contexts' pending (integer) reward sums, give every context the total, apply
+		if (n > 1) {
+			std::vector<int64_t> sum, s1;
+			std::vector<uint32_t> cnt, c1;
+			const size_t cells = (size_t)qgrid * qgrid * qgrid * 64;
+			sum.assign(cells, 0), cnt.assign(cells, 0), s1.resize(cells), c1.resize(cells);
+			for (rt_ctx* k : ctxs) {
+				check(k, rt_qlearn_get_sums(k, s1.data(), c1.data()));
+				for (size_t i = 0; i < cells; i++) sum[i] += s1[i], cnt[i] += c1[i];
+			}
+			for (rt_ctx* k : ctxs) check(k, rt_qlearn_set_sums(k, sum.data(), cnt.data()));
+		}
+		for (rt_ctx* k : ctxs) check(k, rt_qlearn_apply(k));
+	}
 	if (!scene.raytracer) frame++;
 	check(ctx, rt_resolve(ctx, it, 0, height, screenPixels));
 	if (downloadEachTick) check(ctx, rt_download_accumulator(ctx, 0, height, &accumulator[0].x));
 	if (!scene.raytracer && !camChanged) scene.SetIterationNumber(it + 1);
 	camera.SetChange(false);
+}
+
+void Renderer::EnableQLearning(int grid, float3 lo, float3 hi, float alpha, float epsilon, float qInit)
+{
+	if (!ctx) Init();
+	rt_qlearn_params p;
+	p.grid = grid, p.alpha = alpha, p.epsilon = epsilon, p.q_init = qInit;
+	p.lo[0] = lo.x, p.lo[1] = lo.y, p.lo[2] = lo.z, p.hi[0] = hi.x, p.hi[1] = hi.y, p.hi[2] = hi.z;
+	for (rt_ctx* k : ctxs) check(k, rt_qlearn_enable(k, &p));
+	qlearning = true, qgrid = grid;
+}
+void Renderer::DisableQLearning()
+{
+	for (rt_ctx* k : ctxs) check(k, rt_qlearn_enable(k, nullptr));
+	qlearning = false;
 }
 
 static float3 eval(rt_ctx* ctx, int mode, const Ray& ray, int depth, const float3& energy, uint32_t seed)

@@ -25,7 +25,12 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
               "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_device_of",
-              "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy", "rt_build_info", "rt_tuning_info"]
+              "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy", "rt_build_info", "rt_tuning_info",
+              "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table"]
+
+
+class RtQlearnParams(C.Structure):
+    _fields_ = [("grid", C.c_int32), ("lo", C.c_float * 3), ("hi", C.c_float * 3), ("alpha", C.c_float), ("epsilon", C.c_float), ("q_init", C.c_float)]
 
 
 class RtCamera(C.Structure):
@@ -75,6 +80,11 @@ def rt_lib():
         L.rt_create.argtypes = [C.c_int, C.c_int, C.c_int]
         L.rt_last_error.restype = C.c_char_p
         L.rt_last_error.argtypes = [C.c_void_p]
+        L.rt_qlearn_enable.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_qlearn_apply.argtypes = [C.c_void_p]
+        L.rt_qlearn_get_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_qlearn_set_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_qlearn_get_table.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_build_info.restype = C.c_char_p
         L.rt_build_info.argtypes = []
         L.rt_tuning_info.restype = C.c_char_p
@@ -353,6 +363,11 @@ class HostRenderer:
     def tick(self):
         self._chk(self.L.rth_renderer_tick(self.h))
 
+    def tick_qlearning(self, grid, lo=(0, 0, 0), hi=(1, 1, 1), alpha=0.3, epsilon=0.2, q_init=1.0):
+        """rapt::Renderer::EnableQLearning (grid > 0) / DisableQLearning: Tick then learns between path frames, on every context"""
+        self._qgrid = grid
+        self._chk(self.L.rth_renderer_qlearning(self.h, grid, _f3(lo), _f3(hi), C.c_float(alpha), C.c_float(epsilon), C.c_float(q_init)))
+
     def iteration(self):
         """Scene::GetIterationNumber()"""
         return int(self.L.rth_renderer_iteration(self.h))
@@ -500,6 +515,33 @@ class HostRenderer:
         b = np.zeros(8, dtype=np.uint64)
         self._rt(self.rt.rt_get_counters_split(self.ctx, _p(a), _p(b), int(reset)))
         return dict(zip(COUNTER_NAMES, [int(x) for x in a])), dict(zip(COUNTER_NAMES, [int(x) for x in b]))
+
+    # ---- Q-learning guided sampler (include/rt_amd.h rt_qlearn_*; no reference code: parity unpinned) ----
+    def qlearn_enable(self, grid, lo, hi, alpha=0.3, epsilon=0.2, q_init=1.0):
+        p = RtQlearnParams(grid, (C.c_float * 3)(*lo), (C.c_float * 3)(*hi), alpha, epsilon, q_init)
+        self._qgrid = grid
+        self._rt(self.rt.rt_qlearn_enable(self.ctx, C.byref(p)))
+
+    def qlearn_disable(self):
+        self._rt(self.rt.rt_qlearn_enable(self.ctx, None))
+
+    def qlearn_apply(self):
+        self._rt(self.rt.rt_qlearn_apply(self.ctx))
+
+    def qlearn_sums(self):
+        n = self._qgrid ** 3
+        sums, cnts = np.zeros((n, 64), np.int64), np.zeros((n, 64), np.uint32)
+        self._rt(self.rt.rt_qlearn_get_sums(self.ctx, _p(sums), _p(cnts)))
+        return sums, cnts
+
+    def qlearn_set_sums(self, sums, cnts):
+        sums, cnts = np.ascontiguousarray(sums, np.int64), np.ascontiguousarray(cnts, np.uint32)
+        self._rt(self.rt.rt_qlearn_set_sums(self.ctx, _p(sums), _p(cnts)))
+
+    def qlearn_table(self):
+        tab = np.zeros((self._qgrid ** 3, 64), np.float32)
+        self._rt(self.rt.rt_qlearn_get_table(self.ctx, _p(tab)))
+        return tab
 
     def build_info(self):
         """rt_build_info() + rt_tuning_info(): compile flags / compile-time tuning of the library and the tuning this context resolved"""

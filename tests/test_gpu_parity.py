@@ -398,6 +398,21 @@ def test_multi_context_renderer(devices, scenes, oracle_api, host_api):
             out.append(r.tick_accumulator().copy())
         anim[key] = out
         r.close()
+    # Q-learning through Tick (rapt::Renderer::EnableQLearning): the contexts add their integer reward sums after every path frame
+    # and all apply the total, so the sharded Ticks equal the one-context Ticks and every context ends with the same table
+    ql = {}
+    for key, devs in (("one", None), ("many", devices)):
+        r = host_api.HostRenderer(w, h, devices=devs)
+        scenes.mixed_small(r.scene)
+        r.commit()
+        r.scene.set_raytracer(False)
+        r.tick_qlearning(6, (-4, -1, -4), (4, 5, 6))
+        for _ in range(4):
+            r.tick()
+        ql[key] = (r.tick_accumulator().copy(), r.qlearn_table().copy())
+        r.close()
+    assert np.array_equal(ql["one"][0].view(np.uint32), ql["many"][0].view(np.uint32))
+    assert np.array_equal(ql["one"][1].view(np.uint32), ql["many"][1].view(np.uint32)) and ql["one"][1].min() < 0.9
     assert not np.array_equal(anim["one"][0], anim["one"][1])  # the geometry really moved
     for k in range(3):
         assert np.array_equal(anim["one"][k].view(np.uint32), anim["many"][k].view(np.uint32)), ("set_time", k)
@@ -1064,6 +1079,61 @@ def test_whitted_single_launch_equals_rounds(name, kw, w, h, scenes, oracle_api,
         r.close()
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,kw,w,h,box", [("mixed_small", {}, 64, 40, ((-4, -1, -4), (4, 5, 6))), ("pretty_tlas", {"n_instances": 4}, 96, 54, ((-6, -1.5, -1), (8, 5, 10))),
+                                             ("tlas_test2", {}, 64, 40, ((-6, -1, -2), (6, 7, 8)))])
+def test_qlearning_sampler(name, kw, w, h, box, scenes, oracle_api, host_api):
+    """SURVEY.md 8f N4 / BASELINE config 5 "Q-learning sampler on": Dahm & Keller's guided sampling of the indirect bounce
+    (csrc/rt_qlearn.h, rt_qlearn_*).  The reference snapshot holds no code for it (F2), so this is PARITY UNPINNED: the device
+    is held against the oracle's statement of the same scheme (oracle/orc_qlearn.h) -- after every batch the pending reward
+    sums and counts are equal integer for integer, the learned table bit for bit, the frames within the radiance tolerance --
+    and against itself: the rows of a batch rendered as two shards (the sums accumulate, the table is read-only inside a
+    batch) give the same frame and the same sums, which is the sharding rule the design states.  The learned table must
+    actually differ from its start, and the guided estimate must agree with the unguided one on average (unbiased)."""
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
+    orr.scene.set_raytracer(False)
+    r.clear(); r.render(host_api.RT_MODE_PATH, 0, 24)
+    plain = r.accumulator()[..., :3] / 24
+    orr.qlearn_enable(8, box[0], box[1], 0.3, 0.2, 1.0)
+    r.qlearn_enable(8, box[0], box[1], 0.3, 0.2, 1.0)
+    orr.clear(); r.clear()
+    frames = 3
+    for b in range(5):
+        orr.render(b * frames, frames, nthreads=0)
+        r.render(host_api.RT_MODE_PATH, b * frames, frames)
+        so, co, _ = orr.qlearn_state()
+        sg, cg = r.qlearn_sums()
+        assert co.sum() > 0 and np.array_equal(co, cg), b
+        assert np.array_equal(so, sg), b
+        ref, got = orr.accumulator(), r.accumulator()
+        err, cls_ok = rel_err(got[..., :3], ref[..., :3])
+        assert cls_ok and err.max() <= RADIANCE_TOL, (b, err.max())
+        orr.qlearn_apply(); r.qlearn_apply()
+        assert np.array_equal(orr.qlearn_state()[2].view(np.uint32), r.qlearn_table().view(np.uint32)), b
+    # the rows of one batch as two shards, from the same (read-only) table: the same frame, the same pending sums
+    zs, zc = np.zeros_like(sg), np.zeros_like(cg)
+    r.clear(); r.qlearn_set_sums(zs, zc)
+    r.render(host_api.RT_MODE_PATH, 50, frames)
+    full, (s_full, c_full) = r.accumulator().copy(), r.qlearn_sums()
+    r.clear(); r.qlearn_set_sums(zs, zc)
+    r.render_rows(host_api.RT_MODE_PATH, 50, frames, 0, 2, (h + 1) // 2)
+    r.render_rows(host_api.RT_MODE_PATH, 50, frames, 1, 2, h // 2)
+    s_two, c_two = r.qlearn_sums()
+    assert np.array_equal(r.accumulator().view(np.uint32), full.view(np.uint32))
+    assert np.array_equal(s_two, s_full) and np.array_equal(c_two, c_full)
+    r.qlearn_set_sums(zs, zc)
+    tab = r.qlearn_table()
+    assert tab.min() < 0.9 and tab.max() > 1.1  # it learned something
+    # unbiased: the guided mean image agrees with the unguided one where both are finite (noise-level tolerance on the mean)
+    r.clear(); r.render(host_api.RT_MODE_PATH, 100, 24)
+    guided = r.accumulator()[..., :3] / 24
+    fin = np.isfinite(plain) & np.isfinite(guided)
+    assert abs(guided[fin].mean() - plain[fin].mean()) <= 0.08 * plain[fin].mean()
+    r.qlearn_disable()
+    r.clear(); r.render(host_api.RT_MODE_PATH, 0, 24)
+    assert np.array_equal((r.accumulator()[..., :3] / 24).view(np.uint32), plain.view(np.uint32))  # off again: the plain sampler's frame
+    r.close()
 
 
 def test_sample_pools_on_separate_streams(scenes, oracle_api, host_api, monkeypatch):

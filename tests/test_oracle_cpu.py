@@ -151,6 +151,41 @@ def test_reference_probe_observations(scenes, oracle_api):
     r.close(); s.close()
 
 
+def test_qlearning_sampler_cpu(scenes, oracle_api):
+    """The oracle's statement of the Q-learning guided sampler (oracle/orc_qlearn.h; the reference holds no code for it, SURVEY
+    F2: parity unpinned).  Its rewards are integer sums, so the learned table and the frames must not depend on the number of
+    threads that rendered the batch; the table stays positive, its band sums are the sums of its values, rewards are bounded,
+    and the guided estimate agrees with the unguided one on average."""
+    runs = {}
+    for threads in (1, 4):
+        s = oracle_api.OracleScene()
+        scenes.mixed_small(s)
+        s.set_raytracer(False)
+        r = oracle_api.OracleRenderer(s, 40, 28)
+        r.qlearn_enable(6, (-4, -1, -4), (4, 5, 6), 0.3, 0.2, 1.0)
+        for b in range(4):
+            r.render(3 * b, 3, nthreads=threads)
+            sums, cnts, _ = r.qlearn_state()
+            assert cnts.sum() > 0 and sums.min() >= 0 and sums.max() <= 64 * 65536 * int(cnts.max())
+            r.qlearn_apply()
+        tab = r.qlearn_state()[2]
+        runs[threads] = (r.accumulator().copy(), tab.copy())
+        assert tab.min() > 0 and tab.min() < 0.9 < 1.1 < tab.max()
+        r.close(); s.close()
+    assert np.array_equal(runs[1][1].view(np.uint32), runs[4][1].view(np.uint32))
+    assert np.array_equal(runs[1][0].view(np.uint32), runs[4][0].view(np.uint32))
+    s = oracle_api.OracleScene()
+    scenes.mixed_small(s)
+    s.set_raytracer(False)
+    r = oracle_api.OracleRenderer(s, 40, 28)
+    r.render(0, 12, nthreads=0)
+    plain = r.accumulator()[..., :3] / 12
+    guided = runs[1][0][..., :3] / 12
+    fin = np.isfinite(plain) & np.isfinite(guided)
+    assert abs(guided[fin].mean() - plain[fin].mean()) <= 0.1 * plain[fin].mean()
+    r.close(); s.close()
+
+
 def test_primitive_vectors_have_hits():
     """The per-primitive golden vectors are only worth something if they exercise both outcomes."""
     for kind in ("triangle", "sphere", "plane", "disk"):
