@@ -16,7 +16,10 @@ For the traversal kernel k_extend (all timed variants summed) per step of the be
                       CU: every vector-memory instruction passes through) are busy, averaged over them / for the busiest
   ta_cycles_per_vmem_inst   TA_TA_BUSY_sum / SQ_INSTS_VMEM: addresser-busy cycles per vector-memory instruction
 The file is stamped with a hash of the kernel sources (csrc/); bench.py ignores it when the sources changed.
-Usage: valu_roofline.py <pmc_summary.json> <workload> <width> <height> <spp> <kernel_hash of the profiled run's bench line>"""
+One counter set per number of ranks: the file holds {"by_world": {"1": {...}, "2": {...}, ...}}; the set for N ranks is measured on
+ONE GPU with bench.py --emulate-world N (rank 0's rows of the N-rank shard), so that rank 0 of an N-GPU run is priced with the
+lane-ops of its own share.
+Usage: valu_roofline.py <pmc_summary.json> <workload> <width> <height> <spp> <kernel_hash of the profiled run's bench line> [world]"""
 import hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +36,8 @@ def kernel_hash():
 def main():
     src = sys.argv[1]
     d = json.load(open(src))
-    out = {"kernel_hash": kernel_hash(), "source": os.path.relpath(os.path.abspath(src), ROOT), "workload": [sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])],
+    world = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+    out = {"kernel_hash": kernel_hash(), "world": world, "source": os.path.relpath(os.path.abspath(src), ROOT), "workload": [sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])],
            "peak_lane_ops_per_s": PEAK_LANE_OPS, "kernels": {}}
     groups = {"k_extend": [k for k in d if k.startswith("k_extend")], "k_connect": [k for k in d if k.startswith("k_connect")],
               "k_shade": [k for k in d if k.startswith("k_shade")]}
@@ -69,7 +73,15 @@ def main():
         o["hbm_bytes_per_launch"] = int(o["hbm_bytes"] / launches)
         o["lane_ops_per_launch"] = o["lane_ops"] / launches
         out["kernels"][g] = o
-    json.dump(out, open(os.path.join(ROOT, "profiles", "roofline_pmc.json"), "w"), indent=1)
+    path = os.path.join(ROOT, "profiles", "roofline_pmc.json")
+    try:
+        allw = json.load(open(path))
+        if "by_world" not in allw:
+            allw = {"by_world": {}}
+    except Exception:
+        allw = {"by_world": {}}
+    allw["by_world"][str(world)] = out
+    json.dump(allw, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

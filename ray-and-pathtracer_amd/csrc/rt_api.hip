@@ -424,7 +424,9 @@ int rt_set_camera(rt_ctx* c, const rt_camera* cam)
 }
 
 // ---- scene upload: reference-shaped arrays -> HBM traversal layout ---------------------------------
-static void pack_prim(float* rec, const rt_blas& b, uint p, bool last)
+// matTypes: rt_material::type per material (null: none known); the type of the primitive's material rides in bits 4-5 of the
+// record's kind word, so that the kernel that resolves a hit knows what the hit means for the path without a second fetch
+static void pack_prim(float* rec, const rt_blas& b, uint p, bool last, const rt_material* mats = nullptr, uint nMats = 0)
 {
 	memset(rec, 0, 64);
 	int kind, obj, mat;
@@ -450,6 +452,7 @@ static void pack_prim(float* rec, const rt_blas& b, uint p, bool last)
 		kind = RT_KIND_PLANE, obj = q.obj_idx, mat = q.material;
 	}
 	int kl = kind | (last ? RT_LAST_BIT : 0);
+	if (mats && mat >= 0 && (uint)mat < nMats) kl |= (mats[mat].type & 3) << RT_TYPE_SHIFT;
 	memcpy(rec + 13, &obj, 4), memcpy(rec + 14, &mat, 4), memcpy(rec + 15, &kl, 4);
 }
 
@@ -527,7 +530,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		for (uint j = 0; j < b.n_prims; j++) {
 			const uint p = b.prim_idx[j];
 			if (p >= b.n_prims) return fail(c, RT_E_ARG, "rt_upload_scene: blas %u prim_idx[%u] = %u out of range", k, j, p);
-			pack_prim(&prims[(size_t)(primOff + j) * 16], b, p, last[j] != 0);
+			pack_prim(&prims[(size_t)(primOff + j) * 16], b, p, last[j] != 0, d->materials, d->n_materials);
 		}
 	}
 	// 4-wide nodes (rt_scene_dev.h, wide[]): collapse every BLAS; all or nothing (one flag for the kernels)
@@ -814,7 +817,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		fake.spheres = d->brute_spheres, fake.n_sph = d->n_brute_spheres, fake.planes = d->brute_planes, fake.n_pla = d->n_brute_planes;
 		const uint nb = fake.n_sph + fake.n_pla;
 		std::vector<float> brute((size_t)nb * 16 + 16);
-		for (uint j = 0; j < nb; j++) pack_prim(&brute[(size_t)j * 16], fake, j, true);
+		for (uint j = 0; j < nb; j++) pack_prim(&brute[(size_t)j * 16], fake, j, true, d->materials, d->n_materials);
 		HIPCHK(c, dalloc(c->sceneAllocs, &dp, brute.size()));
 		HIPCHK(c, hipMemcpy(dp, brute.data(), brute.size() * 4, hipMemcpyHostToDevice));
 		S.brute = (const float4*)dp;

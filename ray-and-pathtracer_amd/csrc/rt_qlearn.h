@@ -101,19 +101,25 @@ __device__ __forceinline__ void q_reward(const QTable& Q, uint key, float R)
 	atomicAdd((unsigned long long*)&Q.sum[key - 1], (unsigned long long)__float2ll_rn(R * 65536.0f));
 	atomicAdd(&Q.cnt[key - 1], 1u);
 }
-// expected reflected Q at a surface hit (the integral of eq. 8 over the 64 patches)
+// expected reflected Q at a surface hit (the integral of eq. 8 over the 64 patches).  A cell's row is 288 bytes, 16-byte aligned:
+// the values are fetched four at a time (16 loads instead of 64) and added in patch order all the same.
 __device__ __forceinline__ float q_expected(const QTable& Q, int cell, const f3& normal, float rho, bool diffuse)
 {
-	const float* row = Q.q + (size_t)cell * RT_Q_ROW;
+	const float4* row4 = (const float4*)(Q.q + (size_t)cell * RT_Q_ROW);
 	if (!diffuse) {
+		const float4 b0 = row4[0], b1 = row4[1];
 		float T = 0;
-		for (int i = 0; i < 8; i++) T = T + row[i];
+		T = T + b0.x, T = T + b0.y, T = T + b0.z, T = T + b0.w, T = T + b1.x, T = T + b1.y, T = T + b1.z, T = T + b1.w;
 		return rho * (T * (1.0f / 64));
 	}
 	float s = 0;
-	for (int p = 0; p < RT_Q_PATCHES; p++) {
-		const float c = dot(xyz(Q.centre[p]), normal);
-		s = s + row[8 + p] * t_fmaxf(0.f, c);
+#pragma unroll 4
+	for (int k = 0; k < RT_Q_PATCHES / 4; k++) {
+		const float4 v = row4[2 + k];
+		s = s + v.x * t_fmaxf(0.f, dot(xyz(Q.centre[4 * k]), normal));
+		s = s + v.y * t_fmaxf(0.f, dot(xyz(Q.centre[4 * k + 1]), normal));
+		s = s + v.z * t_fmaxf(0.f, dot(xyz(Q.centre[4 * k + 2]), normal));
+		s = s + v.w * t_fmaxf(0.f, dot(xyz(Q.centre[4 * k + 3]), normal));
 	}
 	return rho * (s * (1.0f / 16));
 }
@@ -121,9 +127,11 @@ __device__ __forceinline__ float q_expected(const QTable& Q, int cell, const f3&
 __device__ __forceinline__ f3 q_sample(const QTable& Q, int cell, uint& seed, float& P, int& patch)
 {
 	const float* row = Q.q + (size_t)cell * RT_Q_ROW;
-	float b[8];
+	const float4* row4 = (const float4*)row;
+	const float4 b0 = row4[0], b1 = row4[1];
+	const float b[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
 	float T = 0;
-	for (int i = 0; i < 8; i++) b[i] = row[i], T = T + b[i];
+	for (int i = 0; i < 8; i++) T = T + b[i];
 	const float uSel = RandomFloat(seed), uPick = RandomFloat(seed), u1 = RandomFloat(seed), u2 = RandomFloat(seed);
 	int i = 0, j = 0;
 	float qp;
@@ -140,13 +148,15 @@ __device__ __forceinline__ f3 q_sample(const QTable& Q, int cell, uint& seed, fl
 			acc = acc + b[i];
 		}
 		const float x2 = x - acc;
+		const float4 v0 = row4[2 + 2 * i], v1 = row4[3 + 2 * i]; // the band's eight values
+		const float v[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
 		float acc2 = 0;
 		for (j = 0; j < 7; j++) {
-			if (x2 < acc2 + row[8 + 8 * i + j]) break;
-			acc2 = acc2 + row[8 + 8 * i + j];
+			if (x2 < acc2 + v[j]) break;
+			acc2 = acc2 + v[j];
 		}
 		patch = 8 * i + j;
-		qp = row[8 + patch];
+		qp = v[j];
 	}
 	P = T > 0 ? (1 - Q.eps) * (qp / T) + Q.eps * (1.0f / 64) : 1.0f / 64;
 	return q_direction(i, j, u1, u2);

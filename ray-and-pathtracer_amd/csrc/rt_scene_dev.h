@@ -69,6 +69,7 @@ namespace rtd {
 #define RT_KIND_SPHERE 1
 #define RT_KIND_PLANE 2
 #define RT_LAST_BIT 4
+#define RT_TYPE_SHIFT 4 // bits 4-5 of a primitive record's kind word: rt_material::type of its material (0: unknown)
 #define RT_MAX_LIGHTS 8
 
 #define RT_BLOCK 256
@@ -1011,10 +1012,12 @@ __device__ __forceinline__ bool is_occluded_one(const DScene& S, const f3& O, co
 // normalize(TransformVector(N, matTransform)), bvhInstance.cpp:19).
 // 'ray' is called only for a sphere (it is the one primitive whose normal needs the ray), so a caller that
 // would have to fetch the ray from memory does not do so for the triangles, planes and lights.
+// matType: rt_material::type of the hit primitive's material as the record carries it (0 for a miss, a light, or unknown)
 template <class RayFn>
-__device__ __forceinline__ void resolve_hit_lazy(const DScene& S, const HitRef& hit, RayFn ray, int& objIdx, int& mat, f3& normal)
+__device__ __forceinline__ void resolve_hit_lazy(const DScene& S, const HitRef& hit, RayFn ray, int& objIdx, int& mat, f3& normal, int* matType = nullptr)
 {
 	objIdx = -1, mat = -1, normal = f3(0.0f);
+	if (matType) *matType = 0;
 	if (hit.kind < 0) return;
 	if (hit.kind == 2) {
 		const DLight& L = S.lights[hit.prim];
@@ -1025,6 +1028,7 @@ __device__ __forceinline__ void resolve_hit_lazy(const DScene& S, const HitRef& 
 	const float4 r0 = rec[0], r3 = rec[3];
 	objIdx = __float_as_int(r3.y), mat = __float_as_int(r3.z);
 	const int kind = __float_as_int(r3.w) & 3;
+	if (matType) *matType = (__float_as_int(r3.w) >> RT_TYPE_SHIFT) & 3;
 	if (kind == RT_KIND_TRI) {
 		const float4 r1 = rec[1], r2 = rec[2];
 		normal = f3(r0.w, r1.w, r2.w);
@@ -1038,9 +1042,9 @@ __device__ __forceinline__ void resolve_hit_lazy(const DScene& S, const HitRef& 
 		normal = xyz(r0);
 	}
 }
-__device__ __forceinline__ void resolve_hit(const DScene& S, const HitRef& hit, const f3& O, const f3& D, int& objIdx, int& mat, f3& normal)
+__device__ __forceinline__ void resolve_hit(const DScene& S, const HitRef& hit, const f3& O, const f3& D, int& objIdx, int& mat, f3& normal, int* matType = nullptr)
 {
-	resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = O, d = D; }, objIdx, mat, normal);
+	resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = O, d = D; }, objIdx, mat, normal, matType);
 }
 
 } // namespace rtd

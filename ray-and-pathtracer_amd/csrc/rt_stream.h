@@ -76,11 +76,12 @@ struct StreamState {
 };
 
 // what the hit decides about the path (path mode; 'last': the round whose hits are at depth 0, renderer.cpp:129)
-__device__ __forceinline__ int hit_class(const DScene& S, int objIdx, int mat, int last)
+// matType: the material type the primitive record carried (resolve_hit), 0 = look it up
+__device__ __forceinline__ int hit_class(const DScene& S, int objIdx, int mat, int last, int matType = 0)
 {
 	if (objIdx == -1) return 0;                                 // renderer.cpp:134
 	if (objIdx >= 11 && objIdx < 11 + S.nLights) return 0;      // :135-137
-	const int type = S.mats[mat].type;
+	const int type = matType ? matType : S.mats[mat].type;
 	const bool shadow = type != 3 && type != 2 && S.nLights > 0; // DIFFUSE: the light loop, :158-176
 	const bool cont = !last || shadow; // every material scatters one ray while depth lasts; in the last round a diffuse hit
 	                                   // still needs a continuation entry: light() finds the path's E and L there
@@ -127,8 +128,9 @@ __device__ __forceinline__ NewRay emit_ray_s(const DScene& S, const StreamState&
 	if (decide && ray_decided(S, O, D, rayT)) {
 		r.decided = true;
 		head.t = rayT;
-		resolve_hit(S, head, O, D, r.objIdx, r.mat, r.normal);
-		const int hc = hit_class(S, r.objIdx, r.mat, last);
+		int matType;
+		resolve_hit(S, head, O, D, r.objIdx, r.mat, r.normal, &matType);
+		const int hc = hit_class(S, r.objIdx, r.mat, last, matType);
 		// nothing hit, or a light: Sample() returns at renderer.cpp:134 / :135-137 (in the last round a glass or metal hit has class 0 too)
 		if (finishNoHit && (r.objIdx == -1 || (r.objIdx >= 11 && r.objIdx < 11 + S.nLights))) { r.cls = 0; return r; }
 		T.hitN[p][e] = mk4(r.normal, rayT);
@@ -249,14 +251,14 @@ struct StreamExtendPolicy {
 	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
 	{
 		const int e = (int)ld_stream(T.traceQ + work);
-		int objIdx, mat;
+		int objIdx, mat, matType;
 		f3 normal;
 		const StreamState& Tc = T;
 		const int par = parity;
-		resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = xyz(ld_stream(Tc.O[par] + e)), d = xyz(ld_stream(Tc.D[par] + e)); }, objIdx, mat, normal);
+		resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = xyz(ld_stream(Tc.O[par] + e)), d = xyz(ld_stream(Tc.D[par] + e)); }, objIdx, mat, normal, &matType);
 		st_stream(T.hitN[parity] + e, mk4(normal, hit.t));
 		st_stream(T.hitId[parity] + e, make_int2(objIdx, mat));
-		T.cls[parity][e] = (unsigned char)(CL_LIVE | CL_TRACE | hit_class(S, objIdx, mat, last));
+		T.cls[parity][e] = (unsigned char)(CL_LIVE | CL_TRACE | hit_class(S, objIdx, mat, last, matType)); // the record said what its material is: no second fetch
 	}
 };
 template <bool COUNT>
