@@ -180,11 +180,13 @@ def main():
     if rank == 0:
         sec_per_step = dt / args.steps
         value = W * H * spp / sec_per_step / 1e6
+        if args.emulate_world > 1:  # a profiling line: only rank 0's rows of the N-rank shard were rendered
+            value = W * shard.count * spp / sec_per_step / 1e6
         ext = prof["extend"]
         launches_per_step = ext["launches"] / args.steps
         avg_ms = ext["ms"] / max(1, ext["launches"])  # HIP events on the kernel's own stream, inside the timed steps
         out = {
-            "metric": "Mrays/s at %d×%d×%dspp" % (W, H, spp),
+            "metric": ("Mrays/s at %d×%d×%dspp" % (W, H, spp)) + (" (rank 0's rows of a %d-rank shard only: a profiling line)" % args.emulate_world if args.emulate_world > 1 else ""),
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -276,7 +278,7 @@ def roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, w
     khash = kernel_hash(build_info)
     if pj is not None and "by_world" in pj:  # one counter set per number of ranks (rank 0's rows of the N-rank shard, measured with --emulate-world N)
         pj = pj["by_world"].get(str(world))
-    usable = (pj is not None and pj.get("kernel_hash") == khash and
+    usable = (pj is not None and pj.get("kernel_hash") == khash and not args.qlearn and
               pj.get("workload") == [args.workload, W, H, spp] and pj.get("world", 1) == world)
     rb["pmc"] = {"file": "profiles/roofline_pmc.json", "used": bool(usable), "kernel_hash": khash,
                  "file_kernel_hash": pj.get("kernel_hash") if pj else None}

@@ -1633,6 +1633,9 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	for (int round = 0; round < rounds; round++) {
 		const int parity = round & 1, last = round + 1 == rounds ? 1 : 0, lastNext = round + 2 == rounds ? 1 : 0;
 		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
+#ifdef RT_TAIL_PROBE
+		tail_probe_reset(st);
+#endif
 		prof_begin(c, K_EXTEND, st);
 		if ((c->twoRays & 1) && c->S.stackRows2 > 0) {
 			if (c->counting) hipLaunchKernelGGL((k_extend_s2<true>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
@@ -1640,6 +1643,9 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		} else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		prof_end(c, st);
+#ifdef RT_TAIL_PROBE
+		tail_probe_print(st, "extend_s", round);
+#endif
 		hipLaunchKernelGGL(k_assign, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 		if (pendingJoin) { HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0)); pendingJoin = false; }
 		prof_begin(c, K_SHADE, st);
@@ -2256,9 +2262,10 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[512];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d wide=%d tlas_lds=%d stack_rows=%d slots=%d",
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d wide=%d wide8=%d mega=%d mega_path_max=%d two=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->S.wide ? 1 : 0, c->S.tlasLds, c->S.stackRows, slot_budget(c));
+	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaPathMax, c->twoRays, c->Qt.on,
+	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();
 }
