@@ -287,7 +287,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	memset(&c->S, 0, sizeof(c->S));
 	for (int k = 0; k < RT_MAX_POOLS; k++) memset(&c->pools[k].P, 0, sizeof(PathState)), memset(&c->pools[k].Q, 0, sizeof(Queues));
 	if (getenv("RT_POOLS")) c->nPoolsWanted = atoi(getenv("RT_POOLS"));
-	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0..2; anything else: the default
+	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 3 ? 2 : f); } // 0..3; anything else: the default
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
@@ -1618,10 +1618,14 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 {
 	const float t_min = 0.001f; // renderer.cpp:131
 	const int grid = c->gridBlocks;
-	// measured (profiles/r03_ab_stream_fuse.txt): the second stream pays below ~100 M samples per batch (the drains of the
-	// traversal launches are a larger share: 1/8 frame 9.41 -> 8.62 ms, half frame 27.1 -> 26.8) and costs above (full
-	// frame 49.9 -> 50.5 ms, config 5 2.45 -> 2.50 s: extend and connect want the same units); RT_FUSE = 0 / 2 forces
-	const bool twoStreams = c->fuseTraversal < 0 ? R.nSamples < 100000000u : c->fuseTraversal != 0;
+	// How connect(r) + light(r) share the machine with round r + 1 (profiles/r03_ab_stream_fuse.txt, r03_ab_gate.txt): one kernel at
+	// a time (RT_FUSE=0) pays every traversal launch's drain in full; both streams started together (RT_FUSE=2) make the two
+	// persistent kernels share the machine for their whole length (good below ~100 M samples per batch: 1/8 frame 9.85 -> 8.97 ms;
+	// bad above: full frame 50.82 -> 51.16); the default (RT_FUSE=3) holds the second stream at a gate that extend(r + 1) opens
+	// when its queue runs dry, so connect(r) fills that drain and nothing else: 8.92 / 26.68 / 50.52 ms at 1/8, 1/2 and the full frame,
+	// the best of the three at every size (by 0.3-1 %: a drain that shares the machine gets longer).
+	const bool twoStreams = c->fuseTraversal != 0;
+	const bool gated = twoStreams && (c->fuseTraversal < 0 || c->fuseTraversal == 3); // connect(r) + light(r) wait at a gate that extend(r + 1) opens when its queue runs dry
 	const StreamState& T = c->T;
 	hipStream_t st = c->stream, sb = twoStreams ? c->streamSide : c->stream;
 	const int cnt = c->counting ? 1 : 0;
@@ -1656,6 +1660,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 			HIPCHK(c, hipEventRecord(c->streamFork, st));
 			HIPCHK(c, hipStreamWaitEvent(sb, c->streamFork, 0));
 		}
+		if (gated && !last) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sb, T.counts); // opened by extend(round + 1), launched below on the main stream
 		prof_begin(c, K_CONNECT, sb);
 		launch_connect_s(c, sb, T, round, twoStreams ? c->streamSideSpill : c->spill, twoStreams ? c->sideSpill2 : c->spill2);
 		prof_end(c, sb);
@@ -1693,7 +1698,7 @@ static bool stream_eligible(const rt_ctx* c, int mode, size_t samples)
 static int fuse_mode(const rt_ctx* c, size_t samples)
 {
 	if (c->counting) return 0;
-	int m = c->fuseTraversal < 0 ? 2 : c->fuseTraversal;
+	int m = c->fuseTraversal < 0 || c->fuseTraversal > 2 ? 2 : c->fuseTraversal; // 3 (the gated second stream) exists in the dense pipeline only
 	// mode 1 indexes rays and shadow rays of a round in ONE int work list: slots * (lights + 1) must stay below 2^31
 	if (m == 1 && samples * (size_t)(c->S.nLights + 1) > (size_t)0x7FFFFFFF) m = 2;
 	return m;

@@ -357,6 +357,10 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // with the finished query's result (nearest: result.t / kind / prim / inst; any-hit: result.kind == 1 means occluded); true:
 // the lane goes on with the world-space ray (O, D, tmax, head candidate) as a nearest-hit or (nextAny) any-hit query of the
 // SAME work item; false: the work item is complete and the lane is free.  Needs MIXED (the lane's kind of query changes).
+// A policy with 'static constexpr bool kSignalsDry = true' is told once per wave when the wave finds the queue dry
+// (void queue_dry()): the dense pipeline's extend opens a gate for the kernel that is to fill its drain (rt_stream.h k_gate).
+template <class P, class = void> struct pol_signals { static constexpr bool value = false; };
+template <class P> struct pol_signals<P, decltype((void)P::kSignalsDry)> { static constexpr bool value = P::kSignalsDry; };
 template <class P, class = void> struct pol_advances { static constexpr bool value = false; };
 template <class P> struct pol_advances<P, decltype((void)P::kAdvance)> { static constexpr bool value = P::kAdvance; };
 
@@ -428,6 +432,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_STEP_COUNT
 	uint nsteps = 0, nenter = 0;
 #endif
+	bool signalled = false;  // pol.queue_dry() was called (policies with kSignalsDry)
 	int work = -1;           // queue entry this lane is tracing, -1 = idle
 	int chunkNext = 0, chunkEnd = 0; // wave-uniform: reserved, not yet handed out
 	// A short queue does not need the whole grid: a wave beyond one per RT_SHORT_QUEUE_RAYS entries (and beyond one per
@@ -615,6 +620,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_TAIL_PROBE
 		if (exhausted && !probed) { probed = true; if (lane == 0) atomicMin(&g_tailProbe[1], __builtin_amdgcn_s_memrealtime()); }
 #endif
+		if constexpr (pol_signals<Policy>::value) {
+			if (exhausted && !signalled) {
+				signalled = true;
+				if (lane == 0) pol.queue_dry();
+#ifdef RT_DRAIN_PRIO
+				__builtin_amdgcn_s_setprio(RT_DRAIN_PRIO); // the draining waves ahead of the kernel that fills the drain
+#endif
+			}
+		}
 		const bool stepping = (work >= 0 && link != RT_LINK_DONE) || b_live();
 		if (__ballot(stepping) == 0) {
 			if (exhausted && __ballot(work >= 0 || (TWO && bwork >= 0)) == 0) {

@@ -51,6 +51,7 @@ namespace rtd {
 #define SC_TRACE 7   // length of the traversal queue
 #define SC_LEFTOVER 8 // shadow rays the 4-wide walk handed back
 #define SC_DECIDED 9 // rays answered by their producer (counting launches)
+#define SC_GATE 10   // set by extend when its queue runs dry: k_gate lets connect of the round before start then
 
 struct StreamState {
 	float4* O[2];     // ray origin xyz, w = ray.t after the head tests        } entry e of round parity p
@@ -181,6 +182,20 @@ __device__ __forceinline__ void prepare_round(const StreamState& T, int next /* 
 	T.counts[SC_LEFTOVER] = 0;
 	for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
 }
+// The gate of the second stream (RT_FUSE=3): one wave waits until extend(r) has found its queue dry, then connect(r - 1) and
+// light(r - 1) -- queued behind this kernel -- fill the drain of extend(r): its longest rays finish alone for 0.5-0.9 ms whatever
+// the launch held, with the machine all but idle (profiles/r03_ab_stream_fuse.txt).  Started together (RT_FUSE=2) the two
+// persistent kernels share the machine for their whole length and both run longer; one after the other (RT_FUSE=0) every drain
+// is paid in full.  The wait is bounded (2 s of the 100 MHz clock): a launch that never opens the gate must not hang the stream.
+__global__ void k_gate(int* counts)
+{
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+	while (__hip_atomic_load(&counts[SC_GATE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+		__builtin_amdgcn_s_sleep(64);
+		if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+	}
+	__hip_atomic_store(&counts[SC_GATE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // connect's work heads alone: the leftover launch of the 4-wide walk goes through its own list with them
 __global__ void k_stream_begin(StreamState T)
 {
@@ -234,6 +249,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_s(DScene S, DCamera C, Re
 
 // extend: Scene::FindNearest for the entries of the traversal queue
 struct StreamExtendPolicy {
+	static constexpr bool kSignalsDry = true;
+	__device__ __forceinline__ void queue_dry() const { __hip_atomic_store(&T.counts[SC_GATE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 	const DScene& S;
 	const StreamState& T;
 	int parity, last;
