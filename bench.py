@@ -269,9 +269,9 @@ def roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, w
         pj = json.load(open(ppath))
     except Exception:
         pj = None
-    rb["note"] = ("batches below 100 M samples (and RT_FUSE=2) run connect(r) + light(r) on a second stream beside extend(r + 1): the kernel times of "
-                  "kernel_ms_per_step then overlap and do not add up to the step, and avg_launch_ms is the extend launches' own duration with that "
-                  "company (RT_FUSE=0: one kernel at a time)")
+    rb["note"] = ("batches below 100 M samples (and RT_FUSE=2 / 3) run connect(r) + light(r) on a second stream, held at a gate until extend(r + 1) has "
+                  "found its queue dry: the kernel times of kernel_ms_per_step then overlap and do not add up to the step, and avg_launch_ms is the "
+                  "extend launches' own duration with that company; batches of 100 M samples and more (the default workload) run one kernel at a time")
     # with N ranks the counter file is used when it was measured on this rank's share: the row shard renders H / N rows of every
     # frame, the counter file of the 1-GPU share ("--spp S/N": the same number of samples per rank) is the closest committed
     # stand-in and is NOT used -- frac stays null unless a file for exactly [workload, W, H, spp, world] exists

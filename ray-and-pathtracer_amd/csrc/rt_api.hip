@@ -1623,8 +1623,10 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	// persistent kernels share the machine for their whole length (good below ~100 M samples per batch: 1/8 frame 9.85 -> 8.97 ms;
 	// bad above: full frame 50.82 -> 51.16); the default (RT_FUSE=3) holds the second stream at a gate that extend(r + 1) opens
 	// when its queue runs dry, so connect(r) fills that drain and nothing else: 8.92 / 26.68 / 50.52 ms at 1/8, 1/2 and the full frame,
-	// the best of the three at every size (by 0.3-1 %: a drain that shares the machine gets longer).
-	const bool twoStreams = c->fuseTraversal != 0;
+	// the best of the three at every size (by 0.3-1 %: a drain that shares the machine gets longer).  Default: the gate below 100 M
+	// samples per batch; above, one kernel at a time -- 0.6 % slower there, but every kernel's time and counters are its own, which
+	// is what the roofline block of the bench line is made of.
+	const bool twoStreams = c->fuseTraversal < 0 ? R.nSamples < 100000000u : c->fuseTraversal != 0;
 	const bool gated = twoStreams && (c->fuseTraversal < 0 || c->fuseTraversal == 3); // connect(r) + light(r) wait at a gate that extend(r + 1) opens when its queue runs dry
 	const StreamState& T = c->T;
 	hipStream_t st = c->stream, sb = twoStreams ? c->streamSide : c->stream;
