@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--qlearn", type=int, default=0, metavar="FRAMES", help="Q-learning guided sampling (rt_qlearn_*, Dahm & Keller 2017; the reference has no code for it: "
                     "PARITY UNPINNED): the step renders its spp in batches of FRAMES frames and folds the rewards into the table between them "
                     "(with N ranks the integer reward sums are all-reduced first, so every rank learns the same table)")
+    ap.add_argument("--qlearn-mask", type=int, default=3, help="rt_qlearn_params::learn_mask: 3 = every fourth sample pays rewards (all samples pick guided), 0 = all")
     ap.add_argument("--emulate-world", type=int, default=0, help="profiling on ONE GPU: render only the rows rank 0 of an N-rank run renders "
                     "(no process group, no gather): the counters of that share are what rank 0 of the N-GPU run is priced with")
     args = ap.parse_args()
@@ -121,7 +122,7 @@ def main():
             dpar.render_step(r, acc, mode, 0, spp, shard, host_staging)
             return
         # every step learns from scratch, so that the K timed steps do the same work
-        r.qlearn_enable(16, qbox[0], qbox[1], 0.3, 0.2, 1.0)
+        r.qlearn_enable(16, qbox[0], qbox[1], 0.3, 0.2, 1.0, args.qlearn_mask)
         first, stride, count = shard.rows()
         for f0 in range(0, spp, args.qlearn):
             r.render_rows(mode, f0, min(args.qlearn, spp - f0), first, stride, count)
@@ -193,7 +194,7 @@ def main():
             "config": {"workload": "%s: %s, %dx%d, %d spp, path integrator" % (args.workload, cfg["name"], W, H, spp),
                        "parallelism": "row-interleaved pixel shard x%d + accumulator gather to rank 0" % world,
                        "sampler": ("Q-learning guided indirect bounce (Dahm & Keller 2017; no reference code: PARITY UNPINNED), 16^3 cells x 64 patches, "
-                                   "table updated every %d frames" % args.qlearn) if args.qlearn else "uniform hemisphere (renderer.cpp:181)",
+                                   "table updated every %d frames, rewards from samples with stream state & %d == 0" % (args.qlearn, args.qlearn_mask)) if args.qlearn else "uniform hemisphere (renderer.cpp:181)",
                        "rays_definition": "value counts primary pixel samples (reference's Mrays/s, renderer.cpp:300); all_rays counts every FindNearest + IsOccluded query"},
             "all_rays_mrays_per_s": round(rays_all / sec_per_step / 1e6, 3),
             "rays_per_step": {"nearest": int(cnt[0].item()), "occluded": int(cnt[1].item())},

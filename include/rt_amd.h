@@ -222,7 +222,13 @@ int rt_trace_batch_energy(rt_ctx* ctx, int mode, int n, const float* O, const fl
  * rt_qlearn_get_sums / rt_qlearn_set_sums: the pending rewards (int64 sums in 48.16 fixed point, uint32 counts, grid^3 * 64
  *   each) -- with several ranks the sums are all-reduced between the ranks before every rank applies them.
  * rt_qlearn_get_table: Q as grid^3 * 64 floats (cell-major, patch = 8 * band + sector). */
-typedef struct { int32_t grid; float lo[3], hi[3]; float alpha, epsilon, q_init; } rt_qlearn_params;
+typedef struct {
+	int32_t grid; float lo[3], hi[3]; float alpha, epsilon, q_init;
+	/* learn_mask: a sample pays rewards iff (the state of its random stream after the pixel jitter) & learn_mask == 0 -- 0: every
+	 * sample learns; 3: every fourth one (a surface hit's reward reads 64 table values: the picks stay guided for all samples,
+	 * the table is taught by a fixed, scheduling-independent quarter of them) */
+	uint32_t learn_mask;
+} rt_qlearn_params;
 int rt_qlearn_enable(rt_ctx* ctx, const rt_qlearn_params* params);
 int rt_qlearn_apply(rt_ctx* ctx);
 int rt_qlearn_get_sums(rt_ctx* ctx, int64_t* sums_out, uint32_t* counts_out);

@@ -269,12 +269,12 @@ class OracleRenderer:
         return out
 
     # ---- Q-learning guided sampler (orc_qlearn.h; no reference code: parity unpinned) ----
-    def qlearn_enable(self, grid, lo, hi, alpha=0.3, epsilon=0.2, q_init=1.0):
+    def qlearn_enable(self, grid, lo, hi, alpha=0.3, epsilon=0.2, q_init=1.0, learn_mask=0):
         self._qgrid = grid
-        self.L.orc_qlearn_enable(self.h, grid, _f3(lo), _f3(hi), C.c_float(alpha), C.c_float(epsilon), C.c_float(q_init))
+        self.L.orc_qlearn_enable(self.h, grid, _f3(lo), _f3(hi), C.c_float(alpha), C.c_float(epsilon), C.c_float(q_init), C.c_uint(learn_mask))
 
     def qlearn_disable(self):
-        self.L.orc_qlearn_enable(self.h, 0, _f3((0, 0, 0)), _f3((1, 1, 1)), C.c_float(1), C.c_float(0), C.c_float(1))
+        self.L.orc_qlearn_enable(self.h, 0, _f3((0, 0, 0)), _f3((1, 1, 1)), C.c_float(1), C.c_float(0), C.c_float(1), C.c_uint(0))
 
     def qlearn_apply(self):
         self.L.orc_qlearn_apply(self.h)

@@ -343,11 +343,11 @@ int orc_render(void* h, unsigned frame0, int nframes, unsigned seedBase, int y0,
 	return 0;
 }
 // Q-learning guided sampler (orc_qlearn.h): grid == 0 switches it off
-void orc_qlearn_enable(void* h, int grid, const float* lo, const float* hi, float alpha, float eps, float qInit)
+void orc_qlearn_enable(void* h, int grid, const float* lo, const float* hi, float alpha, float eps, float qInit, unsigned learnMask)
 {
 	QLearn& q = ((OrcRenderer*)h)->r.ql;
 	if (grid <= 0) { q = QLearn(); return; }
-	q.enable(grid, lo, hi, alpha, eps, qInit);
+	q.enable(grid, lo, hi, alpha, eps, qInit, learnMask);
 }
 void orc_qlearn_apply(void* h) { ((OrcRenderer*)h)->r.ql.apply(); }
 void orc_qlearn_get(void* h, long long* sums, unsigned* counts, float* table)

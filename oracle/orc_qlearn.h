@@ -19,6 +19,7 @@ struct QLearn {
 	int grid = 0;
 	float lo[3] = { 0, 0, 0 }, inv[3] = { 0, 0, 0 };
 	float eps = 0, alpha = 0, qMin = 1e-4f;
+	uint learnMask = 0;          // a sample pays rewards iff (its stream's state after the pixel jitter) & learnMask == 0
 	std::vector<float> q;        // [cells][72]: 8 band sums, then 64 values
 	std::vector<long long> sum;  // [cells][64]
 	std::vector<uint> cnt;       // [cells][64]
@@ -41,9 +42,9 @@ struct QLearn {
 			row[i] = b;
 		}
 	}
-	void enable(int g, const float* l, const float* h, float a, float e, float qInit)
+	void enable(int g, const float* l, const float* h, float a, float e, float qInit, uint mask = 0)
 	{
-		on = true, grid = g, alpha = a, eps = e;
+		on = true, grid = g, alpha = a, eps = e, learnMask = mask;
 		for (int k = 0; k < 3; k++) lo[k] = l[k], inv[k] = (float)g / (h[k] - l[k]);
 		const size_t cells = (size_t)g * g * g;
 		q.assign(cells * 72, 0.0f), sum.assign(cells * 64, 0), cnt.assign(cells * 64, 0);

@@ -179,8 +179,8 @@ struct Renderer {
 	}
 
 	// Renderer::Sample (:128-236)
-	// prevKey (Q-learning only): 1 + cell * 64 + patch of the scattering that sent this ray, 0 for none
-	float3 Sample(Ray& ray, int depth, float3 energy, uint& seed, Counters& cnt, uint prevKey = 0) const
+	// Q-learning only: prevKey = 1 + cell * 64 + patch of the scattering that sent this ray, 0 for none; learner = this sample pays rewards
+	float3 Sample(Ray& ray, int depth, float3 energy, uint& seed, Counters& cnt, uint prevKey = 0, bool learner = false) const
 	{
 		const Scene& sc = *scene;
 		if (depth < 0) return float3(0.05f);
@@ -243,9 +243,9 @@ struct Renderer {
 				if (c > 0) {
 					float3 cos_i = float3(c);
 					Ray next(intersectionPoint, d);
-					indirectLightning += m.col * cos_i * Sample(next, depth - 1, energy, seed, cnt, 1u + (uint)cell * 64 + (uint)patch);
+					indirectLightning += m.col * cos_i * Sample(next, depth - 1, energy, seed, cnt, learner ? 1u + (uint)cell * 64 + (uint)patch : 0u, learner);
 					fq = 1.0f / (16.0f * P);
-				} else ql.reward(1u + (uint)cell * 64 + (uint)patch, 0.0f); // below the surface: nothing to trace, the patch learns 0
+				} else if (learner) ql.reward(1u + (uint)cell * 64 + (uint)patch, 0.0f); // below the surface: nothing to trace, the patch learns 0
 				totCol = (directLightning * INVPI + fq * indirectLightning) * m.albedo;
 				break;
 			}
@@ -262,7 +262,7 @@ struct Renderer {
 		}
 		case METAL: { // :192-197
 			Ray reflected = metal_scatter(ray, normal);
-			totCol += m.col * Sample(reflected, depth - 1, energy, seed, cnt);
+			totCol += m.col * Sample(reflected, depth - 1, energy, seed, cnt, 0, learner);
 			break;
 		}
 		case GLASS: { // :198-233
@@ -284,13 +284,13 @@ struct Renderer {
 				float3 refractionRayOrig = outside ? ray.IntersectionPoint() - bias : ray.IntersectionPoint() + bias;
 				Ray refrRay(refractionRayOrig, refractionDirection);
 				float3 tempCol = m.col * energy;
-				refractionColor = tempCol * Sample(refrRay, depth - 1, energy, seed, cnt);
+				refractionColor = tempCol * Sample(refrRay, depth - 1, energy, seed, cnt, 0, learner);
 				totCol += refractionColor * (1 - kr);
 			} else {
 				float3 reflectionDirection = normalize(reflect(ray.D, norm));
 				float3 reflectionRayOrig = outside ? ray.IntersectionPoint() + bias : ray.IntersectionPoint() - bias;
 				Ray reflRay(reflectionRayOrig, reflectionDirection);
-				float3 reflectionColor = m.col * Sample(reflRay, depth - 1, energy, seed, cnt);
+				float3 reflectionColor = m.col * Sample(reflRay, depth - 1, energy, seed, cnt, 0, learner);
 				totCol += reflectionColor * kr;
 			}
 			break;
@@ -318,7 +318,7 @@ struct Renderer {
 			float newY = y + (RandomFloat(seed) * 2 - 1);
 			Ray pr = camera.GetPrimaryRay((int)newX, (int)newY); // Q11: jitter truncated by the int parameters
 			float3 totCol = float3(0);
-			totCol += Sample(pr, 4, float3(1), seed, cnt);
+			totCol += Sample(pr, 4, float3(1), seed, cnt, 0, ql.on && (seed & ql.learnMask) == 0);
 			float r = x_powf(totCol.x * 1, GAMMA); // Q12: gamma per sample, before accumulation
 			float g = x_powf(totCol.y * 1, GAMMA);
 			float b = x_powf(totCol.z * 1, GAMMA);

@@ -2208,7 +2208,7 @@ int rt_qlearn_enable(rt_ctx* c, const rt_qlearn_params* p)
 	HIPCHK(c, dalloc(c->qAllocs, &centre, (size_t)RT_Q_PATCHES));
 	Q.centre = centre, Q.grid = p->grid, Q.on = 1;
 	for (int a = 0; a < 3; a++) Q.lo[a] = p->lo[a], Q.inv[a] = (float)p->grid / (p->hi[a] - p->lo[a]);
-	Q.eps = p->epsilon, Q.alpha = p->alpha, Q.qMin = 1e-4f;
+	Q.eps = p->epsilon, Q.alpha = p->alpha, Q.qMin = 1e-4f, Q.learnMask = p->learn_mask;
 	const int threads = (int)std::max(cells, (size_t)RT_Q_PATCHES);
 	hipLaunchKernelGGL(k_q_init, dim3((threads + 255) / 256), dim3(256), 0, c->stream, Q, p->q_init, centre);
 	HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -36,7 +36,9 @@ struct QTable {
 	int grid, on;
 	float lo[3], inv[3]; // cell = (int)((x - lo) * inv), clamped
 	float eps, alpha, qMin;
+	uint learnMask;      // a sample pays rewards iff (its stream's state after the pixel jitter) & learnMask == 0
 };
+#define RT_Q_LEARNER 0x80000000u // bit of an entry's key word (W.w): this sample pays rewards
 
 __device__ __forceinline__ float q_lum(const f3& c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
 __device__ __forceinline__ int q_cell(const QTable& Q, const f3& x)

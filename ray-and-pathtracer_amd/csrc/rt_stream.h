@@ -491,7 +491,10 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 			f3 nO(0.0f), nD(0.0f), nW(0.0f);
 			uint nextKey = 0;       // QL: (cell, patch) + 1 of the ray this hit scatters
 			bool deadSample = false; // QL: the guided direction points below the surface: nothing to trace
-			const uint prevKey = QL ? __float_as_uint(w4.w) : 0u;
+			// QL: the key word travels in W.w: bits 0-30 the (cell, patch) + 1 that sent this ray, bit 31 "this sample pays rewards"
+			const uint keyWord = QL ? (fresh ? (((__float_as_uint(e4.w) & Qt.learnMask) == 0) ? RT_Q_LEARNER : 0u) : __float_as_uint(w4.w)) : 0u;
+			const bool learner = (keyWord & RT_Q_LEARNER) != 0;
+			const uint prevKey = learner ? (keyWord & ~RT_Q_LEARNER) : 0u;
 
 			if (id.x == -1) {
 				const f3 sky = sky_color(S, D);
@@ -559,10 +562,10 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 						if (c > 0) {
 							const f3 cos_i(c);
 							nW = W * (((1.0f / (16.0f * P)) * (col * cos_i)) * albedo); // 1 / (pi pdf) in the place of the uniform hemisphere's 2
-							nextKey = 1u + (uint)cell * RT_Q_PATCHES + (uint)patch;
+							nextKey = learner ? 1u + (uint)cell * RT_Q_PATCHES + (uint)patch : 0u;
 						} else {
 							deadSample = true; // below the surface: the patch learns a reward of 0, the path carries no weight on
-							q_reward(Qt, 1u + (uint)cell * RT_Q_PATCHES + (uint)patch, 0.0f);
+							if (learner) q_reward(Qt, 1u + (uint)cell * RT_Q_PATCHES + (uint)patch, 0.0f);
 						}
 					} else {
 						const f3 rayToHemi = RandomInHemisphere(seed, normal);
@@ -593,7 +596,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 					T.cls[pout][p.x] = CL_LIVE;
 				} else if (!segmentEnds) {
 					const NewRay nr = emit_ray_s(S, T, pout, p.x, nO, nD, mode_t_min(1), lastNext, false, decide != 0);
-					T.W[pout][p.x] = mk4(nW, __uint_as_float(nextKey));
+					T.W[pout][p.x] = mk4(nW, __uint_as_float(nextKey | (keyWord & RT_Q_LEARNER)));
 					T.cls[pout][p.x] = nr.cls;
 					nDecided += nr.decided ? 1u : 0u;
 				}

@@ -371,6 +371,7 @@ public:
 	void DisableQLearning();
 	bool qlearning = false;
 	int qgrid = 0;
+	uint32_t qlearnMask = 0;          // rt_qlearn_params::learn_mask for the next EnableQLearning (0: every sample pays rewards)
 	float4* accumulator = nullptr; // host copy, refreshed by Tick
 	uint32_t* screenPixels = nullptr; // Surface::pixels analogue (template/precomp.h:134)
 	Scene scene;

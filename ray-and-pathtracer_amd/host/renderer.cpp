@@ -142,7 +142,7 @@ void Renderer::EnableQLearning(int grid, float3 lo, float3 hi, float alpha, floa
 {
 	if (!ctx) Init();
 	rt_qlearn_params p;
-	p.grid = grid, p.alpha = alpha, p.epsilon = epsilon, p.q_init = qInit;
+	p.grid = grid, p.alpha = alpha, p.epsilon = epsilon, p.q_init = qInit, p.learn_mask = qlearnMask;
 	p.lo[0] = lo.x, p.lo[1] = lo.y, p.lo[2] = lo.z, p.hi[0] = hi.x, p.hi[1] = hi.y, p.hi[2] = hi.z;
 	for (rt_ctx* k : ctxs) check(k, rt_qlearn_enable(k, &p));
 	qlearning = true, qgrid = grid;

@@ -30,7 +30,7 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
 
 
 class RtQlearnParams(C.Structure):
-    _fields_ = [("grid", C.c_int32), ("lo", C.c_float * 3), ("hi", C.c_float * 3), ("alpha", C.c_float), ("epsilon", C.c_float), ("q_init", C.c_float)]
+    _fields_ = [("grid", C.c_int32), ("lo", C.c_float * 3), ("hi", C.c_float * 3), ("alpha", C.c_float), ("epsilon", C.c_float), ("q_init", C.c_float), ("learn_mask", C.c_uint32)]
 
 
 class RtCamera(C.Structure):
@@ -517,8 +517,8 @@ class HostRenderer:
         return dict(zip(COUNTER_NAMES, [int(x) for x in a])), dict(zip(COUNTER_NAMES, [int(x) for x in b]))
 
     # ---- Q-learning guided sampler (include/rt_amd.h rt_qlearn_*; no reference code: parity unpinned) ----
-    def qlearn_enable(self, grid, lo, hi, alpha=0.3, epsilon=0.2, q_init=1.0):
-        p = RtQlearnParams(grid, (C.c_float * 3)(*lo), (C.c_float * 3)(*hi), alpha, epsilon, q_init)
+    def qlearn_enable(self, grid, lo, hi, alpha=0.3, epsilon=0.2, q_init=1.0, learn_mask=0):
+        p = RtQlearnParams(grid, (C.c_float * 3)(*lo), (C.c_float * 3)(*hi), alpha, epsilon, q_init, learn_mask)
         self._qgrid = grid
         self._rt(self.rt.rt_qlearn_enable(self.ctx, C.byref(p)))
 

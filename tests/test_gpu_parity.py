@@ -1083,7 +1083,8 @@ def test_whitted_single_launch_equals_rounds(name, kw, w, h, scenes, oracle_api,
 
 @pytest.mark.parametrize("name,kw,w,h,box", [("mixed_small", {}, 64, 40, ((-4, -1, -4), (4, 5, 6))), ("pretty_tlas", {"n_instances": 4}, 96, 54, ((-6, -1.5, -1), (8, 5, 10))),
                                              ("tlas_test2", {}, 64, 40, ((-6, -1, -2), (6, 7, 8)))])
-def test_qlearning_sampler(name, kw, w, h, box, scenes, oracle_api, host_api):
+@pytest.mark.parametrize("mask", [0, 3])
+def test_qlearning_sampler(name, kw, w, h, box, mask, scenes, oracle_api, host_api):
     """SURVEY.md 8f N4 / BASELINE config 5 "Q-learning sampler on": Dahm & Keller's guided sampling of the indirect bounce
     (csrc/rt_qlearn.h, rt_qlearn_*).  The reference snapshot holds no code for it (F2), so this is PARITY UNPINNED: the device
     is held against the oracle's statement of the same scheme (oracle/orc_qlearn.h) -- after every batch the pending reward
@@ -1095,8 +1096,9 @@ def test_qlearning_sampler(name, kw, w, h, box, scenes, oracle_api, host_api):
     orr.scene.set_raytracer(False)
     r.clear(); r.render(host_api.RT_MODE_PATH, 0, 24)
     plain = r.accumulator()[..., :3] / 24
-    orr.qlearn_enable(8, box[0], box[1], 0.3, 0.2, 1.0)
-    r.qlearn_enable(8, box[0], box[1], 0.3, 0.2, 1.0)
+    # mask 3: every fourth sample (by the state of its random stream) pays rewards, all samples pick guided
+    orr.qlearn_enable(8, box[0], box[1], 0.3, 0.2, 1.0, mask)
+    r.qlearn_enable(8, box[0], box[1], 0.3, 0.2, 1.0, mask)
     orr.clear(); r.clear()
     frames = 3
     for b in range(5):
