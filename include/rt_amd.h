@@ -136,7 +136,7 @@ const char* rt_last_error(const rt_ctx* ctx);
 /* ---- scene / camera -------------------------------------------------------------------------- */
 /* Copies the scene into HBM in the traversal layout.  Replaces the pointers Scene keeps to
  * bvh / tlas / bvhInstance / primitive vectors (template/scene.h:1371-1378).
- * RT_E_UNSUPPORTED: more than 8 lights, or a TLAS with more than 256 instances. */
+ * RT_E_UNSUPPORTED: more than 32 lights, or a TLAS with more than 256 instances. */
 int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* desc);
 int rt_set_camera(rt_ctx* ctx, const rt_camera* cam);
 /* Scene::SetTime(t) with animation on (template/scene.h:1228-1244): every triangle of the scene BVH

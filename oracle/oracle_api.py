@@ -279,6 +279,10 @@ class OracleRenderer:
     def qlearn_apply(self):
         self.L.orc_qlearn_apply(self.h)
 
+    def qlearn_set_sums(self, sums, cnts):
+        sums, cnts = np.ascontiguousarray(sums, np.int64), np.ascontiguousarray(cnts, np.uint32)
+        self.L.orc_qlearn_set(self.h, _p(sums), _p(cnts))
+
     def qlearn_state(self):
         """(sums int64, counts uint32, table float32), each [grid^3, 64]"""
         n = self._qgrid ** 3

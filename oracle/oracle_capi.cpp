@@ -358,6 +358,13 @@ void orc_qlearn_get(void* h, long long* sums, unsigned* counts, float* table)
 	if (counts) memcpy(counts, q.cnt.data(), cells * 64 * 4);
 	if (table) for (size_t c = 0; c < cells; c++) memcpy(table + c * 64, &q.q[c * 72 + 8], 64 * 4);
 }
+void orc_qlearn_set(void* h, const long long* sums, const unsigned* counts)
+{
+	QLearn& q = ((OrcRenderer*)h)->r.ql;
+	const size_t cells = (size_t)q.grid * q.grid * q.grid;
+	memcpy(q.sum.data(), sums, cells * 64 * 8);
+	memcpy(q.cnt.data(), counts, cells * 64 * 4);
+}
 // Renderer::Tick: one frame with the reference's iteration bookkeeping; *camChanged in/out
 int orc_tick(void* h, int* camChanged, unsigned frame, unsigned seedBase, int nthreads, unsigned* pixels)
 {

@@ -1797,7 +1797,7 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		}
 		if (mode == RT_MODE_PATH && c->Qt.on && !stream_eligible(c, mode, total))
 			return fail(c, RT_E_UNSUPPORTED, "rt_render: the Q-learning sampler needs a path batch with an entry per sample (within the slot budget, no RT_COUNT_REFERENCE)");
-		if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && !c->Qt.on && total <= (size_t)c->megaPathMax))) {
+		if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && !c->Qt.on && c->S.nLights <= 8 && total <= (size_t)c->megaPathMax))) {
 			rc = run_mega(c, R);
 			if (rc != RT_OK) return rc;
 			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
@@ -1872,7 +1872,7 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 	if (mode == RT_MODE_PATH && c->pathUnsupported) {
 		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
 		rc = check_overflow(c);
-	} else if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && !c->Qt.on && n <= c->megaPathMax))) {
+	} else if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && !c->Qt.on && c->S.nLights <= 8 && n <= c->megaPathMax))) {
 		rc = run_mega(c, R);
 	} else if (stream_eligible(c, mode, (size_t)n)) {
 		rc = ensure_stream_state(c, n);

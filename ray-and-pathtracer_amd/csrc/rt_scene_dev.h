@@ -70,7 +70,7 @@ namespace rtd {
 #define RT_KIND_PLANE 2
 #define RT_LAST_BIT 4
 #define RT_TYPE_SHIFT 4 // bits 4-5 of a primitive record's kind word: rt_material::type of its material (0: unknown)
-#define RT_MAX_LIGHTS 8
+#define RT_MAX_LIGHTS 32 // per-light planes of the path state are sized by the scene's own count; this bounds memory, nothing else
 
 #define RT_BLOCK 256
 // A traversal block's LDS (trace_persistent): 23,040 bytes, seven blocks = 28 waves per CU of the 160 KB.  Three parts,

@@ -62,6 +62,67 @@ def test_row_shard_gather_equals_single_process(world, h, tmp_path, scenes, orac
     assert np.array_equal(got.view(np.uint32), r.accumulator().view(np.uint32))
 
 
+def _qlearn_worker(rank, world, port, w, h, batches, frames, out_path):
+    sys.path.insert(0, ROOT)
+    import importlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dpar = importlib.import_module("ray-and-pathtracer_amd.distributed")
+    scenes = importlib.import_module("ray-and-pathtracer_amd.scenes")
+    from oracle import oracle_api as oa
+    s = oa.OracleScene()
+    scenes.mixed_small(s)
+    s.set_raytracer(False)
+    r = oa.OracleRenderer(s, w, h)
+    r.qlearn_enable(6, (-4, -1, -4), (4, 5, 6), 0.3, 0.2, 1.0, 1)
+    first, stride, count = dpar.shard_rows(h, rank, world)
+    for b in range(batches):
+        for k in range(count):
+            y = first + k * stride
+            r.render(b * frames, frames, y0=y, y1=y + 1)
+        # the rule of DESIGN.md finding 49: the table is read-only inside a batch; the ranks' integer reward sums are added (any
+        # order: integers), every rank applies the total
+        sums, cnts, _ = r.qlearn_state()
+        ts, tc = torch.from_numpy(sums), torch.from_numpy(cnts.astype(np.int64))
+        dist.all_reduce(ts), dist.all_reduce(tc)
+        r.qlearn_set_sums(ts.numpy(), tc.numpy().astype(np.uint32))
+        r.qlearn_apply()
+    acc = torch.from_numpy(r.accumulator())
+    dpar.gather_rows(acc, rank, world, 0)
+    tab = torch.from_numpy(r.qlearn_state()[2].copy())
+    tabs = [torch.empty_like(tab) for _ in range(world)] if rank == 0 else None
+    dist.gather(tab, tabs, dst=0)
+    if rank == 0:
+        for t in tabs:
+            assert torch.equal(t.view(torch.int32), tab.view(torch.int32))  # every rank learned the same table
+        np.save(out_path, acc.numpy())
+        np.save(out_path + ".tab.npy", tab.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 14), (3, 13)])
+def test_qlearning_is_independent_of_the_shard(world, h, tmp_path, scenes, oracle_api):
+    """The Q-learning sampler under a row shard (the oracle's statement of it; the product follows the same rule in bench.py
+    --qlearn and rapt::Renderer::Tick): every rank renders its rows from the same table, the integer reward sums are all-reduced,
+    every rank applies the total.  Frames and table must equal the single-process run bit for bit, batch after batch."""
+    w, batches, frames = 20, 3, 2
+    out = str(tmp_path / "acc.npy")
+    mp.spawn(_qlearn_worker, args=(world, _free_port(), w, h, batches, frames, out), nprocs=world, join=True)
+    got, got_tab = np.load(out), np.load(out + ".tab.npy")
+    s = oracle_api.OracleScene()
+    scenes.mixed_small(s)
+    s.set_raytracer(False)
+    r = oracle_api.OracleRenderer(s, w, h)
+    r.qlearn_enable(6, (-4, -1, -4), (4, 5, 6), 0.3, 0.2, 1.0, 1)
+    for b in range(batches):
+        r.render(b * frames, frames)
+        r.qlearn_apply()
+    assert np.array_equal(got_tab.view(np.uint32), r.qlearn_state()[2].view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), r.accumulator().view(np.uint32))
+
+
 class _RowPainter:
     """Stands where host_api.HostRenderer stands in distributed.render_step (the code bench.py runs per step): checks the
     row arguments exactly as rt_render_rows does (csrc/rt_api.hip: row_first >= 0, row_stride >= 1, row_count >= 1,

@@ -573,13 +573,13 @@ def test_full_size_properties(config, scenes, oracle_api, host_api):
 
 
 def test_limits_are_reported(scenes, oracle_api, host_api):
-    """Device-path limits surface as errors, never as silent fallbacks: > 8 lights, and rendering
+    """Device-path limits surface as errors, never as silent fallbacks: > 32 lights, and rendering
     rows outside the image."""
     r = host_api.HostRenderer(16, 8)
     s = r.scene
     m = s.diffuse(0.8, (1, 1, 1))
     s.plane(0, m, (0, 1, 0), 0)
-    for i in range(9):
+    for i in range(33):
         s.area_light(11 + i, (i, 5, 0), 10.0, (1, 1, 1), 1.0, (0, -1, 0))
     s.build(0)
     with pytest.raises(RuntimeError, match="lights"):
@@ -592,6 +592,39 @@ def test_limits_are_reported(scenes, oracle_api, host_api):
         r.render(host_api.RT_MODE_PATH, 0, 1, y0=4, y1=12)
     with pytest.raises(RuntimeError):
         r.render(host_api.RT_MODE_WHITTED, 0, 2)  # Whitted frames overwrite: one at a time
+    r.close()
+
+
+def _many_lights(b, n=12):
+    """a floor, a diffuse and a glass sphere, a metal mesh, n area lights on a ring (more than the 8 the device path stopped at before round 3)"""
+    import math
+    fl = b.diffuse(0.8, (1, 1, 1), 0.0, 1.0, 4)
+    df = b.diffuse(0.8, (0.2, 0.9, 0.3), 0.6, 0.4, 10)
+    gl = b.glass(1.5, (0.8, 0.9, 1.0))
+    me = b.metal(0.7, (1.0, 0.8, 0.3))
+    for i in range(n):
+        a = 2 * math.pi * i / n
+        b.area_light(11 + i, (2.5 * math.cos(a), 3.0 + 0.1 * i, 1.0 + 2.5 * math.sin(a)), 3.0, (1.0, 0.9 - 0.03 * i, 0.7 + 0.02 * i), 0.6, (0, -1, 0))
+    b.sphere(1, df, (0.4, 0.5, 1.2), 0.5)
+    b.sphere(2, gl, (-0.8, 0.4, 0.6), 0.4)
+    b.mesh_obj(3, assets_mod.obj_path("ico"), me, (1.3, 0.6, 0.4), 0.5)
+    b.plane(0, fl, (0, 1, 0), 0)
+    b.build(0)
+    return dict(name="many_lights", tlas=False)
+
+
+def test_more_than_eight_lights(scenes, oracle_api, host_api):
+    """The reference holds its lights in a vector without a bound (template/scene.h:1374); the device path sizes the per-light planes
+    of its path state by the scene's count.  Twelve lights: primary hits, Whitted and path frames against the oracle."""
+    global assets_mod
+    import importlib
+    assets_mod = importlib.import_module("ray-and-pathtracer_amd.assets")
+    o, orr, r, d = make_pair(_many_lights, oracle_api, host_api, 80, 48)
+    obj_ref, t_ref, _ = orr.primary_hits(1e-6)
+    obj, t = r.primary_hits(1e-6)
+    assert np.array_equal(obj, obj_ref) and np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    check_frames(orr, r, "whitted", 1, host_api)
+    check_frames(orr, r, "path", 6, host_api)
     r.close()
 
 
@@ -1082,7 +1115,8 @@ def test_whitted_single_launch_equals_rounds(name, kw, w, h, scenes, oracle_api,
 
 
 @pytest.mark.parametrize("name,kw,w,h,box", [("mixed_small", {}, 64, 40, ((-4, -1, -4), (4, 5, 6))), ("pretty_tlas", {"n_instances": 4}, 96, 54, ((-6, -1.5, -1), (8, 5, 10))),
-                                             ("tlas_test2", {}, 64, 40, ((-6, -1, -2), (6, 7, 8)))])
+                                             ("tlas_test2", {}, 64, 40, ((-6, -1, -2), (6, 7, 8))),
+                                             ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 96, 54, ((-12, -2, -8), (12, 10, 16)))])  # BASELINE config 5's layout ("Q-learning sampler on")
 @pytest.mark.parametrize("mask", [0, 3])
 def test_qlearning_sampler(name, kw, w, h, box, mask, scenes, oracle_api, host_api):
     """SURVEY.md 8f N4 / BASELINE config 5 "Q-learning sampler on": Dahm & Keller's guided sampling of the indirect bounce
