@@ -92,6 +92,7 @@ struct rt_ctx {
 	int shadeLds = 1;        // RT_SHADE_LDS: the shading kernels keep the material / brute-force primitive tables in LDS
 	int gridShadeS = 0, gridLightS = 0; // resident blocks of the grid-stride shading kernels (a second, partial round of blocks would run at low occupancy)
 	int decideRays = 1;      // RT_DECIDE: producers answer rays whose first traversal step leaves nothing to visit (rt_stream.h ray_decided)
+	int gridTraverseS = 0;
 	int gridExtendS = 0, gridConnectS = 0, gridConnectWideS = 0, gridLeftoverS = 0, gridConnectWide8S = 0;
 	int nPoolsWanted = 1; // RT_POOLS; measured: 2 pools overlap their kernels but do not shorten the frame
 	hipEvent_t fork = nullptr;
@@ -287,7 +288,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	memset(&c->S, 0, sizeof(c->S));
 	for (int k = 0; k < RT_MAX_POOLS; k++) memset(&c->pools[k].P, 0, sizeof(PathState)), memset(&c->pools[k].Q, 0, sizeof(Queues));
 	if (getenv("RT_POOLS")) c->nPoolsWanted = atoi(getenv("RT_POOLS"));
-	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 3 ? 2 : f); } // 0..3; anything else: the default
+	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 3 ? 2 : f); } // 0..3 (dense pipeline: 1 = one traversal launch per round); anything else: the default
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
@@ -323,6 +324,7 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridConnectWideS = resident((const void*)k_connect_s<false, true>);
 		c->gridLeftoverS = std::min(resident((const void*)k_connect_s<false, false, true>), prop.multiProcessorCount);
 		c->gridConnectWide8S = resident((const void*)k_connect_s<false, false, false, true>);
+		c->gridTraverseS = resident((const void*)k_traverse_s);
 		c->gridExtendS2 = std::min(resident((const void*)k_extend_s2<false>), resident((const void*)k_extend_s2<true>));
 		c->gridConnectS2 = std::min(resident((const void*)k_connect_s2<false>), resident((const void*)k_connect_s2<true>));
 		c->gridMega = resident((const void*)k_whitted_mega);
@@ -1626,7 +1628,13 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	// the best of the three at every size (by 0.3-1 %: a drain that shares the machine gets longer).  Default: the gate below 100 M
 	// samples per batch; above, one kernel at a time -- 0.6 % slower there, but every kernel's time and counters are its own, which
 	// is what the roofline block of the bench line is made of.
-	const bool twoStreams = c->fuseTraversal < 0 ? R.nSamples < 100000000u : c->fuseTraversal != 0;
+	// Small batches (RT_FUSE=1; default below RT_MIXED_MAX samples): extend(r) and connect(r - 1) as ONE launch (k_traverse_s), one drain
+	// per round instead of two.
+	// Measured (profiles/r03_ab_one_launch_per_round.txt, 1080p x spp): 1: 3.73 -> 3.24 ms, 2: 4.50 -> 4.18, 4: 6.10 -> 6.02, 8: 9.00 -> 9.08, 16: 14.8 -> 15.8.
+	const unsigned mixedMax = getenv("RT_MIXED_MAX") ? (unsigned)atol(getenv("RT_MIXED_MAX")) : 10000000u;
+	const bool mixed = !c->counting && !c->twoRays && (c->fuseTraversal == 1 || (c->fuseTraversal < 0 && R.nSamples < mixedMax)) &&
+	                   (unsigned long long)R.nSamples * (unsigned)(c->S.nLights + 1) < 0x7FFFFFFFull;
+	const bool twoStreams = !mixed && (c->fuseTraversal < 0 ? R.nSamples < 100000000u : c->fuseTraversal != 0);
 	const bool gated = twoStreams && (c->fuseTraversal < 0 || c->fuseTraversal == 3); // connect(r) + light(r) wait at a gate that extend(r + 1) opens when its queue runs dry
 	const StreamState& T = c->T;
 	hipStream_t st = c->stream, sb = twoStreams ? c->streamSide : c->stream;
@@ -1643,7 +1651,8 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		tail_probe_reset(st);
 #endif
 		prof_begin(c, K_EXTEND, st);
-		if ((c->twoRays & 1) && c->S.stackRows2 > 0) {
+		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill);
+		else if ((c->twoRays & 1) && c->S.stackRows2 > 0) {
 			if (c->counting) hipLaunchKernelGGL((k_extend_s2<true>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
 			else hipLaunchKernelGGL((k_extend_s2<false>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
 		} else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
@@ -1652,12 +1661,18 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 #ifdef RT_TAIL_PROBE
 		tail_probe_print(st, "extend_s", round);
 #endif
+		if (mixed && round > 0) { // the shadow answers of the round before came with this round's hits
+			prof_begin(c, K_SHADE, st);
+			hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, st, c->S, R, T, round - 1, 0, c->shadeLds);
+			prof_end(c, st);
+		}
 		hipLaunchKernelGGL(k_assign, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 		if (pendingJoin) { HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0)); pendingJoin = false; }
 		prof_begin(c, K_SHADE, st);
 		if (c->Qt.on) hipLaunchKernelGGL(k_shade_s<true>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt, c->Qt);
 		else hipLaunchKernelGGL(k_shade_s<false>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt, c->Qt);
 		prof_end(c, st);
+		if (mixed && !last) continue; // this round's shadow rays ride in the next round's traversal launch
 		if (twoStreams) {
 			HIPCHK(c, hipEventRecord(c->streamFork, st));
 			HIPCHK(c, hipStreamWaitEvent(sb, c->streamFork, 0));

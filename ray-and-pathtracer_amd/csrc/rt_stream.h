@@ -662,6 +662,36 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_connect_s2(DScene S,
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
+// traverse: extend of round r and connect of round r - 1 as ONE persistent launch over one work list (RT_FUSE=1): items
+// [0, nTrace) are the traversal queue's rays (nearest hit: the long ones start first), the rest the shadow rays of the round
+// before, light-major.  A lane's kind of query follows its work item (trace_persistent MIXED).  One launch has one drain where
+// two have two, which is most of what a small batch's traversal costs (profiles/r03_ab_stream_fuse.txt: at the 1/8 frame an
+// extend launch is busy 0.2-0.8 ms and drains for 0.5-0.7); at large batches waves that mix the two kinds cost more than the
+// drains return (DESIGN.md finding 19), so this is the small batches' round loop.
+struct StreamTraversePolicy {
+	StreamExtendPolicy ext;
+	StreamConnectPolicy con;
+	int nTrace;
+	__device__ __forceinline__ bool any_of(int work) const { return work >= nTrace; }
+	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
+	{
+		if (work < nTrace) return ext.load(work, O, D, tmax, head);
+		return con.load(work - nTrace, O, D, tmax, head);
+	}
+	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& O, const f3& D) const { ext.store(work, hit, O, D); }
+	__device__ __forceinline__ void store(int work, bool occluded) const { con.store(work - nTrace, occluded); }
+};
+__global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DScene S, StreamState T, int round, int last, float t_min, int refillMin, uint* spill)
+{
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	const int nTrace = T.counts[SC_TRACE], nShadow = T.counts[SC_SHADOW + (round + 2) % 3]; // the shadow records of round - 1
+	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG] }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] }, nTrace };
+	trace_persistent<false, false, false, StreamTraversePolicy, true>(S, pol, nTrace + nShadow * S.nLights, T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+}
+
 // light: the direct-light terms of a diffuse hit, in light order (renderer.cpp:158-176: occlusion test first, scatter
 // only when visible), added to the radiance of the path's continuation entry; in the last round the sample is complete.
 __global__ void RT_LIGHT_BOUNDS k_light_s(DScene S0, RenderParams R, StreamState T, int round, int last, int ldsTables)
