@@ -80,6 +80,13 @@ struct rt_ctx {
 	MegaState M;
 	std::vector<void*> megaAllocs;
 	int megaLanes = 0, gridMega = 0, gridMegaPath = 0;
+	// longest first (rt_mega.h): per-sample cost of the last Whitted launch and the tile order made from it
+	std::vector<void*> megaOrderAllocs;
+	uint* megaCost = nullptr; uint* megaOrder = nullptr; uint* megaHist = nullptr;
+	size_t megaCostCap = 0;
+	unsigned megaCostSamples = 0, megaCostFirst = 0; // the batch megaCost describes (0 samples: nothing yet)
+	int megaLpt = 1;         // RT_MEGA_LPT: 0 keeps the multiplicative permutation
+	int megaDecide = 0;      // RT_MEGA_DECIDE: the flush answers queries that need no walk (measured: level, the launch is as long as its longest pixel)
 	int megaPathMax = 0;     // RT_MEGA_PATH_MAX: path batches up to this many samples run as one launch too (k_path_mega).  Off: measured slower than
 	                         // the five rounds of rt_stream.h at every size (1080p x 1: 3.33 against 3.01 ms, x 2: 4.92 / 3.88; profiles/r03_tick_time.txt)
 	int useMega = 1;         // RT_MEGA: 1 Whitted frames as one launch (default), 0 the wavefront rounds of rt_kernels.h
@@ -292,6 +299,8 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
+	if (getenv("RT_MEGA_LPT")) c->megaLpt = atoi(getenv("RT_MEGA_LPT")) != 0;
+	if (getenv("RT_MEGA_DECIDE")) c->megaDecide = atoi(getenv("RT_MEGA_DECIDE")) != 0;
 	if (getenv("RT_MEGA_PATH_MAX")) c->megaPathMax = atoi(getenv("RT_MEGA_PATH_MAX"));
 	memset(&c->M, 0, sizeof(c->M));
 	memset(&c->Qt, 0, sizeof(c->Qt));
@@ -395,6 +404,7 @@ void rt_destroy(rt_ctx* c)
 	}
 	free_pool(c->streamAllocs);
 	free_pool(c->megaAllocs);
+	free_pool(c->megaOrderAllocs);
 	free_pool(c->qAllocs);
 	if (c->spill2) (void)hipFree(c->spill2);
 	if (c->sideSpill2) (void)hipFree(c->sideSpill2);
@@ -1528,12 +1538,47 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 	int grid = ((int)R.nSamples + RT_SHORT_QUEUE_RAYS * 64 - 1) / (RT_SHORT_QUEUE_RAYS * 64) + 1; // a short queue does not need the whole grid
 	if (grid > gridMax) grid = gridMax;
 	(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
+	// longest first (rt_mega.h): a Whitted launch over the samples the last one rendered deals its tiles out by what they cost then
+	MegaState M = c->M;
+	M.cost = nullptr, M.order = nullptr;
+	M.nWork = (int)(((R.nSamples + (1u << R.permShift) - 1) >> R.permShift) << R.permShift);
+	if (c->megaLpt && R.mode == RT_MODE_WHITTED && R.permMul && !R.customO) {
+		const unsigned tilesPerHead = RT_HEADS * 8u; // sub-queues of n / RT_HEADS entries, a multiple of 64 entries = 8 tiles of 8
+		const unsigned nTiles = (R.nSamples + (1u << R.permShift) - 1) >> R.permShift;
+		const unsigned unit = tilesPerHead * (64u >> R.permShift ? 64u >> R.permShift : 1u) / 8u;
+		const unsigned nTilesPad = (nTiles + unit - 1) / unit * unit;
+		if (c->megaCostCap < (size_t)R.nSamples) {
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			free_pool(c->megaOrderAllocs);
+			c->megaCostCap = 0, c->megaCostSamples = 0;
+			HIPCHK(c, dalloc(c->megaOrderAllocs, &c->megaCost, (size_t)R.nSamples));
+			HIPCHK(c, dalloc(c->megaOrderAllocs, &c->megaOrder, (size_t)nTilesPad + 1024));
+			HIPCHK(c, dalloc(c->megaOrderAllocs, &c->megaHist, (size_t)2 * RT_MEGA_BUCKETS));
+			c->megaCostCap = (size_t)R.nSamples;
+		}
+		if (c->megaCostSamples == R.nSamples && c->megaCostFirst == R.sampleFirst) {
+			(void)hipMemsetAsync(c->megaHist, 0, 2 * RT_MEGA_BUCKETS * sizeof(uint), c->stream);
+			const unsigned blocks = (nTilesPad + RT_MEGA_ORDER_BLOCK - 1) / RT_MEGA_ORDER_BLOCK;
+			hipLaunchKernelGGL(k_mega_hist, dim3(blocks), dim3(RT_MEGA_ORDER_BLOCK), 0, c->stream, c->megaCost, R.permShift, R.nSamples, nTilesPad, c->megaHist);
+			hipLaunchKernelGGL(k_mega_order, dim3(blocks), dim3(RT_MEGA_ORDER_BLOCK), 0, c->stream, c->megaCost, R.permShift, R.nSamples, nTilesPad, c->megaHist, c->megaOrder);
+			M.order = c->megaOrder;
+			M.nWork = (int)(nTilesPad << R.permShift);
+		}
+		M.cost = c->megaCost;
+		c->megaCostSamples = R.nSamples, c->megaCostFirst = R.sampleFirst;
+	}
+#ifdef RT_TAIL_PROBE
+	tail_probe_reset(c->stream);
+#endif
 	prof_begin(c, K_EXTEND);
 	// a flush runs the body of Trace for the lanes that finished a query: it waits for more of them than a plain store does (RT_REFILL_MEGA, 32: 5.0 -> 4.85 ms)
 	const int refillMega = getenv("RT_REFILL_MEGA") && atoi(getenv("RT_REFILL_MEGA")) > 0 && atoi(getenv("RT_REFILL_MEGA")) <= 64 ? atoi(getenv("RT_REFILL_MEGA")) : 32;
-	if (R.mode == RT_MODE_WHITTED) hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
-	else hipLaunchKernelGGL(k_path_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
+	if (R.mode == RT_MODE_WHITTED) hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->megaDecide, c->spill, c->flags);
+	else hipLaunchKernelGGL(k_path_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
 	prof_end(c);
+#ifdef RT_TAIL_PROBE
+	tail_probe_print(c->stream, "mega", 0);
+#endif
 	int f = 0;
 	HIPCHK(c, hipMemcpyAsync(c->hostCounts, c->flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -11,6 +11,7 @@
 // wavefront kernels add it (shade: sky / light; light: W * direct after the light loop), so the frame is theirs bit for bit.
 #pragma once
 #include "rt_kernels.h"
+#include "rt_stream.h" // ray_decided
 
 namespace rtd {
 
@@ -26,7 +27,73 @@ struct MegaState { // [field][lane of the grid]
 	float4* hS;  //   direct light so far xyz
 	float4* pend; // [lane][RT_PEND_CAP][4] {O,depth} {D,-} {W,-} {E,-}
 	int lanes;
+	// longest first (k_mega_hist / k_mega_order below): how long a lane held each sample of the batch (s_memrealtime ticks, 10 ns),
+	// written when the sample is stored, and the order the NEXT launch over the same samples deals its tiles out in
+	uint* cost;        // [sample of the batch]; null: not recorded
+	const uint* order; // [tile position] -> tile; null: the multiplicative permutation
+	int nWork;         // work items of the launch (tile positions << permShift)
 };
+
+// ---- longest first ---------------------------------------------------------------------------------------------------
+// A launch ends when its longest pixel does: on the instanced glass / metal scene the queue is dry after 0.85 ms and the last
+// lane leaves 4.4 ms later (profiles/r03_mega_tail.txt) -- the tree of ONE glass pixel, walked by one lane, whenever it
+// started.  An interactive loop renders the same pixels Tick after Tick, so the time a lane held a pixel in the last Tick says
+// how long it will hold it in this one: tiles are dealt out by descending cost, round robin over the traversal's RT_HEADS
+// sub-queues, so the long trees start at time 0 and the queue ends with sky.  Any order gives the same frame (a pixel's value
+// does not depend on when it is traced); the order inside a cost class is whatever the atomics make it.
+#define RT_MEGA_BUCKETS 64
+#define RT_MEGA_ORDER_BLOCK 1024
+__device__ __forceinline__ int mega_bucket(const uint* cost, uint tile, uint shift, uint nSamples)
+{
+	uint c = 0;
+	for (uint k = 0; k < (1u << shift); k++) {
+		const uint w = (tile << shift) + k;
+		if (w < nSamples) c += cost[w];
+	}
+	if (c == 0) return RT_MEGA_BUCKETS - 1; // nothing known, or a tile beyond the last sample
+	const int e = 31 - __clz((int)c);
+	const int k = 4 * e + (e >= 2 ? (int)((c >> (e - 2)) & 3) : 0); // quarter octaves
+	const int b = 95 - k;
+	return b < 0 ? 0 : (b > RT_MEGA_BUCKETS - 1 ? RT_MEGA_BUCKETS - 1 : b); // class 0: the most expensive tiles
+}
+__global__ void __launch_bounds__(RT_MEGA_ORDER_BLOCK) k_mega_hist(const uint* cost, uint shift, uint nSamples, uint nTilesPad, uint* hist)
+{
+	__shared__ uint h[RT_MEGA_BUCKETS];
+	if (threadIdx.x < RT_MEGA_BUCKETS) h[threadIdx.x] = 0;
+	__syncthreads();
+	const uint t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < nTilesPad) atomicAdd(&h[mega_bucket(cost, t, shift, nSamples)], 1u);
+	__syncthreads();
+	if (threadIdx.x < RT_MEGA_BUCKETS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// hist[0 .. 64): tiles per class; hist[64 .. 128): tiles of the class placed so far.  nTilesPad is a multiple of RT_HEADS * 8, so
+// that the traversal's sub-queues (trace_persistent: n / RT_HEADS entries each, a multiple of 64) are equally long.
+__global__ void __launch_bounds__(RT_MEGA_ORDER_BLOCK) k_mega_order(const uint* cost, uint shift, uint nSamples, uint nTilesPad, uint* hist, uint* order)
+{
+	__shared__ uint h[RT_MEGA_BUCKETS], base[RT_MEGA_BUCKETS];
+	if (threadIdx.x < RT_MEGA_BUCKETS) h[threadIdx.x] = 0;
+	__syncthreads();
+	const uint t = blockIdx.x * blockDim.x + threadIdx.x;
+	int b = 0;
+	uint mine = 0;
+	if (t < nTilesPad) b = mega_bucket(cost, t, shift, nSamples), mine = atomicAdd(&h[b], 1u);
+	__syncthreads();
+	if (threadIdx.x < RT_MEGA_BUCKETS) {
+		uint before = 0;
+		for (int k = 0; k < (int)threadIdx.x; k++) before += hist[k];
+		base[threadIdx.x] = before + (h[threadIdx.x] ? atomicAdd(&hist[RT_MEGA_BUCKETS + threadIdx.x], h[threadIdx.x]) : 0u);
+	}
+	__syncthreads();
+	if (t < nTilesPad) {
+		// groups of eight tiles (64 pixels: what a wave takes at a time), one tile of every eighth of the cost ranking in each,
+		// every eighth in descending order along the queue: the longest trees start first, and no wave is full of them -- such a
+		// wave waits at every flush for half of its lanes to finish their queries (measured: packed by cost, the Tick takes twice
+		// as long as unsorted)
+		const uint rank = base[b] + mine, groups = nTilesPad / 8;
+		const uint r = rank % groups, slot = rank / groups;
+		order[8 * ((r % RT_HEADS) * (groups / RT_HEADS) + r / RT_HEADS) + slot] = t;
+	}
+}
 
 struct WhittedMegaPolicy {
 	static constexpr bool kAdvance = true;
@@ -36,6 +103,8 @@ struct WhittedMegaPolicy {
 	const MegaState& M;
 	int gl;     // this lane's column in M
 	int* flag;
+	int decide; // queries whose first traversal step leaves nothing to visit are answered in the flush (ray_decided)
+	mutable bool startsDone = false; // the work item just loaded is such a query
 
 	__device__ __forceinline__ bool any_of(int) const { return false; } // a pixel starts with Scene::FindNearest
 	// Work item -> sample.  Consecutive work items are handed to the lanes of one wave, and a pixel's cost is its tree: 1 segment
@@ -48,7 +117,8 @@ struct WhittedMegaPolicy {
 	__device__ __forceinline__ bool sample_of(int work, uint& sid) const
 	{
 		uint w = (uint)work;
-		if (R.permMul) {
+		if (M.order) w = (M.order[w >> R.permShift] << R.permShift) + (w & ((1u << R.permShift) - 1));
+		else if (R.permMul) {
 			const uint sh = R.permShift, nTiles = (R.nSamples + (1u << sh) - 1) >> sh;
 			w = ((uint)(((unsigned long long)(w >> sh) * R.permMul) % nTiles) << sh) + (w & ((1u << sh) - 1));
 		}
@@ -80,10 +150,12 @@ struct WhittedMegaPolicy {
 		}
 		M.W[gl] = make_float4(1, 1, 1, __int_as_float(start_depth(R)));
 		M.E[gl] = mk4(E, __int_as_float(0));
-		M.L[gl] = make_float4(0, 0, 0, 0);
+		M.L[gl] = make_float4(0, 0, 0, __uint_as_float((uint)__builtin_amdgcn_s_memrealtime())); // w: when the lane took the sample
 		new_segment(O, D, tmax, head);
+		startsDone = decide && ray_decided(S, O, D, tmax); // a pixel of the sky or the floor: straight to the flush, see advance()
 		return true;
 	}
+	__device__ __forceinline__ bool starts_done() const { return startsDone; }
 	__device__ __forceinline__ void push(int& np, const f3& O, const f3& D, const f3& W, const f3& E, int depth) const
 	{
 		if (np >= RT_PEND_CAP) { *flag = 2; return; }
@@ -110,7 +182,7 @@ struct WhittedMegaPolicy {
 		O = I + dir * 1e-4f, D = dir, tmax = sqrtf(len2), nextAny = true;
 		return true;
 	}
-	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
+	__device__ __forceinline__ bool advance_once(int work, bool wasAny, const HitRef& res, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
 	{
 		const float4 w4 = M.W[gl], e4 = M.E[gl], l4 = M.L[gl];
 		f3 W = xyz(w4), E = xyz(e4), Lsum = xyz(l4);
@@ -169,14 +241,14 @@ struct WhittedMegaPolicy {
 					if (childTraces) segmentEnds = false;
 				} else if (S.nLights > 0) { // DIFFUSE, renderer.cpp:87-122: the light loop, one shadow query at a time
 					M.hI[gl] = mk4(I, __int_as_float(matId));
-					M.L[gl] = mk4(Lsum, 0.0f);
+					M.L[gl] = mk4(Lsum, l4.w);
 					if (light_step(0, I, normal, rayD, m, E, np, f3(0.0f), O, D, tmax, nextAny)) return true;
 				}
 			}
 			if (!segmentEnds) {
 				M.W[gl] = mk4(nW, __int_as_float(nDepth));
 				M.E[gl] = mk4(E, __int_as_float(np));
-				M.L[gl] = mk4(Lsum, 0.0f);
+				M.L[gl] = mk4(Lsum, l4.w);
 				O = nO, D = nD;
 				new_segment(O, D, tmax, head);
 				return true;
@@ -204,7 +276,7 @@ struct WhittedMegaPolicy {
 			const float4 o = pe[0], d = pe[1], w = pe[2], en = pe[3];
 			M.W[gl] = make_float4(w.x, w.y, w.z, o.w);
 			M.E[gl] = make_float4(en.x, en.y, en.z, __int_as_float(np));
-			M.L[gl] = mk4(Lsum, 0.0f);
+			M.L[gl] = mk4(Lsum, l4.w);
 			O = xyz(o), D = xyz(d);
 			new_segment(O, D, tmax, head);
 			return true;
@@ -212,7 +284,23 @@ struct WhittedMegaPolicy {
 		uint sid;
 		sample_of(work, sid);
 		store_sample(R, sid, Lsum);
+		if (M.cost) M.cost[sid - R.sampleFirst] = (uint)__builtin_amdgcn_s_memrealtime() - __float_as_uint(l4.w);
 		return false;
+	}
+	// The flush: the body of Trace for the query that ended -- and for every further query of the pixel that its producer can
+	// answer itself, because the first traversal step (the root pair's boxes, in TLAS mode the reach boxes) would leave it nothing
+	// to visit: the result is then what the head tests left (nearest hit) or "visible" (shadow query), exactly what the walk
+	// returns after that step (ray_decided, rt_stream.h).  A floor pixel -- primary ray, one shadow query per light -- or a
+	// reflection into the sky never enters the walk; a lane leaves the flush with a query that needs the walk, or free.
+	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res0, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
+	{
+		HitRef res = res0;
+		for (;;) {
+			if (!advance_once(work, wasAny, res, O, D, tmax, head, nextAny)) return false;
+			if (!decide || !ray_decided(S, O, D, tmax)) return true;
+			wasAny = nextAny, res = head, res.t = tmax;
+			head.kind = -1, head.prim = 0, head.inst = -1;
+		}
 	}
 };
 
@@ -401,14 +489,14 @@ struct PathMegaPolicy {
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 4 // measured: 3 waves (no spill) and 5 are slower, profiles/r03_tick_mega.txt
 #endif
-__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, uint* spill, int* work)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, int decide, uint* spill, int* work)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	WhittedMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1] };
-	trace_persistent<false, false, false, WhittedMegaPolicy, true>(S, pol, (int)(((R.nSamples + (1u << R.permShift) - 1) >> R.permShift) << R.permShift), work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	WhittedMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], decide };
+	trace_persistent<false, false, false, WhittedMegaPolicy, true>(S, pol, M.nWork, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 }
 
 __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_path_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, uint* spill, int* work)
@@ -418,7 +506,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_path_mega(DScene S,
 	lc.clear();
 	uint rays = 0;
 	PathMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1] };
-	trace_persistent<false, false, false, PathMegaPolicy, true>(S, pol, (int)(((R.nSamples + (1u << R.permShift) - 1) >> R.permShift) << R.permShift), work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, false, false, PathMegaPolicy, true>(S, pol, M.nWork, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 }
 
 } // namespace rtd

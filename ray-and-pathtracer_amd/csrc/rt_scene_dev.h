@@ -357,10 +357,14 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // with the finished query's result (nearest: result.t / kind / prim / inst; any-hit: result.kind == 1 means occluded); true:
 // the lane goes on with the world-space ray (O, D, tmax, head candidate) as a nearest-hit or (nextAny) any-hit query of the
 // SAME work item; false: the work item is complete and the lane is free.  Needs MIXED (the lane's kind of query changes).
+// Such a policy may also offer 'bool starts_done()': true after load() means the query just loaded needs no walk (its result is
+// what load() left in the head candidate) and goes to the next flush as it is.
 // A policy with 'static constexpr bool kSignalsDry = true' is told once per wave when the wave finds the queue dry
 // (void queue_dry()): the dense pipeline's extend opens a gate for the kernel that is to fill its drain (rt_stream.h k_gate).
 template <class P, class = void> struct pol_signals { static constexpr bool value = false; };
 template <class P> struct pol_signals<P, decltype((void)P::kSignalsDry)> { static constexpr bool value = P::kSignalsDry; };
+template <class P, class = void> struct pol_starts_done { static constexpr bool value = false; };
+template <class P> struct pol_starts_done<P, decltype((void)&P::starts_done)> { static constexpr bool value = true; };
 template <class P, class = void> struct pol_advances { static constexpr bool value = false; };
 template <class P> struct pol_advances<P, decltype((void)P::kAdvance)> { static constexpr bool value = P::kAdvance; };
 
@@ -607,6 +611,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 							clean = ray_is_clean(O, D, rD);
 							link = ANYWIDE && !S.useTLAS ? (WIDE8 ? S.rootWide8 : S.rootWide) : S.rootLink;
 							if (link == RT_EMPTY) link = RT_LINK_DONE;
+							if constexpr (pol_starts_done<Policy>::value) { if (pol.starts_done()) link = RT_LINK_DONE; } // the policy answered the query itself
 							rays++;
 							if constexpr (ANYWIDE) { if (!clean) { pol.leftover(mine); work = -1; } } // the binary walk answers this one
 						}

@@ -1114,6 +1114,47 @@ def test_whitted_single_launch_equals_rounds(name, kw, w, h, scenes, oracle_api,
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("name,kw,w,h", [("mixed_small", {}, 200, 83), ("pretty_tlas", {"n_instances": 4}, 192, 108)])
+def test_whitted_longest_first_order(name, kw, w, h, scenes, oracle_api, host_api, monkeypatch):
+    """The single-launch Whitted frame deals its pixels out by what they cost in the launch before (csrc/rt_mega.h "longest
+    first": k_mega_hist / k_mega_order; frames of 16384 samples and more).  Any order must give the same frame: the first
+    launch (no history: the multiplicative permutation), the second and third (history), row shards with their own histories,
+    RT_MEGA_LPT=0 and the wavefront rounds (RT_MEGA=0) all leave the same accumulator bits.  200 x 83 is not a multiple of the
+    8-pixel tile nor of the padded queue."""
+    frames = {}
+    for key, env in (("rounds", {"RT_MEGA": "0"}), ("plain", {"RT_MEGA_LPT": "0"}), ("lpt", {}), ("lpt_decide", {"RT_MEGA_DECIDE": "1"})):
+        for k in ("RT_MEGA", "RT_MEGA_LPT", "RT_MEGA_DECIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = host_api.HostRenderer(w, h)
+        d = scenes.REGISTRY[name](r.scene, **kw)
+        r.commit()
+        if "camera" in d:
+            c = d["camera"]
+            r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+        got = []
+        for _ in range(3):
+            r.clear()
+            r.render(host_api.RT_MODE_WHITTED, 0, 1)
+            got.append(r.accumulator().copy())
+        for _ in range(2):  # shards: each call has another sample range, the history follows the last one
+            r.clear()
+            r.render_rows(host_api.RT_MODE_WHITTED, 0, 1, 0, 1, h // 2)
+            r.render_rows(host_api.RT_MODE_WHITTED, 0, 1, h // 2, 1, h - h // 2)
+            got.append(r.accumulator().copy())
+        for _ in range(2):  # the same shard twice in a row: its history is used
+            r.clear()
+            r.render_rows(host_api.RT_MODE_WHITTED, 0, 1, 0, 1, h)
+            got.append(r.accumulator().copy())
+        r.close()
+        for g in got[1:]:
+            assert np.array_equal(g.view(np.uint32), got[0].view(np.uint32)), key
+        frames[key] = got[0]
+    for key in ("plain", "lpt", "lpt_decide"):
+        assert np.array_equal(frames[key].view(np.uint32), frames["rounds"].view(np.uint32)), key
+
+
 @pytest.mark.parametrize("name,kw,w,h,box", [("mixed_small", {}, 64, 40, ((-4, -1, -4), (4, 5, 6))), ("pretty_tlas", {"n_instances": 4}, 96, 54, ((-6, -1.5, -1), (8, 5, 10))),
                                              ("tlas_test2", {}, 64, 40, ((-6, -1, -2), (6, 7, 8))),
                                              ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 96, 54, ((-12, -2, -8), (12, 10, 16)))])  # BASELINE config 5's layout ("Q-learning sampler on")
