@@ -2087,6 +2087,9 @@ int rt_intersect_scope(rt_ctx* c, int scope, int index, int n, const float* O, c
 	if (e == hipSuccess && tmax) e = hipMemcpyAsync(dT, tmax, (size_t)4 * n, hipMemcpyHostToDevice, c->stream);
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
+#ifdef RT_SECTION_PROBE
+		section_probe_reset(c->stream);
+#endif
 		prof_begin(c, K_QUERY);
 		const bool head = scope == RT_SCOPE_SCENE;
 		if (c->counting) {
@@ -2097,6 +2100,9 @@ int rt_intersect_scope(rt_ctx* c, int scope, int index, int n, const float* O, c
 			else hipLaunchKernelGGL((k_query_nearest<false, false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
 		}
 		prof_end(c);
+#ifdef RT_SECTION_PROBE
+		if (!c->counting) section_probe_print(c->stream, "query", n);
+#endif
 		e = hipStreamSynchronize(c->stream);
 	}
 	static_assert(sizeof(QueryHit) == sizeof(rt_hit), "rt_hit layout");

@@ -80,7 +80,14 @@ namespace rtd {
 //   the rest             the block's copy of the TLAS (pairs, reach records, instance transforms), when it fits
 // rows = 16 without a TLAS copy; a copy takes rows away down to RT_STACK_ROWS_MIN (the 16 instances of config 5: 13 rows;
 // measured there: 13 rows cost nothing, the copy takes 4 % off the frame set); a TLAS too large for that stays in global memory.
-#define RT_LDS_WORDS 5760
+#ifndef RT_DRAIN_PREFETCH
+#define RT_DRAIN_PREFETCH 0 // the drain touches the lines of both children of a pair (trace_persistent): measured slower, see there
+#endif
+#if RT_DRAIN_PREFETCH
+#define RT_LDS_WORDS 5696 // + the 64 words of trace_persistent's pfDump = 5760
+#else
+#define RT_LDS_WORDS 5760 // 18 allocation granules of 320 words
+#endif
 #define RT_STACK_ROWS_MAX 16
 #ifndef RT_STACK_ROWS_MIN
 #define RT_STACK_ROWS_MIN 8
@@ -168,6 +175,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 __device__ __forceinline__ float4 ld_lds(const lds_v4f* p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 typedef __attribute__((address_space(1))) uint glb_uint;
+// read-only scene data at a wave-uniform address: address space 4 makes the load a scalar one (s_load_dwordx4/x16)
+typedef __attribute__((address_space(4))) v4f c_float4;
+__device__ __forceinline__ float4 ld_c(const c_float4* p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+template <class T> __device__ __forceinline__ const T* uniform_ptr(const T* p)
+{
+	const unsigned long long a = (unsigned long long)p;
+	const uint lo = (uint)__builtin_amdgcn_readfirstlane((int)(uint)a), hi = (uint)__builtin_amdgcn_readfirstlane((int)(uint)(a >> 32));
+	return (const T*)(((unsigned long long)hi << 32) | lo);
+}
+#ifndef RT_SCALAR_LONE
+#define RT_SCALAR_LONE 0 // a lone lane's records through the scalar cache: measured level (the round trip is the L2's, whichever path asks)
+#endif
+
 struct Stack {
 	lds_uint* lds;    // &ldsStack[0][threadIdx.x]
 	glb_uint* spill;  // &spill[0][global lane]
@@ -453,6 +473,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_EXPERIMENT_EXTRA_LOADS
 	uint xdummy = 0;
 #endif
+#if RT_DRAIN_PREFETCH
+	// where the drain's line touches land (LDS-DMA: a load without a destination register -- a register would have to stay
+	// reserved until the load lands, which the compiler cannot be told).  Never read; the four waves of the block share it.
+	__shared__ uint pfDump[64];
+#endif
 
 	// context B (TWO): the lane's other ray, parked
 	f3 bO(0.0f), bD(0.0f), brD(0.0f);
@@ -643,6 +668,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_EXPERIMENT_EXTRA_LOADS
 				if (xdummy == 0x7fc12345u && n < 0) *overflow = 3; // keeps the register allocated to the loads
 #endif
+
 #ifdef RT_SECTION_PROBE
 				if (lane == 0) secAcc[7] = RT_SEC_NOW() - secStart;
 				if (lane < 14) atomicAdd(&g_sectionProbe[lane], (unsigned long long)secAcc[lane]);
@@ -770,6 +796,14 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 					}
 				} else {
 					const float4* p = FETCH && !wantPair ? S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT) : S.pairs + 4 * (size_t)lk;
+#if RT_SCALAR_LONE
+					if (nP == 1) {
+						// a lone lane (the drain of a launch: one ray per wave, one dependent step after the other): its record comes
+						// through the scalar cache -- one s_load_dwordx16 instead of four trips through the texture addresser
+						const c_float4* ps = (const c_float4*)uniform_ptr(p);
+						a0 = ld_c(ps), a1 = ld_c(ps + 1), b0 = ld_c(ps + 2), b1 = ld_c(ps + 3);
+					} else
+#endif
 					a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
 					if (useReach) {
 						const float4* q = S.reach + 3 * (size_t)(lk - S.tlasBase);
@@ -779,6 +813,25 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				RT_SEC_WAIT();
 				RT_SEC_ADD(1, secT);
 				const unsigned long long secT2 = RT_SEC_NOW();
+#if RT_DRAIN_PREFETCH
+				// Experiment, off (profiles/r03_lone_step.txt): in the drain of a launch -- the queue is dry, this wave's last rays make one
+				// dependent step after the other in a nearly empty machine, ~0.6 us per step -- touch the lines of BOTH children's
+				// records as soon as a pair record is here (LDS-DMA, one dword each into an LDS word nobody reads: no destination
+				// register to keep reserved), so that the next step's round trip overlaps this step's arithmetic.  Measured: a lone
+				// lane's step 612 -> 684 ns, every drain-bound number 5-8 % worse.  With the scalar-cache variant (RT_SCALAR_LONE:
+				// level) this says the lone step is not waiting for its record; it is the ~300 instructions of a wave iteration.
+				if (!TWO && exhausted && !(S.tlasLds && atTlas)) {
+					const uint pc1 = __float_as_uint(a0.w), pc2 = __float_as_uint(b0.w);
+					if (!(pc1 & RT_INST_BIT)) {
+						const float4* q = (pc1 & RT_LEAF_BIT) ? S.prims + 4 * (size_t)(pc1 & ~RT_LEAF_BIT) : S.pairs + 4 * (size_t)pc1;
+						__builtin_amdgcn_global_load_lds((const glb_uint*)q, (lds_uint*)pfDump, 4, 0, 0);
+					}
+					if (!(pc2 & RT_INST_BIT)) {
+						const float4* q = (pc2 & RT_LEAF_BIT) ? S.prims + 4 * (size_t)(pc2 & ~RT_LEAF_BIT) : S.pairs + 4 * (size_t)pc2;
+						__builtin_amdgcn_global_load_lds((const glb_uint*)q, (lds_uint*)pfDump, 4, 0, 0);
+					}
+				}
+#endif
 #ifdef RT_EXPERIMENT_EXTRA_LOADS
 				// measurement only: N more loads of a pair record (L1 hits, nobody waits for them): does the
 				// vector-memory path limit this kernel?
@@ -868,7 +921,14 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			const float4* rec = S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT);
 			const unsigned long long secT = RT_SEC_NOW();
 			RT_SEC_COUNT(10);
-			const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+			float4 r0, r1, r2, r3;
+#if RT_SCALAR_LONE
+			if (nL == 1 && !TWO) {
+				const c_float4* rs = (const c_float4*)uniform_ptr(rec);
+				r0 = ld_c(rs), r1 = ld_c(rs + 1), r2 = ld_c(rs + 2), r3 = ld_c(rs + 3);
+			} else
+#endif
+			r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
 			RT_SEC_WAIT();
 			RT_SEC_ADD(3, secT);
 			const unsigned long long secT2 = RT_SEC_NOW();
