@@ -85,6 +85,7 @@ struct rt_ctx {
 	uint* megaCost = nullptr; uint* megaOrder = nullptr; uint* megaHist = nullptr;
 	size_t megaCostCap = 0;
 	unsigned megaCostSamples = 0, megaCostFirst = 0; // the batch megaCost describes (0 samples: nothing yet)
+	int deferGamma = 1;      // RT_DEFER_GAMMA: path-mode samples get their gamma in k_accumulate (rt_kernels.h store_sample)
 	int megaLpt = 1;         // RT_MEGA_LPT: 0 keeps the multiplicative permutation
 	int megaDecide = 0;      // RT_MEGA_DECIDE: the flush answers queries that need no walk (measured: level, the launch is as long as its longest pixel)
 	int megaPathMax = 0;     // RT_MEGA_PATH_MAX: path batches up to this many samples run as one launch too (k_path_mega).  Off: measured slower than
@@ -300,6 +301,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
 	if (getenv("RT_MEGA_LPT")) c->megaLpt = atoi(getenv("RT_MEGA_LPT")) != 0;
+	if (getenv("RT_DEFER_GAMMA")) c->deferGamma = atoi(getenv("RT_DEFER_GAMMA")) != 0;
 	if (getenv("RT_MEGA_DECIDE")) c->megaDecide = atoi(getenv("RT_MEGA_DECIDE")) != 0;
 	if (getenv("RT_MEGA_PATH_MAX")) c->megaPathMax = atoi(getenv("RT_MEGA_PATH_MAX"));
 	memset(&c->M, 0, sizeof(c->M));
@@ -1847,6 +1849,7 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		memset(&R, 0, sizeof(R));
 		R.mode = mode, R.frame0 = frame0 + (uint)f, R.nSamples = (uint)total, R.tilePixels = (uint)tilePixels, R.samples = c->samples;
 		R.seedBase = seed_base, R.rowFirst = row_first, R.rowStride = row_stride, R.maxDepth = max_depth, R.accum = c->accum;
+		R.deferGamma = mode == RT_MODE_PATH ? c->deferGamma : 0;
 		if (mode == RT_MODE_PATH && c->pathUnsupported) {
 			// random draws interleave with occlusion queries (shiny / raytracer == 0 diffuse): one lane per sample
 			hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
@@ -2334,10 +2337,10 @@ const char* rt_build_info(void)
 const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
-	char buf[512];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d wide=%d wide8=%d mega=%d mega_path_max=%d two=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	char buf[640];
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_lpt=%d mega_decide=%d mega_path_max=%d two=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaPathMax, c->twoRays, c->Qt.on,
+	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLpt, c->megaDecide, c->megaPathMax, c->twoRays, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();

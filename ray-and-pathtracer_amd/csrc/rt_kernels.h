@@ -70,6 +70,7 @@ struct RenderParams {
 	uint permMul;      // rt_mega.h: work item w is sample (w * permMul) % nSamples (0: w itself), see run_whitted_mega
 	int finishInline;  // path mode with a slot per sample: nothing to resume and no sample to pull when a segment ends,
 	                   // so shade / light store the finished sample themselves and the round has no finish pass
+	int deferGamma;    // path mode: a finished sample is stored raw with w = 1 and k_accumulate applies the gamma (see store_sample)
 };
 
 #define ST_ACTIVE 1      // has a ray for extend + shade
@@ -387,11 +388,18 @@ __device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, 
 
 // A finished sample goes to the [frame][pixel] buffer (renderer.cpp:270 / :279-282: gamma per sample in path
 // mode) or to the caller's array (rt_trace_batch).
+// Deferred gamma (R.deferGamma): the three double-precision pow() of a path-mode sample are the same function of the same three
+// floats wherever they run.  In the shading kernels they run for the lanes of a wave whose path just ended (a third of them,
+// the others wait) at five waves per SIMD, and their registers are part of those kernels' floor; k_accumulate reads every
+// sample anyway, dense and with the whole machine: the sample is stored raw with w = 1 and gets its gamma there (w = 0: the
+// value is final -- the sky texel table of generate).  Same bits, same order of the accumulator's additions.
+__device__ __forceinline__ float4 gamma_sample(const f3& L) { return make_float4(x_powf(L.x * 1, RT_GAMMA), x_powf(L.y * 1, RT_GAMMA), x_powf(L.z * 1, RT_GAMMA), 0.0f); }
 __device__ __forceinline__ void store_sample(const RenderParams& R, uint sid, const f3& L)
 {
 	if (R.customOut) R.customOut[sid] = mk4(L, 0.0f);
 	else if (R.mode == 0) R.samples[sid] = make_float4(L.x / (float)1, L.y / (float)1, L.z / (float)1, 0.0f);
-	else R.samples[sid] = make_float4(x_powf(L.x * 1, RT_GAMMA), x_powf(L.y * 1, RT_GAMMA), x_powf(L.z * 1, RT_GAMMA), 0.0f);
+	else if (R.deferGamma) R.samples[sid] = mk4(L, 1.0f);
+	else R.samples[sid] = gamma_sample(L);
 }
 
 __device__ __forceinline__ void push_pending(PathState& P, int slot, const f3& O, const f3& D, const f3& W, const f3& E, int depth, int* overflow)
@@ -971,7 +979,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_sample_general(DScene S, DCamera C
 			W = cur.W * ((2 * (col * cos_i)) * albedo);
 		}
 		if (R.customOut) R.customOut[sid] = mk4(Lsum, 0.0f);
-		else R.samples[sid] = make_float4(x_powf(Lsum.x * 1, RT_GAMMA), x_powf(Lsum.y * 1, RT_GAMMA), x_powf(Lsum.z * 1, RT_GAMMA), 0.0f);
+		else store_sample(R, sid, Lsum);
 	}
 }
 
@@ -986,7 +994,8 @@ __global__ void k_accumulate(DCamera C, RenderParams R, int batchFrames)
 	if (R.mode == 0) { R.accum[pixel] = R.samples[lp]; return; }
 	float4 a = R.accum[pixel];
 	for (int f = 0; f < batchFrames; f++) {
-		const float4 s = R.samples[(size_t)f * R.tilePixels + lp];
+		float4 s = R.samples[(size_t)f * R.tilePixels + lp];
+		if (s.w != 0) s = gamma_sample(xyz(s)); // stored raw (R.deferGamma)
 		a.x += s.x, a.y += s.y, a.z += s.z, a.w += 0;
 	}
 	R.accum[pixel] = a;
