@@ -85,6 +85,9 @@ struct rt_ctx {
 	uint* megaCost = nullptr; uint* megaOrder = nullptr; uint* megaHist = nullptr;
 	size_t megaCostCap = 0;
 	unsigned megaCostSamples = 0, megaCostFirst = 0; // the batch megaCost describes (0 samples: nothing yet)
+	int decideShadow = 0;    // RT_DECIDE_SHADOW: the dense pipeline's connect answers shadow rays that need no walk when it loads them (rt_stream.h
+	                         // StreamConnectPolicy).  Off: measured slower (connect 8.7 -> 9.15 ms: the test moves from a pair step into the refill, and a
+	                         // lane that answered its ray there idles until the next refill all the same)
 	int deferGamma = 1;      // RT_DEFER_GAMMA: path-mode samples get their gamma in k_accumulate (rt_kernels.h store_sample)
 	int megaLpt = 1;         // RT_MEGA_LPT: 0 keeps the multiplicative permutation
 	int megaDecide = 0;      // RT_MEGA_DECIDE: the flush answers queries that need no walk (measured: level, the launch is as long as its longest pixel)
@@ -301,6 +304,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
 	if (getenv("RT_MEGA_LPT")) c->megaLpt = atoi(getenv("RT_MEGA_LPT")) != 0;
+	if (getenv("RT_DECIDE_SHADOW")) c->decideShadow = atoi(getenv("RT_DECIDE_SHADOW")) != 0;
 	if (getenv("RT_DEFER_GAMMA")) c->deferGamma = atoi(getenv("RT_DEFER_GAMMA")) != 0;
 	if (getenv("RT_MEGA_DECIDE")) c->megaDecide = atoi(getenv("RT_MEGA_DECIDE")) != 0;
 	if (getenv("RT_MEGA_PATH_MAX")) c->megaPathMax = atoi(getenv("RT_MEGA_PATH_MAX"));
@@ -1642,7 +1646,7 @@ static int ensure_stream_state(rt_ctx* c, int n)
 }
 static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int round, uint* spill, uint* spillTwo)
 {
-	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27);
+	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27) | (c->decideShadow ? RT_TUNE_DECIDE_SHADOW : 0);
 	if ((c->twoRays & 2) && c->S.stackRows2 > 0 && !c->S.wide) {
 		if (c->counting) hipLaunchKernelGGL((k_connect_s2<true>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spillTwo, c->counters + 1);
 		else hipLaunchKernelGGL((k_connect_s2<false>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spillTwo, c->counters + 1);
@@ -1698,7 +1702,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		tail_probe_reset(st);
 #endif
 		prof_begin(c, K_EXTEND, st);
-		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill);
+		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin) | (c->decideShadow ? RT_TUNE_DECIDE_SHADOW : 0), c->spill);
 		else if ((c->twoRays & 1) && c->S.stackRows2 > 0) {
 			if (c->counting) hipLaunchKernelGGL((k_extend_s2<true>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
 			else hipLaunchKernelGGL((k_extend_s2<false>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
@@ -2338,8 +2342,8 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_lpt=%d mega_decide=%d mega_path_max=%d two=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
-	         c->useStream, c->decideRays, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d decide_shadow=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_lpt=%d mega_decide=%d mega_path_max=%d two=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	         c->useStream, c->decideRays, c->decideShadow, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
 	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLpt, c->megaDecide, c->megaPathMax, c->twoRays, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
