@@ -1047,8 +1047,10 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
     out, rays = {}, {}
     pO = pD = None
     for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_gated", {"RT_FUSE": "3"}), ("stream_one_launch_per_round", {"RT_FUSE": "1"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
-                     ("stream_two_rays", {"RT_TWO": "3", "RT_FUSE": "2"}), ("one_launch", {"RT_MEGA_PATH_MAX": "4194304"})):
-        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_TWO"):
+                     ("stream_two_rays", {"RT_TWO": "3", "RT_FUSE": "2"}), ("one_launch", {"RT_MEGA_PATH_MAX": "4194304"}),
+                     ("stream_decide_shadow", {"RT_DECIDE_SHADOW": "1", "RT_FUSE": "0"}), ("stream_decide_shadow_one_launch_per_round", {"RT_DECIDE_SHADOW": "1", "RT_FUSE": "1"}),
+                     ("stream_gamma_at_the_store", {"RT_DEFER_GAMMA": "0"})):
+        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_TWO", "RT_DECIDE_SHADOW", "RT_DEFER_GAMMA"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("RT_MEGA_PATH_MAX", "0")
         for k, v in env.items():
@@ -1077,7 +1079,8 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
                 pO, pD = pO[::7].copy(), pD[::7].copy()
             out[key + "_sample"] = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 99) for depth in (0, 1, 4)]
         r.close()
-    for key in ("stream", "stream_serial", "stream_gated", "stream_one_launch_per_round", "stream_nodecide", "stream_two_rays", "one_launch"):
+    for key in ("stream", "stream_serial", "stream_gated", "stream_one_launch_per_round", "stream_nodecide", "stream_two_rays", "one_launch",
+                "stream_decide_shadow", "stream_decide_shadow_one_launch_per_round", "stream_gamma_at_the_store"):
         assert np.array_equal(out["slot"].view(np.uint32), out[key].view(np.uint32)), key
         assert rays[key] == rays["slot"], (key, rays[key], rays["slot"])
     for other in ("stream_sample", "one_launch_sample"):
