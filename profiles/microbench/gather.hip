@@ -92,6 +92,42 @@ __global__ void __launch_bounds__(256, 7) walkAmask(const float4* __restrict__ t
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// A with only the FIRST N lanes of every wave walking (contiguous active lanes): does the texture addresser skip quads (or
+// larger groups) that have no enabled lane?  Compare with every 4th lane (the same number of lanes, one in every quad).
+template <int N>
+__global__ void __launch_bounds__(256, 7) walkAfirst(const float4* __restrict__ tab, int steps, unsigned mask, float* out)
+{
+	unsigned idx = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u & mask;
+	float acc = 0;
+	const bool on = (threadIdx.x & 63) < N;
+	for (int s = 0; s < steps; s++) {
+		if (on) {
+			const float4* p = tab + 4 * (size_t)idx;
+			const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+			acc += a.x + b.y + c.z + d.x;
+			idx = __float_as_uint(a.w) & mask;
+		}
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+// ... and with N lanes scattered irregularly over the wave (a traversal's pair step)
+template <int N>
+__global__ void __launch_bounds__(256, 7) walkAscatter(const float4* __restrict__ tab, int steps, unsigned mask, float* out)
+{
+	unsigned idx = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u & mask;
+	float acc = 0;
+	const unsigned l = threadIdx.x & 63;
+	const bool on = ((l * 37u + 11u) & 63u) < N; // a permutation of the lanes: N of 64 on, irregularly placed
+	for (int s = 0; s < steps; s++) {
+		if (on) {
+			const float4* p = tab + 4 * (size_t)idx;
+			const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+			acc += a.x + b.y + c.z + d.x;
+			idx = __float_as_uint(a.w) & mask;
+		}
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
 // A with a wave-uniform base in SGPRs and a 32-bit byte offset per lane (global_load ... v_off, s[base]): does the
 // address form matter to the vector-memory path?
 __global__ void __launch_bounds__(256, 7) walkAs(const float4* __restrict__ tab, int steps, unsigned mask, float* out)
@@ -156,8 +192,9 @@ __global__ void __launch_bounds__(256, 7) walkA8(const float4* __restrict__ tab,
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-int main()
+int main(int argc, char** argv)
 {
+	const bool only_new = argc > 1; // any argument: only the lane-placement variants
 	hipDeviceProp_t prop;
 	CHK(hipGetDeviceProperties(&prop, 0));
 	const int blocks = prop.multiProcessorCount * 7, threads = 256, steps = 2000;
@@ -183,7 +220,7 @@ int main()
 		hipEvent_t a, b;
 		CHK(hipEventCreate(&a));
 		CHK(hipEventCreate(&b));
-		for (int variant = 0; variant < 14; variant++) {
+		for (int variant = (only_new ? 14 : 0); variant < 20; variant++) {
 			for (int rep = 0; rep < 2; rep++) {
 				CHK(hipEventRecord(a));
 				if (variant == 0) hipLaunchKernelGGL(walkA, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
@@ -199,13 +236,19 @@ int main()
 				if (variant == 11) hipLaunchKernelGGL(walkSc1, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 12) hipLaunchKernelGGL(walkNt, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 13) hipLaunchKernelGGL(walkSc01, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 14) hipLaunchKernelGGL(walkAfirst<16>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 15) hipLaunchKernelGGL(walkAfirst<32>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 16) hipLaunchKernelGGL(walkAscatter<16>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 17) hipLaunchKernelGGL(walkAscatter<26>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 18) hipLaunchKernelGGL(walkAfirst<26>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
+				if (variant == 19) hipLaunchKernelGGL(walkAfirst<8>, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				if (variant == 6) hipLaunchKernelGGL(walkA8, dim3(blocks), dim3(threads), 0, 0, tab, steps, R - 1, out);
 				CHK(hipEventRecord(b));
 				CHK(hipEventSynchronize(b));
 				float ms;
 				CHK(hipEventElapsedTime(&ms, a, b));
-				const double per[14] = { 1, 0.25, 0.5, 0.5, 1, 1, 1, 0.5, 0.25, 1, 1, 1, 1, 1 };
-				const char* names[14] = { "A  lane, 4 loads/rec", "Q  quad, 1 load/lane", "P  pair, 2 loads/lane", "Q2 quad, 2 chains", "Q4 quad, 4 chains", "A1 lane, 1 load (16 B)", "A8 lane, 8 loads (128 B)", "A  every 2nd lane only", "A  every 4th lane only", "As lane, 4 loads, saddr+voffset", "As + sc0", "As + sc1", "As + nt", "As + sc0 sc1" };
+				const double per[20] = { 1, 0.25, 0.5, 0.5, 1, 1, 1, 0.5, 0.25, 1, 1, 1, 1, 1, 16 / 64.0, 32 / 64.0, 16 / 64.0, 26 / 64.0, 26 / 64.0, 8 / 64.0 };
+				const char* names[20] = { "A  lane, 4 loads/rec", "Q  quad, 1 load/lane", "P  pair, 2 loads/lane", "Q2 quad, 2 chains", "Q4 quad, 4 chains", "A1 lane, 1 load (16 B)", "A8 lane, 8 loads (128 B)", "A  every 2nd lane only", "A  every 4th lane only", "As lane, 4 loads, saddr+voffset", "As + sc0", "As + sc1", "As + nt", "As + sc0 sc1", "A  first 16 lanes only", "A  first 32 lanes only", "A  16 lanes, scattered", "A  26 lanes, scattered", "A  first 26 lanes only", "A  first 8 lanes only" };
 				const double walkers = (double)blocks * threads * per[variant];
 				if (rep == 1) printf("table %5u KB  %-26s %8.3f ms  %8.2f G records/s  (%.0f walkers)\n", R * 64 / 1024, names[variant], ms, walkers * steps / ms / 1e6, walkers);
 			}
