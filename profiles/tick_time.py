@@ -12,7 +12,8 @@ for name, kw, w, h in (("mixed_small", {}, 1920, 1080), ("pretty_tlas", {"n_inst
                 c = d["camera"]; r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
             r.scene.set_raytracer(not path)
             r.L.rth_renderer_set_download(r.h, download)
-            r.tick(); r.tick()
+            for _ in range(6):
+                r.tick()
             n = 20
             t = time.perf_counter()
             for _ in range(n):

@@ -79,7 +79,16 @@ struct rt_ctx {
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
 	std::vector<void*> megaAllocs;
-	int megaLanes = 0, gridMega = 0, gridMegaPath = 0;
+	int megaLanes = 0, gridMega = 0, gridMegaPath = 0, gridLevel = 0;
+	// Whitted frames by tree levels (rt_mega.h LevelState): queues, term log
+	std::vector<void*> levelAllocs;
+	LevelState V;
+	size_t levelCap = 0; int levelLevels = 0; size_t levelSamples = 0;
+	int megaLevels = 2;      // RT_MEGA_LEVELS: Whitted frames up to RT_LEVEL_SAMPLES_MAX samples run one launch per tree level (1), as one launch (0), or
+	                         // as whichever of the two was faster when this context last tried both on a batch of this shape (2, default: the frames
+	                         // are identical either way; deep glass trees gain 40 %, shallow scenes lose 10 % to the extra launches)
+	struct { unsigned nSamples = 0; int depth = 0; int tried[2] = { 0, 0 }; float ms[2] = { 0, 0 }; int choice = -1; } megaAuto; // [0] single launch, [1] levels
+	hipEvent_t megaEv[2] = { nullptr, nullptr };
 	// longest first (rt_mega.h): per-sample cost of the last Whitted launch and the tile order made from it
 	std::vector<void*> megaOrderAllocs;
 	uint* megaCost = nullptr; uint* megaOrder = nullptr; uint* megaHist = nullptr;
@@ -304,6 +313,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
 	if (getenv("RT_MEGA_LPT")) c->megaLpt = atoi(getenv("RT_MEGA_LPT")) != 0;
+	if (getenv("RT_MEGA_LEVELS")) c->megaLevels = atoi(getenv("RT_MEGA_LEVELS"));
 	if (getenv("RT_DECIDE_SHADOW")) c->decideShadow = atoi(getenv("RT_DECIDE_SHADOW")) != 0;
 	if (getenv("RT_DEFER_GAMMA")) c->deferGamma = atoi(getenv("RT_DEFER_GAMMA")) != 0;
 	if (getenv("RT_MEGA_DECIDE")) c->megaDecide = atoi(getenv("RT_MEGA_DECIDE")) != 0;
@@ -343,6 +353,7 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridExtendS2 = std::min(resident((const void*)k_extend_s2<false>), resident((const void*)k_extend_s2<true>));
 		c->gridConnectS2 = std::min(resident((const void*)k_connect_s2<false>), resident((const void*)k_connect_s2<true>));
 		c->gridMega = resident((const void*)k_whitted_mega);
+		c->gridLevel = resident((const void*)k_whitted_level);
 		c->gridMegaPath = resident((const void*)k_path_mega);
 		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : std::min(resident((const void*)k_shade_s<false>), resident((const void*)k_shade_s<true>));
 		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
@@ -411,6 +422,7 @@ void rt_destroy(rt_ctx* c)
 	free_pool(c->streamAllocs);
 	free_pool(c->megaAllocs);
 	free_pool(c->megaOrderAllocs);
+	free_pool(c->levelAllocs);
 	free_pool(c->qAllocs);
 	if (c->spill2) (void)hipFree(c->spill2);
 	if (c->sideSpill2) (void)hipFree(c->sideSpill2);
@@ -418,6 +430,7 @@ void rt_destroy(rt_ctx* c)
 	if (c->streamSideSpill) (void)hipFree(c->streamSideSpill);
 	if (c->streamFork) (void)hipEventDestroy(c->streamFork);
 	if (c->streamJoin) (void)hipEventDestroy(c->streamJoin);
+	for (int k = 0; k < 2; k++) if (c->megaEv[k]) (void)hipEventDestroy(c->megaEv[k]);
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
 	if (c->samples) (void)hipFree(c->samples);
@@ -486,6 +499,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		if (m.type < 1 || m.type > 3) return fail(c, RT_E_ARG, "rt_upload_scene: material %u has type %d", i, m.type);
 	}
 	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->megaAuto = {}; // another scene: the Whitted forms are timed again
 	free_pool(c->sceneAllocs);
 	c->sceneLoaded = false;
 	c->pathUnsupported = false;
@@ -1513,6 +1527,8 @@ static int run_rounds_fused(rt_ctx* c, const RenderParams* Rs, int nPools, int r
 }
 
 // ---- Whitted frames as one persistent launch (rt_mega.h) -----------------------------------------------
+#define RT_LEVEL_SAMPLES_MAX (16u << 20) // larger batches keep the single launch: their drain is a small part of them, and the queues would take GBs
+static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int grid0, int refill, bool* redo);
 static int run_mega(rt_ctx* c, const RenderParams& R0)
 {
 	RenderParams R = R0;
@@ -1548,7 +1564,31 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 	MegaState M = c->M;
 	M.cost = nullptr, M.order = nullptr;
 	M.nWork = (int)(((R.nSamples + (1u << R.permShift) - 1) >> R.permShift) << R.permShift);
-	if (c->megaLpt && R.mode == RT_MODE_WHITTED && R.permMul && !R.customO) {
+	bool useLevels = c->megaLevels && R.mode == RT_MODE_WHITTED && !R.customO && R.maxDepth >= 1 && R.maxDepth <= RT_LEVEL_MAX && R.nSamples <= RT_LEVEL_SAMPLES_MAX && c->S.nLights <= 32;
+	// RT_MEGA_LEVELS=2: both forms give the same frame, so the context may simply time them -- each form twice on the first four batches
+	// of a shape (the first run of a form pays its allocations and has no cost history), then whichever was faster
+	int probe = -1; // the form this batch is timed as
+	if (useLevels && c->megaLevels == 2) {
+		auto& A = c->megaAuto;
+		if (A.nSamples != R.nSamples || A.depth != R.maxDepth) A = {}, A.nSamples = R.nSamples, A.depth = R.maxDepth;
+		if (A.choice < 0) {
+			probe = A.tried[0] < 2 ? 0 : 1;
+			if (!c->megaEv[0]) { (void)hipEventCreate(&c->megaEv[0]); (void)hipEventCreate(&c->megaEv[1]); }
+			(void)hipEventRecord(c->megaEv[0], c->stream);
+		}
+		useLevels = A.choice >= 0 ? A.choice == 1 : probe == 1;
+	}
+	auto probe_end = [&]() {
+		if (probe < 0) return;
+		auto& A = c->megaAuto;
+		float ms = 0;
+		(void)hipEventRecord(c->megaEv[1], c->stream);
+		(void)hipEventSynchronize(c->megaEv[1]);
+		(void)hipEventElapsedTime(&ms, c->megaEv[0], c->megaEv[1]);
+		A.ms[probe] = ms, A.tried[probe]++;
+		if (A.tried[0] >= 2 && A.tried[1] >= 2) A.choice = A.ms[1] < A.ms[0] ? 1 : 0;
+	};
+	if (c->megaLpt && R.mode == RT_MODE_WHITTED && R.permMul && !R.customO && !useLevels) {
 		const unsigned tilesPerHead = RT_HEADS * 8u; // sub-queues of n / RT_HEADS entries, a multiple of 64 entries = 8 tiles of 8
 		const unsigned nTiles = (R.nSamples + (1u << R.permShift) - 1) >> R.permShift;
 		const unsigned unit = tilesPerHead * (64u >> R.permShift ? 64u >> R.permShift : 1u) / 8u;
@@ -1573,12 +1613,23 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 		M.cost = c->megaCost;
 		c->megaCostSamples = R.nSamples, c->megaCostFirst = R.sampleFirst;
 	}
+	// a flush runs the body of Trace for the lanes that finished a query: it waits for more of them than a plain store does (RT_REFILL_MEGA, 32: 5.0 -> 4.85 ms)
+	const int refillMega = getenv("RT_REFILL_MEGA") && atoi(getenv("RT_REFILL_MEGA")) > 0 && atoi(getenv("RT_REFILL_MEGA")) <= 64 ? atoi(getenv("RT_REFILL_MEGA")) : 32;
+	if (useLevels) {
+		bool redo = false;
+		MegaState ML = M;
+		ML.cost = nullptr, ML.order = nullptr;
+		ML.nWork = (int)(((R.nSamples + (1u << R.permShift) - 1) >> R.permShift) << R.permShift);
+		const int rc = run_levels(c, R, ML, grid, refillMega, &redo);
+		if (rc != RT_OK || !redo) { probe_end(); return rc; }
+		probe = -1, c->megaAuto.choice = 0; // this scene overflows the level queues: the single launch from now on
+		// a queue overflowed (more than two live branches per sample on average): the frame again, as one launch
+		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream);
+	}
 #ifdef RT_TAIL_PROBE
 	tail_probe_reset(c->stream);
 #endif
 	prof_begin(c, K_EXTEND);
-	// a flush runs the body of Trace for the lanes that finished a query: it waits for more of them than a plain store does (RT_REFILL_MEGA, 32: 5.0 -> 4.85 ms)
-	const int refillMega = getenv("RT_REFILL_MEGA") && atoi(getenv("RT_REFILL_MEGA")) > 0 && atoi(getenv("RT_REFILL_MEGA")) <= 64 ? atoi(getenv("RT_REFILL_MEGA")) : 32;
 	if (R.mode == RT_MODE_WHITTED) hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->megaDecide, c->spill, c->flags);
 	else hipLaunchKernelGGL(k_path_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
 	prof_end(c);
@@ -1591,6 +1642,51 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 	f = c->hostCounts[0];
 	if (f != 0) (void)hipMemsetAsync(c->flags, 0, 2 * sizeof(int), c->stream);
 	if (f == 2) return fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
+	if (f == 199) return fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
+	if (f >= 100) return fail(c, RT_E_STATE, "debug check %d failed in the Whitted kernel (RT_DEBUG_CHECKS build)", f - 100);
+	if (f) return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+	HIPCHK(c, hipGetLastError());
+	probe_end();
+	return RT_OK;
+}
+
+// Whitted frames by tree levels (rt_mega.h): depth launches of k_whitted_level + k_whitted_reduce.  *redo: a queue overflowed.
+static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int grid0, int refill, bool* redo)
+{
+	const int levels = R.maxDepth;
+	const size_t cap = ((size_t)2 * R.nSamples + 65536 + 63) & ~(size_t)63;
+	if (c->levelCap < cap || c->levelLevels < levels || c->levelSamples < (size_t)R.nSamples) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		free_pool(c->levelAllocs);
+		c->levelCap = 0, c->levelLevels = 0, c->levelSamples = 0;
+		LevelState V;
+		memset(&V, 0, sizeof(V));
+		std::vector<void*>& A = c->levelAllocs;
+		HIPCHK(c, dalloc(A, &V.seg[0], cap * 4)); HIPCHK(c, dalloc(A, &V.seg[1], cap * 4));
+		HIPCHK(c, dalloc(A, &V.count, (size_t)RT_LEVEL_MAX + 2));
+		HIPCHK(c, dalloc(A, &V.termKey, cap * (size_t)levels)); HIPCHK(c, dalloc(A, &V.termVal, cap * (size_t)levels));
+		HIPCHK(c, dalloc(A, &V.head, (size_t)R.nSamples));
+		V.cap = (int)cap;
+		c->V = V, c->levelCap = cap, c->levelLevels = levels, c->levelSamples = (size_t)R.nSamples;
+	}
+	LevelState V = c->V;
+	(void)hipMemsetAsync(V.count, 0, (RT_LEVEL_MAX + 2) * sizeof(int), c->stream);
+	(void)hipMemsetAsync(V.head, 0xFF, (size_t)R.nSamples * sizeof(int), c->stream);
+	prof_begin(c, K_EXTEND);
+	for (int level = 0; level < levels; level++) {
+		if (level > 0) (void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
+		V.level = level;
+		const int grid = level == 0 ? std::min(grid0, c->gridLevel) : c->gridLevel;
+		hipLaunchKernelGGL(k_whitted_level, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M0, V, tuning(c, (c->refillMin & ~0xFF) | refill), c->spill, c->flags);
+	}
+	hipLaunchKernelGGL(k_whitted_reduce, dim3((R.nSamples + 255) / 256), dim3(256), 0, c->stream, R, V);
+	prof_end(c);
+	HIPCHK(c, hipMemcpyAsync(c->hostCounts, c->flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const int f = c->hostCounts[0];
+	if (f != 0) (void)hipMemsetAsync(c->flags, 0, 2 * sizeof(int), c->stream);
+	*redo = f == 3;
+	if (f == 3) return RT_OK;
 	if (f == 199) return fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
 	if (f >= 100) return fail(c, RT_E_STATE, "debug check %d failed in the Whitted kernel (RT_DEBUG_CHECKS build)", f - 100);
 	if (f) return fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
@@ -2342,9 +2438,9 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d decide_shadow=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_lpt=%d mega_decide=%d mega_path_max=%d two=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d decide_shadow=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d mega_decide=%d mega_path_max=%d two=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->decideShadow, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLpt, c->megaDecide, c->megaPathMax, c->twoRays, c->Qt.on,
+	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->megaDecide, c->megaPathMax, c->twoRays, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();

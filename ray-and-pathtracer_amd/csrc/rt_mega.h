@@ -304,6 +304,231 @@ struct WhittedMegaPolicy {
 	}
 };
 
+// ---- Renderer::Trace by tree levels ------------------------------------------------------------------------------------
+// The single launch above is as long as its longest pixel: one lane walks the whole tree of a glass pixel, up to 15 nearest-hit
+// queries and their light loops one after the other (4.4 of 5.3 ms on the bench scene, profiles/r03_mega_tail.txt).  The branches
+// of a tree are independent given what Trace hands them (ray, weight, energy, depth); what ties them to one lane is the ORDER in
+// which their terms enter the pixel's radiance, which is part of the result (float addition).  So: one launch per tree LEVEL.  A
+// work item is a SEGMENT (level 0: the camera ray of a sample; level l + 1: the children the segments of level l appended to a
+// queue); the lane that takes it runs the body of Trace at its hit as above -- the light loop of a diffuse hit stays with the
+// lane, one shadow query at a time -- but hands every child to the next level's queue instead of walking it, and LOGS the one
+// term a segment can add (sky / light / W * direct) under the segment's key instead of adding it.  The key is the segment's
+// path in the tree, six bits per level, with the digits chosen so that numeric order is the depth-first order the reference's
+// recursion adds in: glass: refraction 1, reflection 2 (renderer.cpp:61-79); metal: 1; a diffuse hit's own term sorts first (its
+// digit is 0) and its mirror branches come LAST LIGHT FIRST (the single launch pops them off a stack), light i = 1 + (n - 1 - i).
+// k_whitted_reduce then adds each sample's terms in key order, from 0, as the recursion would have: same bits.
+// A frame is depth launches of at most 1 + lights queries per lane and a streaming pass, instead of one launch of up to 31.
+#define RT_LEVEL_MAX 10   // levels (6 bits each in a 64-bit key); deeper Trace calls keep the single launch
+#define RT_LEVEL_CHUNK 32 // queue slots a wave reserves at a time (one atomic per chunk, not per child)
+struct LevelState {
+	float4* seg[2];              // segment queues by level parity, 4 float4 per segment: {O, depth} {D, sample} {W, key lo} {E, key hi}
+	int* count;                  // [RT_LEVEL_MAX + 2] slots reserved in the queue of each level (level 0: unused)
+	unsigned long long* termKey; // [level][cap]
+	float4* termVal;             // [level][cap] xyz, w = the sample's term logged before this one (int, -1: none)
+	int* head;                   // [sample of the batch] the sample's most recent term, -1: none
+	int cap;                     // segments per queue = terms per level
+	int level;
+};
+typedef __attribute__((address_space(3))) int lds_int;
+
+struct WhittedLevelPolicy {
+	static constexpr bool kAdvance = true;
+	const DScene& S;
+	const DCamera& C;
+	const RenderParams& R;
+	const MegaState& M;
+	const LevelState& V;
+	int gl;
+	int* flag;
+	lds_int* res; // this wave's reservation in the next level's queue: [0] next slot, [1] end
+
+	__device__ __forceinline__ bool any_of(int) const { return false; }
+	__device__ __forceinline__ bool sample_of(int work, uint& sid) const
+	{
+		uint w = (uint)work;
+		if (R.permMul) {
+			const uint sh = R.permShift, nTiles = (R.nSamples + (1u << sh) - 1) >> sh;
+			w = ((uint)(((unsigned long long)(w >> sh) * R.permMul) % nTiles) << sh) + (w & ((1u << sh) - 1));
+		}
+		sid = R.sampleFirst + w;
+		return w < R.nSamples;
+	}
+	__device__ __forceinline__ void new_segment(const f3& O, const f3& D, float& tmax, HitRef& head) const
+	{
+		float rayT = 1e34f;
+		head.kind = -1, head.inst = -1, head.prim = 0, head.t = 0;
+		LaneCounters unused;
+		find_nearest_head<false>(S, O, D, (float)1e-6, rayT, head, unused); // renderer.cpp:24
+		M.O[gl] = mk4(O, 0.0f), M.D[gl] = mk4(D, 0.0f);
+		tmax = rayT;
+	}
+	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
+	{
+		if (V.level == 0) {
+			uint sid, seed;
+			if (!sample_of(work, sid)) return false;
+			sample_primary(C, R, sid, O, D, seed);
+			M.W[gl] = make_float4(1, 1, 1, __int_as_float(start_depth(R)));
+			M.E[gl] = make_float4(1, 1, 1, 0);
+			M.L[gl] = make_float4(0, 0, __uint_as_float(sid), 0); // key 0
+		} else {
+			const float4* sg = V.seg[V.level & 1] + 4 * (size_t)work;
+			const float4 s0 = sg[0], s1 = sg[1], s2 = sg[2], s3 = sg[3];
+			if (__float_as_int(s0.w) < 0) return false; // a slot its wave reserved and did not fill
+			O = xyz(s0), D = xyz(s1);
+			M.W[gl] = make_float4(s2.x, s2.y, s2.z, s0.w);
+			M.E[gl] = make_float4(s3.x, s3.y, s3.z, 0);
+			M.L[gl] = make_float4(s2.w, s3.w, s1.w, 0);
+		}
+		new_segment(O, D, tmax, head);
+		return true;
+	}
+	// the one term of this segment, under its key, at the front of its sample's list
+	__device__ __forceinline__ void log_term(int work, unsigned long long key, uint sid, const f3& v) const
+	{
+		const size_t id = (size_t)V.level * (size_t)V.cap + (size_t)work;
+		V.termKey[id] = key;
+		const int before = atomicExch(&V.head[sid - R.sampleFirst], (int)id);
+		V.termVal[id] = mk4(v, __int_as_float(before));
+	}
+	struct Child { bool want; f3 O, D, W, E; int depth; uint digit; };
+	// the children of the lanes that are here together go to the next level's queue: one reservation for all of them
+	__device__ __forceinline__ void append(const Child& a, const Child& b, unsigned long long key, uint sid) const
+	{
+		const uint lane = threadIdx.x & 63;
+		const unsigned long long below = (1ull << lane) - 1;
+		const unsigned long long ma = __ballot(a.want), mb = __ballot(b.want);
+		const int na = __popcll(ma), cnt = na + __popcll(mb);
+		if (cnt == 0) return;
+		const int leader = __builtin_ctzll(__ballot(true));
+		int next = 0, end = 0, fresh = 0;
+		if ((int)lane == leader) {
+			next = res[0], end = res[1];
+			const int rem = end - next;
+			if (cnt > rem) {
+				const int need = (cnt - rem + RT_LEVEL_CHUNK - 1) / RT_LEVEL_CHUNK * RT_LEVEL_CHUNK;
+				fresh = atomicAdd(&V.count[V.level + 1], need);
+				res[0] = fresh + (cnt - rem), res[1] = fresh + need;
+			} else res[0] = next + cnt;
+		}
+		next = __builtin_amdgcn_readlane(next, leader), end = __builtin_amdgcn_readlane(end, leader), fresh = __builtin_amdgcn_readlane(fresh, leader);
+		const int rem = end - next;
+		const int shift = 58 - 6 * V.level; // the child's digit: level l + 1 of the key
+		for (int k = 0; k < 2; k++) {
+			const Child& ch = k ? b : a;
+			if (!ch.want) continue;
+			const int i = k ? na + __popcll(mb & below) : __popcll(ma & below);
+			const int slot = i < rem ? next + i : fresh + (i - rem);
+			if (slot >= V.cap) { *flag = 3; continue; } // the host repeats the frame as one launch
+			const unsigned long long ck = key | ((unsigned long long)ch.digit << shift);
+			float4* sg = V.seg[(V.level + 1) & 1] + 4 * (size_t)slot;
+			sg[0] = mk4(ch.O, __int_as_float(ch.depth)), sg[1] = mk4(ch.D, __uint_as_float(sid));
+			sg[2] = mk4(ch.W, __uint_as_float((uint)ck)), sg[3] = mk4(ch.E, __uint_as_float((uint)(ck >> 32)));
+		}
+	}
+	// the shadow ray of light i for the diffuse hit kept in M (renderer.cpp:93-99); false: no light left
+	__device__ __forceinline__ bool light_step(int i, const f3& I, const f3& normal, const f3& rayD, const DMaterial& m, f3& E, const f3& direct,
+	                                           f3& O, f3& D, float& tmax, bool& nextAny) const
+	{
+		if (i >= S.nLights) return false;
+		uint unusedSeed = 0;
+		const f3 pickedPos = light_position(S.lights[i], true, unusedSeed);
+		f3 dir = pickedPos - I;
+		const float len2 = dot(dir, dir);
+		dir = normalize(dir);
+		const f3 att = diffuse_scatter(m, rayD, dir, light_intensity(S.lights[i], I, normal, pickedPos), normal, E); // before the query: E changes either way (:95-96)
+		M.E[gl] = mk4(E, 0.0f);
+		M.hN[gl] = mk4(normal, __int_as_float(i));
+		M.hA[gl] = mk4(att, 0.0f);
+		M.hS[gl] = mk4(direct, 0.0f);
+		O = I + dir * 1e-4f, D = dir, tmax = sqrtf(len2), nextAny = true;
+		return true;
+	}
+	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res0, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
+	{
+		const float4 w4 = M.W[gl], e4 = M.E[gl], l4 = M.L[gl];
+		const f3 W = xyz(w4);
+		f3 E = xyz(e4);
+		const int depth = __float_as_int(w4.w);
+		const unsigned long long key = (unsigned long long)__float_as_uint(l4.x) | ((unsigned long long)__float_as_uint(l4.y) << 32);
+		const uint sid = __float_as_uint(l4.z);
+		const f3 rayO = xyz(M.O[gl]), rayD = xyz(M.D[gl]);
+		Child a, b;
+		a.want = b.want = false, a.depth = b.depth = 0, a.digit = b.digit = 0;
+		bool go = false; // the lane goes on with a shadow query of this segment
+		nextAny = false;
+		if (!wasAny) {
+			int objIdx, matId;
+			f3 normal;
+			resolve_hit(S, res0, rayO, rayD, objIdx, matId, normal);
+			const float t = res0.t;
+			const f3 I = rayO + t * rayD;
+			const int nDepth = depth - 1;
+			const bool childTraces = nDepth > 0; // Trace(depth <= 0) = 0 (renderer.cpp:23)
+			if (objIdx == -1) log_term(work, key, sid, W * sky_color(S, rayD));
+			else if (objIdx >= 11 && objIdx < 11 + S.nLights) log_term(work, key, sid, W * light_intensity(S.lights[objIdx - 11], I, normal, I));
+			else {
+				const DMaterial m = S.mats[matId];
+				const f3 col(m.col[0], m.col[1], m.col[2]);
+				if (m.type == 3) { // GLASS, renderer.cpp:45-80
+					const float kr = glass_fresnel(normalize(rayD), normalize(normal), m.ir);
+					const bool outside = dot(rayD, normal) < 0;
+					const f3 bias = 0.0001f * normal;
+					const f3 norm = outside ? normal : -normal;
+					const float r = !outside ? m.ir : (1 / m.ir);
+					if (outside) {
+						E.x *= x_expf(m.absorption[0] * -t);
+						E.y *= x_expf(m.absorption[1] * -t);
+						E.z *= x_expf(m.absorption[2] * -t);
+					}
+					if (childTraces) {
+						if (kr < 1) {
+							a.want = true, a.digit = 1, a.depth = nDepth, a.E = E;
+							a.D = normalize(glass_refract(rayD, norm, r));
+							a.O = outside ? I - bias : I + bias;
+							const f3 tempCol = col * E;
+							a.W = W * (tempCol * (1 - kr));
+						}
+						b.want = true, b.digit = 2, b.depth = nDepth, b.E = E;
+						b.D = normalize(reflect(rayD, norm));
+						b.O = outside ? I + bias : I - bias;
+						b.W = W * (col * kr);
+					}
+				} else if (m.type == 2) { // METAL, renderer.cpp:81-86
+					if (childTraces) {
+						a.want = true, a.digit = 1, a.depth = nDepth, a.E = E;
+						a.O = I + normal * 0.001f, a.D = reflect(rayD, normal);
+						a.W = W * (col * E);
+					}
+				} else if (S.nLights > 0) { // DIFFUSE, renderer.cpp:87-122
+					M.hI[gl] = mk4(I, __int_as_float(matId));
+					go = light_step(0, I, normal, rayD, m, E, f3(0.0f), O, D, tmax, nextAny);
+				}
+			}
+		} else {
+			// the occlusion answer for light i of the diffuse hit
+			const float4 i4 = M.hI[gl], n4 = M.hN[gl], a4 = M.hA[gl], s4 = M.hS[gl];
+			const f3 I = xyz(i4), normal = xyz(n4), att = xyz(a4);
+			f3 direct = xyz(s4);
+			const int i = __float_as_int(n4.w);
+			const DMaterial m = S.mats[__float_as_int(i4.w)];
+			const f3 col(m.col[0], m.col[1], m.col[2]);
+			if (res0.kind != 1) { // visible
+				if (m.shinieness != 0 && depth - 1 > 0) { // renderer.cpp:101-102: a mirror branch per visible light
+					a.want = true, a.digit = (uint)(1 + (S.nLights - 1 - i)), a.depth = depth - 1, a.E = E;
+					a.O = I, a.D = reflect(rayD, normal);
+					a.W = W * ((m.shinieness * col) * E);
+				}
+				direct = direct + (1 - m.shinieness) * col * att * E;
+			}
+			go = light_step(i + 1, I, normal, rayD, m, E, direct, O, D, tmax, nextAny);
+			if (!go) log_term(work, key, sid, W * direct);
+		}
+		append(a, b, key, sid);
+		return go;
+	}
+};
+
 // Renderer::Sample (path mode, renderer.cpp:128-236) the same way, for batches the size of a Tick: a frame of the dense
 // wavefront (rt_stream.h) is five rounds whose traversal launches are mostly drain at 2 M samples (a path Tick of the bench
 // scene: 2.2 of 2.95 ms).  A lane keeps its sample for all five hit levels; the random stream of the sample is drawn in the
@@ -497,6 +722,44 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene
 	uint rays = 0;
 	WhittedMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], decide };
 	trace_persistent<false, false, false, WhittedMegaPolicy, true>(S, pol, M.nWork, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScene S, DCamera C, RenderParams R, MegaState M, LevelState V, int refillMin, uint* spill, int* work)
+{
+	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
+	__shared__ int reservation[RT_BLOCK / 64][2];
+	LaneCounters lc;
+	lc.clear();
+	uint rays = 0;
+	lds_int* res = (lds_int*)&reservation[threadIdx.x >> 6][0];
+	if ((threadIdx.x & 63) == 0) res[0] = 0, res[1] = 0;
+	WhittedLevelPolicy pol{ S, C, R, M, V, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], res };
+	const int n = V.level == 0 ? M.nWork : (V.count[V.level] < V.cap ? V.count[V.level] : V.cap);
+	trace_persistent<false, false, false, WhittedLevelPolicy, true>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	// the slots this wave reserved and did not fill are nothing to trace
+	const int lo = res[0] + (int)(threadIdx.x & 63), hi = res[1];
+	if (lo < hi && lo < V.cap) V.seg[(V.level + 1) & 1][4 * (size_t)lo] = make_float4(0, 0, 0, __int_as_float(-1));
+}
+// every sample's terms in key order, from 0 (the order Trace's recursion adds them in)
+__global__ void k_whitted_reduce(RenderParams R, LevelState V)
+{
+	const uint s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= R.nSamples) return;
+	f3 L(0.0f);
+	unsigned long long last = 0;
+	bool first = true;
+	for (;;) {
+		int best = -1;
+		unsigned long long bestKey = ~0ull;
+		for (int id = V.head[s]; id >= 0; id = __float_as_int(V.termVal[id].w)) {
+			const unsigned long long k = V.termKey[id];
+			if ((first || k > last) && k <= bestKey) best = id, bestKey = k;
+		}
+		if (best < 0) break;
+		L = L + xyz(V.termVal[best]);
+		last = bestKey, first = false;
+	}
+	store_sample(R, R.sampleFirst + s, L);
 }
 
 __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_path_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, uint* spill, int* work)

@@ -1119,14 +1119,17 @@ def test_whitted_single_launch_equals_rounds(name, kw, w, h, scenes, oracle_api,
 
 @pytest.mark.parametrize("name,kw,w,h", [("mixed_small", {}, 200, 83), ("pretty_tlas", {"n_instances": 4}, 192, 108)])
 def test_whitted_longest_first_order(name, kw, w, h, scenes, oracle_api, host_api, monkeypatch):
-    """The single-launch Whitted frame deals its pixels out by what they cost in the launch before (csrc/rt_mega.h "longest
-    first": k_mega_hist / k_mega_order; frames of 16384 samples and more).  Any order must give the same frame: the first
-    launch (no history: the multiplicative permutation), the second and third (history), row shards with their own histories,
-    RT_MEGA_LPT=0 and the wavefront rounds (RT_MEGA=0) all leave the same accumulator bits.  200 x 83 is not a multiple of the
-    8-pixel tile nor of the padded queue."""
+    """The single-launch Whitted frame (RT_MEGA_LEVELS=0) deals its pixels out by what they cost in the launch before
+    (csrc/rt_mega.h "longest first": k_mega_hist / k_mega_order; frames of 16384 samples and more).  Any order must give the same
+    frame: the first launch (no history: the multiplicative permutation), the second and third (history), row shards with their
+    own histories, RT_MEGA_LPT=0, the wavefront rounds (RT_MEGA=0) and the default -- one launch per tree level with the terms
+    logged under depth-first keys and added by k_whitted_reduce ("levels"; "auto", the default, times both forms on the first
+    batches of a shape and keeps the faster) -- all leave the same accumulator bits.  200 x 83 is
+    not a multiple of the 8-pixel tile nor of the padded queue."""
     frames = {}
-    for key, env in (("rounds", {"RT_MEGA": "0"}), ("plain", {"RT_MEGA_LPT": "0"}), ("lpt", {}), ("lpt_decide", {"RT_MEGA_DECIDE": "1"})):
-        for k in ("RT_MEGA", "RT_MEGA_LPT", "RT_MEGA_DECIDE"):
+    for key, env in (("rounds", {"RT_MEGA": "0"}), ("plain", {"RT_MEGA_LEVELS": "0", "RT_MEGA_LPT": "0"}), ("lpt", {"RT_MEGA_LEVELS": "0"}),
+                     ("lpt_decide", {"RT_MEGA_LEVELS": "0", "RT_MEGA_DECIDE": "1"}), ("levels", {"RT_MEGA_LEVELS": "1"}), ("auto", {})):
+        for k in ("RT_MEGA", "RT_MEGA_LPT", "RT_MEGA_DECIDE", "RT_MEGA_LEVELS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1154,7 +1157,7 @@ def test_whitted_longest_first_order(name, kw, w, h, scenes, oracle_api, host_ap
         for g in got[1:]:
             assert np.array_equal(g.view(np.uint32), got[0].view(np.uint32)), key
         frames[key] = got[0]
-    for key in ("plain", "lpt", "lpt_decide"):
+    for key in ("plain", "lpt", "lpt_decide", "levels", "auto"):
         assert np.array_equal(frames[key].view(np.uint32), frames["rounds"].view(np.uint32)), key
 
 
