@@ -551,7 +551,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		if (freeMask != 0) {
 			const int cnt = __popcll(freeMask);
 			const bool nothingLeft = TWO ? __ballot((idle || doneLane) && freeB) == ~0ull : freeMask == ~0ull;
-			if (cnt >= refillMin || nothingLeft) {
+			// (once the queue is dry there is nothing to hand out: the block is for finished lanes only -- a wave's last rays then
+			// skip it on all the iterations in which none of them finished)
+			if ((cnt >= refillMin || nothingLeft) && (TWO || !exhausted || __ballot(doneLane) != 0)) {
 				const unsigned long long secT = RT_SEC_NOW();
 				RT_SEC_COUNT(13);
 				if constexpr (TWO) {
