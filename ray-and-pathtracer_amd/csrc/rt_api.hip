@@ -99,6 +99,7 @@ struct rt_ctx {
 	                         // lane that answered its ray there idles until the next refill all the same)
 	int deferGamma = 1;      // RT_DEFER_GAMMA: path-mode samples get their gamma in k_accumulate (rt_kernels.h store_sample)
 	int megaLpt = 1;         // RT_MEGA_LPT: 0 keeps the multiplicative permutation
+	int levelDecide = 0;     // RT_LEVEL_DECIDE: the same in the launches by tree levels (level as well: 3.08 against 3.02 ms)
 	int megaDecide = 0;      // RT_MEGA_DECIDE: the flush answers queries that need no walk (measured: level, the launch is as long as its longest pixel)
 	int megaPathMax = 0;     // RT_MEGA_PATH_MAX: path batches up to this many samples run as one launch too (k_path_mega).  Off: measured slower than
 	                         // the five rounds of rt_stream.h at every size (1080p x 1: 3.33 against 3.01 ms, x 2: 4.92 / 3.88; profiles/r03_tick_time.txt)
@@ -317,6 +318,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_DECIDE_SHADOW")) c->decideShadow = atoi(getenv("RT_DECIDE_SHADOW")) != 0;
 	if (getenv("RT_DEFER_GAMMA")) c->deferGamma = atoi(getenv("RT_DEFER_GAMMA")) != 0;
 	if (getenv("RT_MEGA_DECIDE")) c->megaDecide = atoi(getenv("RT_MEGA_DECIDE")) != 0;
+	if (getenv("RT_LEVEL_DECIDE")) c->levelDecide = atoi(getenv("RT_LEVEL_DECIDE")) != 0;
 	if (getenv("RT_MEGA_PATH_MAX")) c->megaPathMax = atoi(getenv("RT_MEGA_PATH_MAX"));
 	memset(&c->M, 0, sizeof(c->M));
 	memset(&c->Qt, 0, sizeof(c->Qt));
@@ -1677,7 +1679,7 @@ static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int
 		if (level > 0) (void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		V.level = level;
 		const int grid = level == 0 ? std::min(grid0, c->gridLevel) : c->gridLevel;
-		hipLaunchKernelGGL(k_whitted_level, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M0, V, tuning(c, (c->refillMin & ~0xFF) | refill), c->spill, c->flags);
+		hipLaunchKernelGGL(k_whitted_level, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M0, V, tuning(c, (c->refillMin & ~0xFF) | refill), c->levelDecide, c->spill, c->flags);
 	}
 	hipLaunchKernelGGL(k_whitted_reduce, dim3((R.nSamples + 255) / 256), dim3(256), 0, c->stream, R, V);
 	prof_end(c);

@@ -341,6 +341,8 @@ struct WhittedLevelPolicy {
 	int gl;
 	int* flag;
 	lds_int* res; // this wave's reservation in the next level's queue: [0] next slot, [1] end
+	int decide;   // queries whose first traversal step leaves nothing to visit are answered in the flush (ray_decided)
+	mutable bool startsDone = false;
 
 	__device__ __forceinline__ bool any_of(int) const { return false; }
 	__device__ __forceinline__ bool sample_of(int work, uint& sid) const
@@ -381,8 +383,10 @@ struct WhittedLevelPolicy {
 			M.L[gl] = make_float4(s2.w, s3.w, s1.w, 0);
 		}
 		new_segment(O, D, tmax, head);
+		startsDone = decide && ray_decided(S, O, D, tmax);
 		return true;
 	}
+	__device__ __forceinline__ bool starts_done() const { return startsDone; }
 	// the one term of this segment, under its key, at the front of its sample's list
 	__device__ __forceinline__ void log_term(int work, unsigned long long key, uint sid, const f3& v) const
 	{
@@ -444,7 +448,18 @@ struct WhittedLevelPolicy {
 		O = I + dir * 1e-4f, D = dir, tmax = sqrtf(len2), nextAny = true;
 		return true;
 	}
-	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res0, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
+	// as WhittedMegaPolicy::advance: a shadow query of the light loop that needs no walk is answered at once
+	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& resIn, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
+	{
+		HitRef res = resIn;
+		for (;;) {
+			if (!advance_once(work, wasAny, res, O, D, tmax, head, nextAny)) return false;
+			if (!decide || !ray_decided(S, O, D, tmax)) return true;
+			wasAny = nextAny, res = head, res.t = tmax;
+			head.kind = -1, head.prim = 0, head.inst = -1;
+		}
+	}
+	__device__ __forceinline__ bool advance_once(int work, bool wasAny, const HitRef& res0, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
 	{
 		const float4 w4 = M.W[gl], e4 = M.E[gl], l4 = M.L[gl];
 		const f3 W = xyz(w4);
@@ -724,7 +739,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene
 	trace_persistent<false, false, false, WhittedMegaPolicy, true>(S, pol, M.nWork, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScene S, DCamera C, RenderParams R, MegaState M, LevelState V, int refillMin, uint* spill, int* work)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScene S, DCamera C, RenderParams R, MegaState M, LevelState V, int refillMin, int decide, uint* spill, int* work)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	__shared__ int reservation[RT_BLOCK / 64][2];
@@ -733,7 +748,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScen
 	uint rays = 0;
 	lds_int* res = (lds_int*)&reservation[threadIdx.x >> 6][0];
 	if ((threadIdx.x & 63) == 0) res[0] = 0, res[1] = 0;
-	WhittedLevelPolicy pol{ S, C, R, M, V, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], res };
+	WhittedLevelPolicy pol{ S, C, R, M, V, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], res, decide };
 	const int n = V.level == 0 ? M.nWork : (V.count[V.level] < V.cap ? V.count[V.level] : V.cap);
 	trace_persistent<false, false, false, WhittedLevelPolicy, true>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	// the slots this wave reserved and did not fill are nothing to trace

@@ -1128,8 +1128,8 @@ def test_whitted_longest_first_order(name, kw, w, h, scenes, oracle_api, host_ap
     not a multiple of the 8-pixel tile nor of the padded queue."""
     frames = {}
     for key, env in (("rounds", {"RT_MEGA": "0"}), ("plain", {"RT_MEGA_LEVELS": "0", "RT_MEGA_LPT": "0"}), ("lpt", {"RT_MEGA_LEVELS": "0"}),
-                     ("lpt_decide", {"RT_MEGA_LEVELS": "0", "RT_MEGA_DECIDE": "1"}), ("levels", {"RT_MEGA_LEVELS": "1"}), ("auto", {})):
-        for k in ("RT_MEGA", "RT_MEGA_LPT", "RT_MEGA_DECIDE", "RT_MEGA_LEVELS"):
+                     ("lpt_decide", {"RT_MEGA_LEVELS": "0", "RT_MEGA_DECIDE": "1"}), ("levels", {"RT_MEGA_LEVELS": "1"}), ("levels_decide", {"RT_MEGA_LEVELS": "1", "RT_LEVEL_DECIDE": "1"}), ("auto", {})):
+        for k in ("RT_MEGA", "RT_MEGA_LPT", "RT_MEGA_DECIDE", "RT_MEGA_LEVELS", "RT_LEVEL_DECIDE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1157,7 +1157,7 @@ def test_whitted_longest_first_order(name, kw, w, h, scenes, oracle_api, host_ap
         for g in got[1:]:
             assert np.array_equal(g.view(np.uint32), got[0].view(np.uint32)), key
         frames[key] = got[0]
-    for key in ("plain", "lpt", "lpt_decide", "levels", "auto"):
+    for key in ("plain", "lpt", "lpt_decide", "levels", "levels_decide", "auto"):
         assert np.array_equal(frames[key].view(np.uint32), frames["rounds"].view(np.uint32)), key
 
 
