@@ -1161,6 +1161,44 @@ def test_whitted_longest_first_order(name, kw, w, h, scenes, oracle_api, host_ap
         assert np.array_equal(frames[key].view(np.uint32), frames["rounds"].view(np.uint32)), key
 
 
+@pytest.mark.parametrize("name,kw,w,h", [("mixed_small", {}, 97, 61), ("pretty_tlas", {"n_instances": 4}, 120, 67), ("scene3", {"force_diffuse": False}, 96, 54),
+                                         ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 101, 57)])
+def test_whitted_levels_depths_and_batches(name, kw, w, h, scenes, host_api, monkeypatch):
+    """Renderer::Trace by tree levels (csrc/rt_mega.h k_whitted_level / k_whitted_reduce, RT_MEGA_LEVELS=1) against the
+    wavefront rounds (RT_MEGA=0) at every depth from 1 (no children at all) to 7 (more levels than the default 4; keys of
+    seven digits), for two frames (Whitted frames overwrite the accumulator: one per call), full frames and interleaved row
+    shards: identical accumulator bits."""
+    out = {}
+    for key, env in (("rounds", {"RT_MEGA": "0"}), ("levels", {"RT_MEGA_LEVELS": "1"})):
+        for k in ("RT_MEGA", "RT_MEGA_LEVELS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = host_api.HostRenderer(w, h)
+        d = scenes.REGISTRY[name](r.scene, **kw)
+        r.commit()
+        if "camera" in d:
+            c = d["camera"]
+            r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+        got = []
+        for depth in (1, 2, 3, 4, 7):
+            for frame0 in (5, 6):
+                r.clear()
+                r.render(host_api.RT_MODE_WHITTED, frame0, 1, max_depth=depth)
+                got.append(r.accumulator().copy())
+            r.clear()
+            r.render_rows(host_api.RT_MODE_WHITTED, 5, 1, 0, 3, (h + 2) // 3, max_depth=depth)
+            r.render_rows(host_api.RT_MODE_WHITTED, 5, 1, 1, 3, (h + 1) // 3, max_depth=depth)
+            r.render_rows(host_api.RT_MODE_WHITTED, 5, 1, 2, 3, h // 3, max_depth=depth)
+            got.append(r.accumulator().copy())
+        r.close()
+        out[key] = got
+    for i, (a, b) in enumerate(zip(out["rounds"], out["levels"])):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+    for k in range(0, len(out["levels"]), 3):  # the shards of a depth give its single frame
+        assert np.array_equal(out["levels"][k].view(np.uint32), out["levels"][k + 2].view(np.uint32)), k
+
+
 @pytest.mark.parametrize("name,kw,w,h,box", [("mixed_small", {}, 64, 40, ((-4, -1, -4), (4, 5, 6))), ("pretty_tlas", {"n_instances": 4}, 96, 54, ((-6, -1.5, -1), (8, 5, 10))),
                                              ("tlas_test2", {}, 64, 40, ((-6, -1, -2), (6, 7, 8))),
                                              ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 96, 54, ((-12, -2, -8), (12, 10, 16)))])  # BASELINE config 5's layout ("Q-learning sampler on")
