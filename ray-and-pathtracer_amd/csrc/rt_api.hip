@@ -1672,6 +1672,8 @@ static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int
 		c->V = V, c->levelCap = cap, c->levelLevels = levels, c->levelSamples = (size_t)R.nSamples;
 	}
 	LevelState V = c->V;
+	V.qcap = V.cap;
+	if (getenv("RT_LEVEL_CAP") && atoi(getenv("RT_LEVEL_CAP")) >= 64 && atoi(getenv("RT_LEVEL_CAP")) < V.cap) V.qcap = atoi(getenv("RT_LEVEL_CAP")) & ~63; // tests: queues that overflow
 	(void)hipMemsetAsync(V.count, 0, (RT_LEVEL_MAX + 2) * sizeof(int), c->stream);
 	(void)hipMemsetAsync(V.head, 0xFF, (size_t)R.nSamples * sizeof(int), c->stream);
 	prof_begin(c, K_EXTEND);

@@ -327,6 +327,7 @@ struct LevelState {
 	float4* termVal;             // [level][cap] xyz, w = the sample's term logged before this one (int, -1: none)
 	int* head;                   // [sample of the batch] the sample's most recent term, -1: none
 	int cap;                     // segments per queue = terms per level
+	int qcap;                    // queue slots in use (= cap; tests make it smaller: a queue that overflows)
 	int level;
 };
 typedef __attribute__((address_space(3))) int lds_int;
@@ -423,7 +424,7 @@ struct WhittedLevelPolicy {
 			if (!ch.want) continue;
 			const int i = k ? na + __popcll(mb & below) : __popcll(ma & below);
 			const int slot = i < rem ? next + i : fresh + (i - rem);
-			if (slot >= V.cap) { *flag = 3; continue; } // the host repeats the frame as one launch
+			if (slot >= V.qcap) { *flag = 3; continue; } // the host repeats the frame as one launch
 			const unsigned long long ck = key | ((unsigned long long)ch.digit << shift);
 			float4* sg = V.seg[(V.level + 1) & 1] + 4 * (size_t)slot;
 			sg[0] = mk4(ch.O, __int_as_float(ch.depth)), sg[1] = mk4(ch.D, __uint_as_float(sid));
@@ -749,11 +750,11 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScen
 	lds_int* res = (lds_int*)&reservation[threadIdx.x >> 6][0];
 	if ((threadIdx.x & 63) == 0) res[0] = 0, res[1] = 0;
 	WhittedLevelPolicy pol{ S, C, R, M, V, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], res, decide };
-	const int n = V.level == 0 ? M.nWork : (V.count[V.level] < V.cap ? V.count[V.level] : V.cap);
+	const int n = V.level == 0 ? M.nWork : (V.count[V.level] < V.qcap ? V.count[V.level] : V.qcap);
 	trace_persistent<false, false, false, WhittedLevelPolicy, true>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	// the slots this wave reserved and did not fill are nothing to trace
 	const int lo = res[0] + (int)(threadIdx.x & 63), hi = res[1];
-	if (lo < hi && lo < V.cap) V.seg[(V.level + 1) & 1][4 * (size_t)lo] = make_float4(0, 0, 0, __int_as_float(-1));
+	if (lo < hi && lo < V.qcap) V.seg[(V.level + 1) & 1][4 * (size_t)lo] = make_float4(0, 0, 0, __int_as_float(-1));
 }
 // every sample's terms in key order, from 0 (the order Trace's recursion adds them in)
 __global__ void k_whitted_reduce(RenderParams R, LevelState V)

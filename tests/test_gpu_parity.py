@@ -1169,8 +1169,8 @@ def test_whitted_levels_depths_and_batches(name, kw, w, h, scenes, host_api, mon
     seven digits), for two frames (Whitted frames overwrite the accumulator: one per call), full frames and interleaved row
     shards: identical accumulator bits."""
     out = {}
-    for key, env in (("rounds", {"RT_MEGA": "0"}), ("levels", {"RT_MEGA_LEVELS": "1"})):
-        for k in ("RT_MEGA", "RT_MEGA_LEVELS"):
+    for key, env in (("rounds", {"RT_MEGA": "0"}), ("levels", {"RT_MEGA_LEVELS": "1"}), ("levels_overflow", {"RT_MEGA_LEVELS": "1", "RT_LEVEL_CAP": "256"})):
+        for k in ("RT_MEGA", "RT_MEGA_LEVELS", "RT_LEVEL_CAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1194,6 +1194,9 @@ def test_whitted_levels_depths_and_batches(name, kw, w, h, scenes, host_api, mon
         r.close()
         out[key] = got
     for i, (a, b) in enumerate(zip(out["rounds"], out["levels"])):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+    # queues of 256 segments: every frame with more children than that overflows them and is repeated as one launch
+    for i, (a, b) in enumerate(zip(out["rounds"], out["levels_overflow"])):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
     for k in range(0, len(out["levels"]), 3):  # the shards of a depth give its single frame
         assert np.array_equal(out["levels"][k].view(np.uint32), out["levels"][k + 2].view(np.uint32)), k
