@@ -1590,7 +1590,7 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 		A.ms[probe] = ms, A.tried[probe]++;
 		if (A.tried[0] >= 2 && A.tried[1] >= 2) A.choice = A.ms[1] < A.ms[0] ? 1 : 0;
 	};
-	if (c->megaLpt && R.mode == RT_MODE_WHITTED && R.permMul && !R.customO && !useLevels) {
+	if (c->megaLpt && R.mode == RT_MODE_WHITTED && R.permMul && !R.customO) {
 		const unsigned tilesPerHead = RT_HEADS * 8u; // sub-queues of n / RT_HEADS entries, a multiple of 64 entries = 8 tiles of 8
 		const unsigned nTiles = (R.nSamples + (1u << R.permShift) - 1) >> R.permShift;
 		const unsigned unit = tilesPerHead * (64u >> R.permShift ? 64u >> R.permShift : 1u) / 8u;
@@ -1619,10 +1619,7 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 	const int refillMega = getenv("RT_REFILL_MEGA") && atoi(getenv("RT_REFILL_MEGA")) > 0 && atoi(getenv("RT_REFILL_MEGA")) <= 64 ? atoi(getenv("RT_REFILL_MEGA")) : 32;
 	if (useLevels) {
 		bool redo = false;
-		MegaState ML = M;
-		ML.cost = nullptr, ML.order = nullptr;
-		ML.nWork = (int)(((R.nSamples + (1u << R.permShift) - 1) >> R.permShift) << R.permShift);
-		const int rc = run_levels(c, R, ML, grid, refillMega, &redo);
+		const int rc = run_levels(c, R, M, grid, refillMega, &redo); // level 0 deals its tiles out like the single launch (M.order), and records what they cost
 		if (rc != RT_OK || !redo) { probe_end(); return rc; }
 		probe = -1, c->megaAuto.choice = 0; // this scene overflows the level queues: the single launch from now on
 		// a queue overflowed (more than two live branches per sample on average): the frame again, as one launch

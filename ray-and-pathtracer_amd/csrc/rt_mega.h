@@ -349,7 +349,8 @@ struct WhittedLevelPolicy {
 	__device__ __forceinline__ bool sample_of(int work, uint& sid) const
 	{
 		uint w = (uint)work;
-		if (R.permMul) {
+		if (M.order) w = (M.order[w >> R.permShift] << R.permShift) + (w & ((1u << R.permShift) - 1)); // longest first, as the single launch
+		else if (R.permMul) {
 			const uint sh = R.permShift, nTiles = (R.nSamples + (1u << sh) - 1) >> sh;
 			w = ((uint)(((unsigned long long)(w >> sh) * R.permMul) % nTiles) << sh) + (w & ((1u << sh) - 1));
 		}
@@ -373,7 +374,7 @@ struct WhittedLevelPolicy {
 			sample_primary(C, R, sid, O, D, seed);
 			M.W[gl] = make_float4(1, 1, 1, __int_as_float(start_depth(R)));
 			M.E[gl] = make_float4(1, 1, 1, 0);
-			M.L[gl] = make_float4(0, 0, __uint_as_float(sid), 0); // key 0
+			M.L[gl] = make_float4(0, 0, __uint_as_float(sid), __uint_as_float((uint)__builtin_amdgcn_s_memrealtime())); // key 0; w: when the lane took the sample
 		} else {
 			const float4* sg = V.seg[V.level & 1] + 4 * (size_t)work;
 			const float4 s0 = sg[0], s1 = sg[1], s2 = sg[2], s3 = sg[3];
@@ -454,7 +455,14 @@ struct WhittedLevelPolicy {
 	{
 		HitRef res = resIn;
 		for (;;) {
-			if (!advance_once(work, wasAny, res, O, D, tmax, head, nextAny)) return false;
+			if (!advance_once(work, wasAny, res, O, D, tmax, head, nextAny)) {
+				// level 0: how long the lane held the camera ray and its light loop -- the next frame's order (k_mega_order)
+				if (V.level == 0 && M.cost) {
+					const float4 l4 = M.L[gl];
+					M.cost[__float_as_uint(l4.z) - R.sampleFirst] = (uint)__builtin_amdgcn_s_memrealtime() - __float_as_uint(l4.w);
+				}
+				return false;
+			}
 			if (!decide || !ray_decided(S, O, D, tmax)) return true;
 			wasAny = nextAny, res = head, res.t = tmax;
 			head.kind = -1, head.prim = 0, head.inst = -1;
