@@ -73,7 +73,7 @@ def main():
         o["hbm_bytes_per_launch"] = int(o["hbm_bytes"] / launches)
         o["lane_ops_per_launch"] = o["lane_ops"] / launches
         out["kernels"][g] = o
-    path = os.path.join(ROOT, "profiles", "roofline_pmc.json")
+    path = os.environ.get("RT_ROOFLINE_PMC_OUT") or os.path.join(ROOT, "profiles", "roofline_pmc.json")
     try:
         allw = json.load(open(path))
         if "by_world" not in allw:

@@ -75,6 +75,8 @@ struct rt_ctx {
 	hipStream_t streamSide = nullptr;
 	uint* streamSideSpill = nullptr;
 	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
+	bool gateBroken = false; // a k_gate launch timed out: this context's two streams do not overlap, no more gating
+	unsigned long long gateWaits = 0, gateTimeouts = 0; // rt_get_gate_stats
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
@@ -1186,11 +1188,11 @@ int rt_build_tlas(rt_ctx* c, const float* bounds6, uint32_t n, rt_tlas_node* nod
 
 int rt_set_time(rt_ctx* c, float t)
 {
-	if (c) c->S.wide8 = nullptr; // the quantised boxes were rounded around the uploaded geometry: a refitted tree is walked through the exact nodes
 	if (!c) return RT_E_ARG;
 	if (!c->sceneLoaded) return fail(c, RT_E_STATE, "rt_set_time: no scene uploaded");
 	if (c->S.useTLAS) return fail(c, RT_E_UNSUPPORTED, "rt_set_time: the reference animates only without the TLAS (animOn, template/scene.h:1389)");
 	if (!c->primsOrig) return RT_OK; // nothing to animate
+	c->S.wide8 = nullptr; // the quantised boxes were rounded around the uploaded geometry: a refitted tree is walked through the exact nodes
 	HIPCHK(c, hipSetDevice(c->device));
 	// float r = fmodf(t, 2 * PI); float a = sinf(r) * 0.5f;  (template/scene.h:1229-1230; sinf in f64, rounded once)
 	const float r = fmodf(t, 2 * RT_PI);
@@ -1545,7 +1547,7 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 		R.permMul = p;
 	}
 	const int gridMax = R.mode == RT_MODE_WHITTED ? c->gridMega : c->gridMegaPath;
-	const int lanes = std::max(c->gridMega, c->gridMegaPath) * RT_BLOCK;
+	const int lanes = std::max(std::max(c->gridMega, c->gridMegaPath), c->gridLevel) * RT_BLOCK; // run_levels indexes the same arrays by lane of ITS grid
 	if (c->megaLanes < lanes) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		free_pool(c->megaAllocs);
@@ -1593,7 +1595,8 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 	if (c->megaLpt && R.mode == RT_MODE_WHITTED && R.permMul && !R.customO) {
 		const unsigned tilesPerHead = RT_HEADS * 8u; // sub-queues of n / RT_HEADS entries, a multiple of 64 entries = 8 tiles of 8
 		const unsigned nTiles = (R.nSamples + (1u << R.permShift) - 1) >> R.permShift;
-		const unsigned unit = tilesPerHead * (64u >> R.permShift ? 64u >> R.permShift : 1u) / 8u;
+		// k_mega_order's slot mapping is a bijection only when groups = nTilesPad / 8 is a multiple of RT_HEADS: pad to 8 * RT_HEADS tiles whatever the tile size
+		const unsigned unit = std::max(tilesPerHead * (64u >> R.permShift ? 64u >> R.permShift : 1u) / 8u, 8u * RT_HEADS);
 		const unsigned nTilesPad = (nTiles + unit - 1) / unit * unit;
 		if (c->megaCostCap < (size_t)R.nSamples) {
 			HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1783,7 +1786,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	const bool mixed = !c->counting && !c->twoRays && (c->fuseTraversal == 1 || (c->fuseTraversal < 0 && R.nSamples < mixedMax)) &&
 	                   (unsigned long long)R.nSamples * (unsigned)(c->S.nLights + 1) < 0x7FFFFFFFull;
 	const bool twoStreams = !mixed && (c->fuseTraversal < 0 ? R.nSamples < 100000000u : c->fuseTraversal != 0);
-	const bool gated = twoStreams && (c->fuseTraversal < 0 || c->fuseTraversal == 3); // connect(r) + light(r) wait at a gate that extend(r + 1) opens when its queue runs dry
+	const bool gated = twoStreams && !c->gateBroken && (c->fuseTraversal < 0 || c->fuseTraversal == 3); // connect(r) + light(r) wait at a gate that extend(r + 1) opens when its queue runs dry
 	const StreamState& T = c->T;
 	hipStream_t st = c->stream, sb = twoStreams ? c->streamSide : c->stream;
 	const int cnt = c->counting ? 1 : 0;
@@ -1792,8 +1795,22 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	hipLaunchKernelGGL(k_generate_s, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, rounds == 1 ? 1 : 0, c->decideRays, cnt);
 	prof_end(c, st);
 	bool pendingJoin = false;
+	int sideRound = -1; // connect + light of this round still have to be submitted to the second stream
+	hipError_t sideErr = hipSuccess;
+	auto side_launch = [&](int r, bool gate) {
+		const int lastR = r + 1 == rounds ? 1 : 0;
+		if (twoStreams) { const hipError_t e = hipStreamWaitEvent(sb, c->streamFork, 0); if (e != hipSuccess) sideErr = e; }
+		if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sb, T.counts, r + 2); // opened by extend(r + 1), already submitted on the main stream
+		prof_begin(c, K_CONNECT, sb);
+		launch_connect_s(c, sb, T, r, twoStreams ? c->streamSideSpill : c->spill, twoStreams ? c->sideSpill2 : c->spill2);
+		prof_end(c, sb);
+		prof_begin(c, K_SHADE, sb);
+		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, r, lastR, c->shadeLds);
+		prof_end(c, sb);
+		if (twoStreams) { const hipError_t e = hipEventRecord(c->streamJoin, sb); if (e != hipSuccess) sideErr = e; pendingJoin = true; }
+	};
 	for (int round = 0; round < rounds; round++) {
-		const int parity = round & 1, last = round + 1 == rounds ? 1 : 0, lastNext = round + 2 == rounds ? 1 : 0;
+		const int last = round + 1 == rounds ? 1 : 0, lastNext = round + 2 == rounds ? 1 : 0;
 		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 #ifdef RT_TAIL_PROBE
 		tail_probe_reset(st);
@@ -1801,14 +1818,20 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		prof_begin(c, K_EXTEND, st);
 		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin) | (c->decideShadow ? RT_TUNE_DECIDE_SHADOW : 0), c->spill);
 		else if ((c->twoRays & 1) && c->S.stackRows2 > 0) {
-			if (c->counting) hipLaunchKernelGGL((k_extend_s2<true>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
-			else hipLaunchKernelGGL((k_extend_s2<false>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
-		} else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
-		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, parity, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+			if (c->counting) hipLaunchKernelGGL((k_extend_s2<true>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
+			else hipLaunchKernelGGL((k_extend_s2<false>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
+		} else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		prof_end(c, st);
 #ifdef RT_TAIL_PROBE
 		tail_probe_print(st, "extend_s", round);
 #endif
+		if (sideRound >= 0) {
+			// connect + light of the round before, on the second stream: submitted only now, BEHIND extend(round), so that the gate
+			// can never sit in front of the kernel that opens it (two HIP streams may share one hardware queue)
+			side_launch(sideRound, gated);
+			sideRound = -1;
+		}
 		if (mixed && round > 0) { // the shadow answers of the round before came with this round's hits
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, st, c->S, R, T, round - 1, 0, c->shadeLds);
@@ -1821,24 +1844,21 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		else hipLaunchKernelGGL(k_shade_s<false>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt, c->Qt);
 		prof_end(c, st);
 		if (mixed && !last) continue; // this round's shadow rays ride in the next round's traversal launch
-		if (twoStreams) {
-			HIPCHK(c, hipEventRecord(c->streamFork, st));
-			HIPCHK(c, hipStreamWaitEvent(sb, c->streamFork, 0));
-		}
-		if (gated && !last) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sb, T.counts); // opened by extend(round + 1), launched below on the main stream
-		prof_begin(c, K_CONNECT, sb);
-		launch_connect_s(c, sb, T, round, twoStreams ? c->streamSideSpill : c->spill, twoStreams ? c->sideSpill2 : c->spill2);
-		prof_end(c, sb);
-		prof_begin(c, K_SHADE, sb);
-		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, round, last, c->shadeLds);
-		prof_end(c, sb);
-		if (twoStreams) { HIPCHK(c, hipEventRecord(c->streamJoin, sb)); pendingJoin = true; }
+		if (twoStreams) HIPCHK(c, hipEventRecord(c->streamFork, st));
+		if (twoStreams && !last) sideRound = round; // submitted behind extend(round + 1)
+		else side_launch(round, false);
 	}
+	if (sideErr != hipSuccess) return fail(c, RT_E_HIP, "second stream of the round loop: %s", hipGetErrorString(sideErr));
 	if (pendingJoin) HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0));
 	if (cnt) hipLaunchKernelGGL(k_fold_decided, dim3(1), dim3(1), 0, st, c->S, T.counts, c->counters);
-	HIPCHK(c, hipMemcpyAsync(c->hostCounts, T.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipMemcpyAsync(c->hostCounts, T.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
 	HIPCHK(c, hipStreamSynchronize(st));
 	const int* hc = c->hostCounts;
+	if (gated) {
+		c->gateWaits += (unsigned long long)hc[SC_GATE_WAITS], c->gateTimeouts += (unsigned long long)hc[SC_GATE_TIMEOUTS];
+		if (hc[SC_GATE_TIMEOUTS] > 0) c->gateBroken = true; // the two streams did not run side by side: both streams at once (RT_FUSE=2) from now on
+		if (hc[SC_GATE_WAITS] | hc[SC_GATE_TIMEOUTS]) (void)hipMemsetAsync(T.counts + SC_GATE_WAITS, 0, 2 * sizeof(int), st);
+	}
 	int rc = RT_OK;
 	if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 	else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
@@ -2397,6 +2417,7 @@ int rt_qlearn_apply(rt_ctx* c)
 int rt_qlearn_get_sums(rt_ctx* c, int64_t* sums, uint32_t* counts)
 {
 	if (!c || !c->Qt.on || !sums || !counts) return fail(c, RT_E_STATE, "rt_qlearn_get_sums: the sampler is off, or a null argument");
+	HIPCHK(c, hipSetDevice(c->device));
 	const size_t n = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipMemcpy(sums, c->Qt.sum, n * 8, hipMemcpyDeviceToHost));
@@ -2406,6 +2427,7 @@ int rt_qlearn_get_sums(rt_ctx* c, int64_t* sums, uint32_t* counts)
 int rt_qlearn_set_sums(rt_ctx* c, const int64_t* sums, const uint32_t* counts)
 {
 	if (!c || !c->Qt.on || !sums || !counts) return fail(c, RT_E_STATE, "rt_qlearn_set_sums: the sampler is off, or a null argument");
+	HIPCHK(c, hipSetDevice(c->device));
 	const size_t n = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipMemcpy(c->Qt.sum, sums, n * 8, hipMemcpyHostToDevice));
@@ -2415,6 +2437,7 @@ int rt_qlearn_set_sums(rt_ctx* c, const int64_t* sums, const uint32_t* counts)
 int rt_qlearn_get_table(rt_ctx* c, float* q_out)
 {
 	if (!c || !c->Qt.on || !q_out) return fail(c, RT_E_STATE, "rt_qlearn_get_table: the sampler is off, or a null argument");
+	HIPCHK(c, hipSetDevice(c->device));
 	const size_t cells = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid;
 	std::vector<float> rows(cells * RT_Q_ROW);
 	HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2445,6 +2468,14 @@ const char* rt_tuning_info(rt_ctx* c)
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();
+}
+
+int rt_get_gate_stats(rt_ctx* c, uint64_t* waits, uint64_t* timeouts)
+{
+	if (!c) return RT_E_ARG;
+	if (waits) *waits = c->gateWaits;
+	if (timeouts) *timeouts = c->gateTimeouts;
+	return RT_OK;
 }
 
 int rt_synchronize(rt_ctx* c)

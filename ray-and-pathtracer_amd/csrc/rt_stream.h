@@ -51,7 +51,9 @@ namespace rtd {
 #define SC_TRACE 7   // length of the traversal queue
 #define SC_LEFTOVER 8 // shadow rays the 4-wide walk handed back
 #define SC_DECIDED 9 // rays answered by their producer (counting launches)
-#define SC_GATE 10   // set by extend when its queue runs dry: k_gate lets connect of the round before start then
+#define SC_GATE 10   // round + 1 of the last extend launch of this batch that found its queue dry: k_gate(r) lets connect(r) start at r + 2
+#define SC_GATE_WAITS 11    // k_gate launches that found the gate closed when they started (they really waited)
+#define SC_GATE_TIMEOUTS 12 // k_gate launches that gave up (the two streams did not run side by side): the host stops gating
 
 struct StreamState {
 	float4* O[2];     // ray origin xyz, w = ray.t after the head tests        } entry e of round parity p
@@ -175,26 +177,32 @@ __global__ void k_fold_decided(DScene S, int* counts, DCounters* counters)
 __device__ __forceinline__ void prepare_round(const StreamState& T, int next /* the round being prepared */, int n0)
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0) return;
-	if (n0 >= 0) T.counts[SC_N + next % 3] = n0; // generate: the batch's samples are round 0's entries
+	if (n0 >= 0) T.counts[SC_N + next % 3] = n0, T.counts[SC_GATE] = 0; // generate: the batch's samples are round 0's entries; no extend of this batch has run dry yet
 	T.counts[SC_TRACE] = 0, T.counts[SC_N + (next + 1) % 3] = 0, T.counts[SC_SHADOW + next % 3] = 0;
 	for (int h = 0; h < RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
 	// connect of the round before 'next' (it starts after the kernel this runs in)
 	T.counts[SC_LEFTOVER] = 0;
 	for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
 }
-// The gate of the second stream (RT_FUSE=3): one wave waits until extend(r) has found its queue dry, then connect(r - 1) and
-// light(r - 1) -- queued behind this kernel -- fill the drain of extend(r): its longest rays finish alone for 0.5-0.9 ms whatever
+// The gate of the second stream (RT_FUSE=3): one wave waits until extend(r + 1) has found its queue dry, then connect(r) and
+// light(r) -- queued behind this kernel -- fill the drain of extend(r + 1): its longest rays finish alone for 0.5-0.9 ms whatever
 // the launch held, with the machine all but idle (profiles/r03_ab_stream_fuse.txt).  Started together (RT_FUSE=2) the two
 // persistent kernels share the machine for their whole length and both run longer; one after the other (RT_FUSE=0) every drain
-// is paid in full.  The wait is bounded (2 s of the 100 MHz clock): a launch that never opens the gate must not hang the stream.
-__global__ void k_gate(int* counts)
+// is paid in full.  Every extend launch publishes its round + 1 when it runs dry (StreamExtendPolicy::queue_dry; generate zeroes
+// the word at the start of a batch), and gate(r) waits for a value >= r + 2: what extend(r) or an earlier batch left there
+// cannot open it.  The host submits gate(r) AFTER extend(r + 1), so streams that share a hardware queue cannot put the waiter in
+// front of the kernel it waits for.  The wait is bounded (50 ms of the 100 MHz clock; a gated batch's extend launch takes a
+// few ms): a timeout is counted, the host reads the count with the batch's flags and stops gating for this context.
+__global__ void k_gate(int* counts, int want)
 {
 	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-	while (__hip_atomic_load(&counts[SC_GATE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+	bool waited = false;
+	while (__hip_atomic_load(&counts[SC_GATE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+		waited = true;
 		__builtin_amdgcn_s_sleep(64);
-		if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+		if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) { if (threadIdx.x == 0) counts[SC_GATE_TIMEOUTS]++; break; }
 	}
-	__hip_atomic_store(&counts[SC_GATE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (waited && threadIdx.x == 0) counts[SC_GATE_WAITS]++;
 }
 // connect's work heads alone: the leftover launch of the 4-wide walk goes through its own list with them
 __global__ void k_stream_begin(StreamState T)
@@ -250,11 +258,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_s(DScene S, DCamera C, Re
 // extend: Scene::FindNearest for the entries of the traversal queue
 struct StreamExtendPolicy {
 	static constexpr bool kSignalsDry = true;
-	__device__ __forceinline__ void queue_dry() const { __hip_atomic_store(&T.counts[SC_GATE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	__device__ __forceinline__ void queue_dry() const { __hip_atomic_store(&T.counts[SC_GATE], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 	const DScene& S;
 	const StreamState& T;
 	int parity, last;
 	int* flag;
+	int round;
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
 	{
 		const int e = (int)ld_stream(T.traceQ + work);
@@ -279,13 +288,13 @@ struct StreamExtendPolicy {
 	}
 };
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S, StreamState T, int parity, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S, StreamState T, int round, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	StreamExtendPolicy pol{ S, T, parity, last, &T.counts[SC_FLAG] };
+	StreamExtendPolicy pol{ S, T, round & 1, last, &T.counts[SC_FLAG], round };
 	trace_persistent<false, COUNT, false>(S, pol, T.counts[SC_TRACE], T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) {
 		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
@@ -298,13 +307,13 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S
 #define RT_TWO_WAVES 5
 #endif
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_extend_s2(DScene S, StreamState T, int parity, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_extend_s2(DScene S, StreamState T, int round, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS2];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	StreamExtendPolicy pol{ S, T, parity, last, &T.counts[SC_FLAG] };
+	StreamExtendPolicy pol{ S, T, round & 1, last, &T.counts[SC_FLAG], round };
 	trace_persistent<false, COUNT, false, StreamExtendPolicy, false, false, RT_PAIR_REPEAT, true>(S, pol, T.counts[SC_TRACE], T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) {
 		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
@@ -696,7 +705,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DSce
 	lc.clear();
 	uint rays = 0;
 	const int nTrace = T.counts[SC_TRACE], nShadow = T.counts[SC_SHADOW + (round + 2) % 3]; // the shadow records of round - 1
-	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG] }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG], (refillMin & RT_TUNE_DECIDE_SHADOW) ? &S : nullptr }, nTrace };
+	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG], round }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG], (refillMin & RT_TUNE_DECIDE_SHADOW) ? &S : nullptr }, nTrace };
 	trace_persistent<false, false, false, StreamTraversePolicy, true>(S, pol, nTrace + nShadow * S.nLights, T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 }
 

@@ -1088,6 +1088,34 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), other
 
 
+def test_gate_of_the_second_stream_really_waits(scenes, host_api, monkeypatch):
+    """RT_FUSE=3 (csrc/rt_stream.h k_gate): connect(r) + light(r) wait on the second stream until extend(r + 1) has found its queue
+    dry.  Round 3's gate never waited (a flag every extend launch set and only the gate cleared: ADVICE.md r3); now every extend
+    publishes its round + 1, gate(r) waits for r + 2 and is submitted behind extend(r + 1).  The library counts the gate launches
+    that found the gate closed and those that timed out: with extend launches of a few hundred microseconds the gates of a batch
+    must have waited, none may time out, and the frame is the serial loop's bit for bit."""
+    frames = {}
+    for fuse in ("0", "3"):
+        monkeypatch.setenv("RT_FUSE", fuse)
+        r = host_api.HostRenderer(640, 360)
+        d = scenes.REGISTRY["pretty_tlas"](r.scene, n_instances=4)
+        r.commit()
+        c = d["camera"]
+        r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+        for rep in range(2):  # the second batch starts with whatever the first left in the gate word
+            r.clear()
+            r.render(host_api.RT_MODE_PATH, 0, 8)  # 1.8 M samples per batch
+        frames[fuse] = r.accumulator().copy()
+        waits, timeouts = r.gate_stats()
+        if fuse == "3":
+            assert timeouts == 0, "a gate timed out: the two streams do not overlap on this box"
+            assert waits >= 4, "gates of two 5-round batches that never waited: %d" % waits
+        else:
+            assert (waits, timeouts) == (0, 0)
+        r.close()
+    assert np.array_equal(frames["0"].view(np.uint32), frames["3"].view(np.uint32))
+
+
 @pytest.mark.parametrize("name,kw,w,h", [("mixed_small", {}, 96, 64), ("pretty_tlas", {"n_instances": 4}, 160, 90), ("scene3", {"force_diffuse": False}, 96, 54),
                                          ("background", {}, 120, 80), ("tower", {}, 120, 68), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72)])
 def test_whitted_single_launch_equals_rounds(name, kw, w, h, scenes, oracle_api, host_api, monkeypatch):
