@@ -109,9 +109,6 @@ struct rt_ctx {
 	// Q-learning guided sampling (rt_qlearn.h)
 	QTable Qt;
 	std::vector<void*> qAllocs;
-	int twoRays = 0;         // RT_TWO: the stream pipeline's traversal kernels carry two rays per lane (trace_persistent<TWO>): bit 0 extend, bit 1 connect
-	int gridExtendS2 = 0, gridConnectS2 = 0;
-	uint* spill2 = nullptr; uint* sideSpill2 = nullptr; // their spill columns (two per lane)
 	int shadeLds = 1;        // RT_SHADE_LDS: the shading kernels keep the material / brute-force primitive tables in LDS
 	int gridShadeS = 0, gridLightS = 0; // resident blocks of the grid-stride shading kernels (a second, partial round of blocks would run at low occupancy)
 	int decideRays = 1;      // RT_DECIDE: producers answer rays whose first traversal step leaves nothing to visit (rt_stream.h ray_decided)
@@ -324,7 +321,6 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_MEGA_PATH_MAX")) c->megaPathMax = atoi(getenv("RT_MEGA_PATH_MAX"));
 	memset(&c->M, 0, sizeof(c->M));
 	memset(&c->Qt, 0, sizeof(c->Qt));
-	if (getenv("RT_TWO")) c->twoRays = atoi(getenv("RT_TWO")) & 3;
 	if (getenv("RT_SHADE_LDS")) c->shadeLds = atoi(getenv("RT_SHADE_LDS")) != 0;
 	memset(&c->T, 0, sizeof(c->T));
 	if (c->nPoolsWanted < 1) c->nPoolsWanted = 1;
@@ -354,8 +350,6 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridLeftoverS = std::min(resident((const void*)k_connect_s<false, false, true>), prop.multiProcessorCount);
 		c->gridConnectWide8S = resident((const void*)k_connect_s<false, false, false, true>);
 		c->gridTraverseS = resident((const void*)k_traverse_s);
-		c->gridExtendS2 = std::min(resident((const void*)k_extend_s2<false>), resident((const void*)k_extend_s2<true>));
-		c->gridConnectS2 = std::min(resident((const void*)k_connect_s2<false>), resident((const void*)k_connect_s2<true>));
 		c->gridMega = resident((const void*)k_whitted_mega);
 		c->gridLevel = resident((const void*)k_whitted_level);
 		c->gridMegaPath = resident((const void*)k_path_mega);
@@ -428,8 +422,6 @@ void rt_destroy(rt_ctx* c)
 	free_pool(c->megaOrderAllocs);
 	free_pool(c->levelAllocs);
 	free_pool(c->qAllocs);
-	if (c->spill2) (void)hipFree(c->spill2);
-	if (c->sideSpill2) (void)hipFree(c->sideSpill2);
 	if (c->streamSide) { (void)hipStreamSynchronize(c->streamSide); (void)hipStreamDestroy(c->streamSide); }
 	if (c->streamSideSpill) (void)hipFree(c->streamSideSpill);
 	if (c->streamFork) (void)hipEventDestroy(c->streamFork);
@@ -830,7 +822,6 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	}
 	S.useTLAS = d->use_tlas ? 1 : 0;
 	S.stackRows = RT_STACK_ROWS_MAX;
-	S.stackRows2 = RT_LDS_WORDS2 / RT_BLOCK / 2 - 6;
 
 	if (d->use_tlas) {
 		std::vector<DInstance> inst(d->n_instances);
@@ -987,9 +978,6 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 			S.tlasLds = rows >= RT_STACK_ROWS_MIN ? 1 : 0;
 			if (getenv("RT_TLAS_LDS")) S.tlasLds = S.tlasLds && atoi(getenv("RT_TLAS_LDS")) != 0;
 			if (S.tlasLds) S.stackRows = rows < RT_STACK_ROWS_MAX ? rows : RT_STACK_ROWS_MAX;
-			// two rays per lane: two stack columns (+ world-ray rows) per lane beside the same TLAS copy; too few rows: one ray per lane
-			const int rows2 = S.tlasLds ? ((RT_LDS_WORDS2 - ((words + 3) & ~3)) / RT_BLOCK) / 2 - 6 : RT_LDS_WORDS2 / RT_BLOCK / 2 - 6;
-			S.stackRows2 = rows2 >= RT_STACK_ROWS_MIN2 ? rows2 : 0;
 		}
 	}
 	std::vector<DLight> lights(d->n_lights ? d->n_lights : 1);
@@ -1708,11 +1696,6 @@ static int ensure_stream_state(rt_ctx* c, int n)
 		HIPCHK(c, hipEventCreateWithFlags(&c->streamFork, hipEventDisableTiming));
 		HIPCHK(c, hipEventCreateWithFlags(&c->streamJoin, hipEventDisableTiming));
 	}
-	if (c->twoRays && !c->spill2) {
-		const size_t words = (size_t)2 * (RT_STACK_MAX - RT_STACK_ROWS_MIN2) * c->gridBlocks * RT_BLOCK;
-		HIPCHK(c, hipMalloc((void**)&c->spill2, words * sizeof(uint)));
-		HIPCHK(c, hipMalloc((void**)&c->sideSpill2, words * sizeof(uint)));
-	}
 	if (c->streamCap >= n && c->streamLights == c->S.nLights && (c->streamWide || !wide)) return RT_OK;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->streamSide));
@@ -1744,13 +1727,10 @@ static int ensure_stream_state(rt_ctx* c, int n)
 	c->streamCap = (int)cap, c->streamLights = c->S.nLights, c->streamWide = wide;
 	return RT_OK;
 }
-static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int round, uint* spill, uint* spillTwo)
+static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int round, uint* spill)
 {
 	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27) | (c->decideShadow ? RT_TUNE_DECIDE_SHADOW : 0);
-	if ((c->twoRays & 2) && c->S.stackRows2 > 0 && !c->S.wide) {
-		if (c->counting) hipLaunchKernelGGL((k_connect_s2<true>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spillTwo, c->counters + 1);
-		else hipLaunchKernelGGL((k_connect_s2<false>), dim3(c->gridConnectS2), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spillTwo, c->counters + 1);
-	} else if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
+	if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
 	else if (c->S.wide8) {
 		// the 8-wide quantised walk, then the binary walk over the rays it handed back (not clean: normally none)
 		hipLaunchKernelGGL((k_connect_s<false, false, false, true>), dim3(c->gridConnectWide8S), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
@@ -1783,7 +1763,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	// per round instead of two.
 	// Measured (profiles/r03_ab_one_launch_per_round.txt, 1080p x spp): 1: 3.73 -> 3.24 ms, 2: 4.50 -> 4.18, 4: 6.10 -> 6.02, 8: 9.00 -> 9.08, 16: 14.8 -> 15.8.
 	const unsigned mixedMax = getenv("RT_MIXED_MAX") ? (unsigned)atol(getenv("RT_MIXED_MAX")) : 10000000u;
-	const bool mixed = !c->counting && !c->twoRays && (c->fuseTraversal == 1 || (c->fuseTraversal < 0 && R.nSamples < mixedMax)) &&
+	const bool mixed = !c->counting && (c->fuseTraversal == 1 || (c->fuseTraversal < 0 && R.nSamples < mixedMax)) &&
 	                   (unsigned long long)R.nSamples * (unsigned)(c->S.nLights + 1) < 0x7FFFFFFFull;
 	const bool twoStreams = !mixed && (c->fuseTraversal < 0 ? R.nSamples < 100000000u : c->fuseTraversal != 0);
 	const bool gated = twoStreams && !c->gateBroken && (c->fuseTraversal < 0 || c->fuseTraversal == 3); // connect(r) + light(r) wait at a gate that extend(r + 1) opens when its queue runs dry
@@ -1802,7 +1782,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		if (twoStreams) { const hipError_t e = hipStreamWaitEvent(sb, c->streamFork, 0); if (e != hipSuccess) sideErr = e; }
 		if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sb, T.counts, r + 2); // opened by extend(r + 1), already submitted on the main stream
 		prof_begin(c, K_CONNECT, sb);
-		launch_connect_s(c, sb, T, r, twoStreams ? c->streamSideSpill : c->spill, twoStreams ? c->sideSpill2 : c->spill2);
+		launch_connect_s(c, sb, T, r, twoStreams ? c->streamSideSpill : c->spill);
 		prof_end(c, sb);
 		prof_begin(c, K_SHADE, sb);
 		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, r, lastR, c->shadeLds);
@@ -1817,11 +1797,8 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 #endif
 		prof_begin(c, K_EXTEND, st);
 		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin) | (c->decideShadow ? RT_TUNE_DECIDE_SHADOW : 0), c->spill);
-		else if ((c->twoRays & 1) && c->S.stackRows2 > 0) {
-			if (c->counting) hipLaunchKernelGGL((k_extend_s2<true>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
-			else hipLaunchKernelGGL((k_extend_s2<false>), dim3(c->gridExtendS2), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill2, c->counters);
-		} else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
-		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+		else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		prof_end(c, st);
 #ifdef RT_TAIL_PROBE
 		tail_probe_print(st, "extend_s", round);
@@ -2462,9 +2439,9 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d decide_shadow=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d mega_decide=%d mega_path_max=%d two=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d decide_shadow=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d mega_decide=%d mega_path_max=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->decideShadow, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->megaDecide, c->megaPathMax, c->twoRays, c->Qt.on,
+	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->megaDecide, c->megaPathMax, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();

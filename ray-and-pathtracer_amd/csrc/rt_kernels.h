@@ -679,9 +679,6 @@ struct ListedPolicy {
 #ifndef RT_CONNECT_WAVES
 #define RT_CONNECT_WAVES 7
 #endif
-#ifndef RT_CONNECT_REPEAT
-#define RT_CONNECT_REPEAT 6 // pair steps per iteration of the any-hit walk (extend: RT_PAIR_REPEAT = 4; 6 there spills)
-#endif
 // WIDE: the 4-wide walk (needs S.wide); LISTED: the work items are Q.leftover[0 .. Q.counts[8])
 template <bool COUNT, bool WIDE = false, bool LISTED = false>
 __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S, PathState P, Queues Q, int parity, int refillMin, uint* spill, DCounters* counters)
@@ -693,9 +690,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S
 	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights, &Q.counts[3], Q.leftover, &Q.counts[8] };
 	if constexpr (LISTED) {
 		ListedPolicy<ConnectPolicy> lp{ pol, Q.leftover };
-		trace_persistent<true, COUNT, false, ListedPolicy<ConnectPolicy>, false, false, RT_CONNECT_REPEAT>(S, lp, Q.counts[8], Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+		trace_persistent<true, COUNT, false, ListedPolicy<ConnectPolicy>>(S, lp, Q.counts[8], Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	} else
-		trace_persistent<true, COUNT, false, ConnectPolicy, false, WIDE, RT_CONNECT_REPEAT>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+		trace_persistent<true, COUNT, false, ConnectPolicy, false, WIDE ? 4 : 2>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -1086,7 +1083,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, co
 		ListedPolicy<OccludedQueryPolicy> lp{ pol, leftover };
 		trace_persistent<true, COUNT, false>(S, lp, work[2], work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	} else
-		trace_persistent<true, COUNT, false, OccludedQueryPolicy, false, WIDE, RT_PAIR_REPEAT, false, WIDE8>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+		trace_persistent<true, COUNT, false, OccludedQueryPolicy, false, WIDE8 ? 8 : (WIDE ? 4 : 2)>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 

@@ -148,7 +148,6 @@ struct DScene {
 	int nInst;     // instances
 	int tlasLds;   // every traversal block walks its own LDS copy of the TLAS (pairs, reach records, instance transforms)
 	int stackRows; // stack entries per lane kept in LDS (the split of the block's LDS, see RT_LDS_WORDS)
-	int stackRows2; // the same for the kernels with two rays per lane (RT_LDS_WORDS2: two columns per lane)
 	int useTLAS;
 	int nBruteSph, nBrutePla;
 	int nLights;
@@ -195,11 +194,7 @@ struct Stack {
 	uint rows;        // entries held in LDS
 	uint sp;
 	int* overflow;
-	// two ray contexts per lane (trace_persistent<TWO>): 'lds' names the LDS column of the context the lane is working on
-	// (it travels with the context); the spill column of the second context lies secondSpill entries further
-	lds_uint* secondLds; // first LDS address of the second contexts' columns (wave-uniform); null: one context per lane
-	size_t secondSpill;
-	__device__ __forceinline__ size_t spill_at(uint entry) const { return (size_t)entry * spillStride + (secondLds && lds >= secondLds ? secondSpill : (size_t)0); }
+	__device__ __forceinline__ size_t spill_at(uint entry) const { return (size_t)entry * spillStride; }
 	__device__ __forceinline__ void push(uint v)
 	{
 		RT_CHECK(sp <= RT_STACK_MAX, 1, overflow);
@@ -226,7 +221,6 @@ __device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* ove
 	st.spill = (glb_uint*)spill + (blockIdx.x * blockDim.x + threadIdx.x);
 	st.sp = 0;
 	st.overflow = overflow;
-	st.secondLds = nullptr, st.secondSpill = 0;
 	return st;
 }
 
@@ -336,6 +330,9 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #ifndef RT_PAIR_REPEAT
 #define RT_PAIR_REPEAT 4 // pair steps per iteration at most (unrolled)
 #endif
+#ifndef RT_CONNECT_REPEAT
+#define RT_CONNECT_REPEAT 6 // the same for a launch of any-hit queries only (six spill in the nearest-hit kernel at its 72 registers)
+#endif
 #define RT_HEAD_STRIDE 1024 // ints between two heads
 #ifndef RT_HEADS_PROBE
 #define RT_HEADS_PROBE 6 // sub-queues a wave finds empty in a row before it stops looking (every probe is one more
@@ -389,24 +386,17 @@ template <class P> struct pol_starts_done<P, decltype((void)&P::starts_done)> { 
 template <class P, class = void> struct pol_advances { static constexpr bool value = false; };
 template <class P> struct pol_advances<P, decltype((void)P::kAdvance)> { static constexpr bool value = P::kAdvance; };
 
-// TWO == true: every lane carries TWO rays (contexts A and B).  All step code works on context A; before a step kind runs,
-// a lane whose A does not want that kind while its B does swaps the two (v_swap_b32 on the ~19 registers of a context), so
-// that a step kind finds a taker in nearly every lane instead of in the 35 of 64 a pair step has with one ray per lane
-// (the texture addresser and the VALU spend their time per instruction, not per enabled lane).  Each ray still makes
-// exactly the steps it makes alone, in the same order: results are identical.  Costs: registers (5 waves per SIMD
-// instead of 7, but 10 rays per lane of a SIMD instead of 7) and LDS (two stack columns per lane: RT_LDS_WORDS2).
-#ifndef RT_LDS_WORDS2
-#define RT_LDS_WORDS2 8192 // 32 KB per block: five blocks per CU
-#endif
-#define RT_STACK_ROWS_MIN2 6 // fewer LDS stack rows per context than this: the scene keeps one ray per lane
-template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false, bool WIDE = false, int REPEAT = RT_PAIR_REPEAT, bool TWO = false, bool WIDE8 = false>
+template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false, int WIDTH = 2>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
                                                  uint* ldsStack, uint* spill, int* overflow, LaneCounters& lc, uint& rays)
 {
-	static_assert(!WIDE || (ANY && !COUNT && !MIXED), "the wide walk is exact for any-hit queries only");
-	static_assert(!TWO || (!MIXED && !WIDE && !RT_FETCH_STEP), "two contexts per lane: the plain binary walks only");
-	static_assert(!WIDE8 || (ANY && !COUNT && !MIXED && !WIDE && !TWO), "the 8-wide walk is exact for any-hit queries only");
+	// WIDTH: 2 the reference's binary walk; 4 / 8: inside a BLAS / the scene BVH the walk uses the 4-wide nodes (wide[]) or the 8-wide
+	// quantised ones (wide8[]) -- occlusion queries only, never counting launches
+	static_assert(WIDTH == 2 || WIDTH == 4 || WIDTH == 8, "binary, 4-wide or 8-wide");
+	static_assert(WIDTH == 2 || (ANY && !COUNT && !MIXED), "a wide walk is exact for any-hit queries only");
+	constexpr bool WIDE = WIDTH == 4, WIDE8 = WIDTH == 8;
 	constexpr bool ANYWIDE = WIDE || WIDE8; // a wide walk: rays that are not clean go back to the binary walk
+	constexpr int REPEAT = ANY && !MIXED ? RT_CONNECT_REPEAT : RT_PAIR_REPEAT; // pair steps per iteration at most
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
 	const int refillMin = tuning & 0xFF, stepMinBusy = (tuning >> 8) & 0xFF, pairAgainBusy = (tuning >> 20) & 0x7F;
 	const int stepMinXformBusy = ((tuning >> 27) & 0xF) ? ((tuning >> 27) & 0xF) : stepMinBusy; // entry / exit: arithmetic and LDS only when the TLAS is in LDS
@@ -421,16 +411,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	int tried = 0;                  // sub-queues found empty since the last successful reservation
 	int chunk = subLen / (wavesPerHead * 2); // size of the next reservation
 	chunk = chunk >= RT_CHUNK ? RT_CHUNK : (chunk <= RT_CHUNK_MIN ? RT_CHUNK_MIN : (chunk & ~(RT_CHUNK_MIN - 1)));
-	const uint stackRows = TWO ? (uint)S.stackRows2 : (uint)S.stackRows;
+	const uint stackRows = (uint)S.stackRows;
 	Stack st = make_stack(ldsStack, spill, overflow, stackRows);
 	// the world-space ray while the lane walks a BLAS: rows [stackRows, stackRows + 6) of the context's LDS column, [row][lane]
 #define worldRay (st.lds + stackRows * RT_BLOCK)
-	if constexpr (TWO) st.secondLds = (lds_uint*)ldsStack + (stackRows + 6) * RT_BLOCK, st.secondSpill = (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN2) * st.spillStride;
 	// A small TLAS is walked in LDS.  The traversal is bound by the vector-memory path (lane accesses through the
 	// texture addresser and L1); a TLAS visit is seven of them (pair + reach record) and an
 	// instance entry four, together a quarter of all accesses on the bench scene; ds_read takes another pipe.
 	// Layout: [pair][4] | [pair][3] reach | [instance][3] invT rows 0-2 | [instance] root link (rootWide for the wide walk)
-	lds_v4f* const tlasL = (lds_v4f*)((lds_uint*)ldsStack + (TWO ? 2 : 1) * (stackRows + 6) * RT_BLOCK);
+	lds_v4f* const tlasL = (lds_v4f*)((lds_uint*)ldsStack + (stackRows + 6) * RT_BLOCK);
 	if (S.tlasLds) {
 		const int nP = S.tlasPairs * 4, nR = S.tlasPairs * 3, nI = S.nInst * 3;
 		for (int i = (int)threadIdx.x; i < nP + nR + nI; i += RT_BLOCK) {
@@ -480,33 +469,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	__shared__ uint pfDump[64];
 #endif
 
-	// context B (TWO): the lane's other ray, parked
-	f3 bO(0.0f), bD(0.0f), brD(0.0f);
-	float brayT = 0;
-	uint blink = RT_LINK_DONE, bhitPrim = 0, bsp = 0;
-	int bhitInst = -1, bhitKind = -1, binst = -1, bwork = -1;
-	bool bclean = false;
-	lds_uint* blds = st.lds + (stackRows + 6) * RT_BLOCK;
-	auto swap_ab = [&](bool need) {
-		if constexpr (TWO) {
-			if (__ballot(need) == 0) return;
-			if (need) {
-#define RT_SWAPF(a, b) asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b))
-				RT_SWAPF(O.x, bO.x); RT_SWAPF(O.y, bO.y); RT_SWAPF(O.z, bO.z);
-				RT_SWAPF(D.x, bD.x); RT_SWAPF(D.y, bD.y); RT_SWAPF(D.z, bD.z);
-				RT_SWAPF(rD.x, brD.x); RT_SWAPF(rD.y, brD.y); RT_SWAPF(rD.z, brD.z);
-				RT_SWAPF(rayT, brayT); RT_SWAPF(link, blink); RT_SWAPF(hit.prim, bhitPrim); RT_SWAPF(st.sp, bsp);
-				RT_SWAPF(hit.inst, bhitInst); RT_SWAPF(hit.kind, bhitKind); RT_SWAPF(inst, binst); RT_SWAPF(work, bwork);
-				{ lds_uint* t = st.lds; st.lds = blds; blds = t; }
-#undef RT_SWAPF
-			}
-			const bool t = clean;
-			clean = need ? bclean : clean, bclean = need ? t : bclean;
-		}
-	};
-	// what context B would want (the same link tests as for A below)
-	auto b_live = [&]() { return TWO && bwork >= 0 && blink != RT_LINK_DONE; };
-
 	// next node for this lane: pop the stack; an empty stack ends the ray, the sentinel leaves the instance
 	auto pop_next = [&]() {
 		if (st.sp == 0) { link = RT_LINK_DONE; return; }
@@ -545,24 +507,16 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
 		bool idle = work < 0;
 		bool doneLane = work >= 0 && link == RT_LINK_DONE;
-		const bool freeB = TWO && (bwork < 0 || blink == RT_LINK_DONE);
-		unsigned long long freeMask = __ballot(idle || doneLane || freeB); // lanes with a free context (one is refilled per lane and event)
+		unsigned long long freeMask = __ballot(idle || doneLane); // lanes that can take a new work item
 		RT_SEC_COUNT(8);
 		if (freeMask != 0) {
 			const int cnt = __popcll(freeMask);
-			const bool nothingLeft = TWO ? __ballot((idle || doneLane) && freeB) == ~0ull : freeMask == ~0ull;
+			const bool nothingLeft = freeMask == ~0ull;
 			// (once the queue is dry there is nothing to hand out: the block is for finished lanes only -- a wave's last rays then
 			// skip it on all the iterations in which none of them finished)
-			if ((cnt >= refillMin || nothingLeft) && (TWO || !exhausted || __ballot(doneLane) != 0)) {
+			if ((cnt >= refillMin || nothingLeft) && (!exhausted || __ballot(doneLane) != 0)) {
 				const unsigned long long secT = RT_SEC_NOW();
 				RT_SEC_COUNT(13);
-				if constexpr (TWO) {
-					// flush and refill below work on A: a finished ray waiting in B goes there first (it must be flushed before the
-					// wave can leave), else a free B when A is busy
-					const bool bDone = bwork >= 0 && blink == RT_LINK_DONE;
-					swap_ab((bDone && !doneLane) || (!(idle || doneLane) && freeB));
-					idle = work < 0, doneLane = work >= 0 && link == RT_LINK_DONE;
-				}
 				if (doneLane) {
 					RT_CHECK(work >= 0 && work < n && st.sp <= RT_STACK_MAX, 4, overflow);
 #ifdef RT_STEP_COUNT
@@ -571,7 +525,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #endif
 					// results are written here, many lanes at a time, not one lane per iteration
 					if constexpr (pol_advances<Policy>::value) {
-						static_assert(MIXED && !TWO && !WIDE, "an advancing policy changes its lane's kind of query");
+						static_assert(MIXED, "an advancing policy changes its lane's kind of query");
 						HitRef res = hit;
 						res.t = rayT;
 						float tmax = 0;
@@ -662,9 +616,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #endif
 			}
 		}
-		const bool stepping = (work >= 0 && link != RT_LINK_DONE) || b_live();
+		const bool stepping = work >= 0 && link != RT_LINK_DONE;
 		if (__ballot(stepping) == 0) {
-			if (exhausted && __ballot(work >= 0 || (TWO && bwork >= 0)) == 0) {
+			if (exhausted && __ballot(work >= 0) == 0) {
 #ifdef RT_TAIL_PROBE
 				if (lane == 0) atomicMax(&g_tailProbe[2], __builtin_amdgcn_s_memrealtime());
 #endif
@@ -694,10 +648,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		const int stepMin = exhausted ? 1 : stepMinBusy, pairAgain = exhausted ? 1 : pairAgainBusy, stepMinXform = exhausted ? 1 : stepMinXformBusy;
 #pragma unroll
 		for (int rep = 0; rep < REPEAT; rep++) {
-			if constexpr (TWO) {
-				const bool aPair = work >= 0 && link != RT_LINK_DONE && !(link & (RT_LEAF_BIT | RT_INST_BIT));
-				swap_ab(!aPair && b_live() && !(blink & (RT_LEAF_BIT | RT_INST_BIT)));
-			}
 			const uint lk = link;
 			const bool live = work >= 0 && lk != RT_LINK_DONE;
 			const bool wantPair = live && !(lk & (RT_LEAF_BIT | RT_INST_BIT));
@@ -708,10 +658,9 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			if (rep == 0) {
 				if (nP < stepMin) {
 					// fewer than stepMin: only if nothing else is wanted more
-					const bool bl = b_live();
-					const int nL = FETCH ? 0 : __popcll(__ballot(isLeaf || (bl && blink < RT_LINK_EXIT && (blink & RT_LEAF_BIT))));
-					const int nN = __popcll(__ballot((live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT)) || (bl && !(blink & RT_LEAF_BIT) && (blink & RT_INST_BIT))));
-					const int nE = __popcll(__ballot((live && lk == RT_LINK_EXIT) || (bl && blink == RT_LINK_EXIT)));
+					const int nL = FETCH ? 0 : __popcll(__ballot(isLeaf));
+					const int nN = __popcll(__ballot(live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT)));
+					const int nE = __popcll(__ballot(live && lk == RT_LINK_EXIT));
 					if (nP < nL || nP < nN || nP < nE) break;
 				}
 			} else if (nP < pairAgain) break;
@@ -823,7 +772,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				// register to keep reserved), so that the next step's round trip overlaps this step's arithmetic.  Measured: a lone
 				// lane's step 612 -> 684 ns, every drain-bound number 5-8 % worse.  With the scalar-cache variant (RT_SCALAR_LONE:
 				// level) this says the lone step is not waiting for its record; it is the ~300 instructions of a wave iteration.
-				if (!TWO && exhausted && !(S.tlasLds && atTlas)) {
+				if (exhausted && !(S.tlasLds && atTlas)) {
 					const uint pc1 = __float_as_uint(a0.w), pc2 = __float_as_uint(b0.w);
 					if (!(pc1 & RT_INST_BIT)) {
 						const float4* q = (pc1 & RT_LEAF_BIT) ? S.prims + 4 * (size_t)(pc1 & ~RT_LEAF_BIT) : S.pairs + 4 * (size_t)pc1;
@@ -889,23 +838,19 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		bool wantLeaf = live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
 		bool wantExit = live && lk == RT_LINK_EXIT;
 		bool wantEnter = live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT);
-		// TWO: a kind is wanted by a lane when either of its rays wants it; the ray that does is swapped into A when the kind runs
-		const bool bl = b_live();
-		const bool bLeaf = bl && blink < RT_LINK_EXIT && (blink & RT_LEAF_BIT), bExit = bl && blink == RT_LINK_EXIT, bEnter = bl && !(blink & RT_LEAF_BIT) && (blink & RT_INST_BIT);
-		const int nL = __popcll(__ballot(wantLeaf || bLeaf)), nP = __popcll(__ballot((live && !(lk & (RT_LEAF_BIT | RT_INST_BIT))) || (bl && !(blink & (RT_LEAF_BIT | RT_INST_BIT))))); // FETCH: max(nL, nP) stands for their sum below
-		const int nN = __popcll(__ballot(wantEnter || bEnter)), nE = __popcll(__ballot(wantExit || bExit));
+		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(live && !(lk & (RT_LEAF_BIT | RT_INST_BIT)))); // FETCH: max(nL, nP) stands for their sum below
+		const int nN = __popcll(__ballot(wantEnter)), nE = __popcll(__ballot(wantExit));
 		int most = nL > nP ? nL : nP;
 		most = nN > most ? nN : most;
 		most = nE > most ? nE : most;
 		const bool runLeaf = !FETCH && nL > 0 && (nL >= stepMin || nL == most);
 		const bool runEnter = nN > 0 && (nN >= stepMinXform || nN == most);
 		const bool runExit = nE > 0 && (nE >= stepMinXform || nE == most);
-		if (most == 0 && __ballot(live || bl) != 0) {
+		if (most == 0 && __ballot(live) != 0) {
 			// live lanes whose link no step kind understands (a corrupt tree): nothing would ever change again.  Every
 			// wave must reach its exit, so the rays are dropped and the launch reports RT_E_STATE.
 			*overflow = 199;
 			if (live) link = RT_LINK_DONE;
-			if (TWO && bl) blink = RT_LINK_DONE;
 			continue;
 		}
 
@@ -913,12 +858,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		if ((runLeaf && wantLeaf) || (runEnter && wantEnter) || (runExit && wantExit)) nsteps++;
 		if (runEnter && wantEnter) nenter++;
 #endif
-		if constexpr (TWO) {
-			if (runLeaf) {
-				swap_ab(!wantLeaf && b_live() && blink < RT_LINK_EXIT && (blink & RT_LEAF_BIT));
-				lk = link, live = work >= 0 && lk != RT_LINK_DONE, wantLeaf = live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
-			}
-		}
 		if (runLeaf && wantLeaf) {
 			// a leaf step of its own (the wide walk): all four vectors of the record in one go (nearly every record is a triangle)
 			const float4* rec = S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT);
@@ -926,7 +865,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			RT_SEC_COUNT(10);
 			float4 r0, r1, r2, r3;
 #if RT_SCALAR_LONE
-			if (nL == 1 && !TWO) {
+			if (nL == 1) {
 				const c_float4* rs = (const c_float4*)uniform_ptr(rec);
 				r0 = ld_c(rs), r1 = ld_c(rs + 1), r2 = ld_c(rs + 2), r3 = ld_c(rs + 3);
 			} else
@@ -938,14 +877,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			leaf_test(lk, r0, r1, r2, r3);
 			RT_SEC_WAIT();
 			RT_SEC_ADD(4, secT2);
-		}
-		if constexpr (TWO) {
-			if (runEnter) {
-				// (a context that just made its leaf step may already want this kind: it takes it, a step is a step)
-				const bool aEnter = work >= 0 && link != RT_LINK_DONE && !(link & RT_LEAF_BIT) && (link & RT_INST_BIT);
-				swap_ab(!aEnter && b_live() && !(blink & RT_LEAF_BIT) && (blink & RT_INST_BIT));
-				lk = link, live = work >= 0 && lk != RT_LINK_DONE, wantEnter = live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT);
-			}
 		}
 		if (runEnter && wantEnter) {
 			const unsigned long long secT = RT_SEC_NOW();
@@ -982,13 +913,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			if constexpr (ANYWIDE) { if (!clean) { pol.leftover(work); work = -1; link = RT_LINK_DONE; } } // not clean in object space: the binary walk redoes this ray
 			RT_SEC_WAIT();
 			RT_SEC_ADD(5, secT);
-		}
-		if constexpr (TWO) {
-			if (runExit) {
-				const bool aExit = work >= 0 && link == RT_LINK_EXIT;
-				swap_ab(!aExit && b_live() && blink == RT_LINK_EXIT);
-				lk = link, wantExit = work >= 0 && lk == RT_LINK_EXIT;
-			}
 		}
 		if (runExit && wantExit) {
 			const unsigned long long secT = RT_SEC_NOW();

@@ -54,6 +54,7 @@ namespace rtd {
 #define SC_GATE 10   // round + 1 of the last extend launch of this batch that found its queue dry: k_gate(r) lets connect(r) start at r + 2
 #define SC_GATE_WAITS 11    // k_gate launches that found the gate closed when they started (they really waited)
 #define SC_GATE_TIMEOUTS 12 // k_gate launches that gave up (the two streams did not run side by side): the host stops gating
+#define SC_ROUND 13  // the round whose extend runs next / is running (prepare_round): what an extend launch publishes + 1 at SC_GATE
 
 struct StreamState {
 	float4* O[2];     // ray origin xyz, w = ray.t after the head tests        } entry e of round parity p
@@ -178,7 +179,7 @@ __device__ __forceinline__ void prepare_round(const StreamState& T, int next /* 
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0) return;
 	if (n0 >= 0) T.counts[SC_N + next % 3] = n0, T.counts[SC_GATE] = 0; // generate: the batch's samples are round 0's entries; no extend of this batch has run dry yet
-	T.counts[SC_TRACE] = 0, T.counts[SC_N + (next + 1) % 3] = 0, T.counts[SC_SHADOW + next % 3] = 0;
+	T.counts[SC_TRACE] = 0, T.counts[SC_N + (next + 1) % 3] = 0, T.counts[SC_SHADOW + next % 3] = 0, T.counts[SC_ROUND] = next;
 	for (int h = 0; h < RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
 	// connect of the round before 'next' (it starts after the kernel this runs in)
 	T.counts[SC_LEFTOVER] = 0;
@@ -258,12 +259,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_s(DScene S, DCamera C, Re
 // extend: Scene::FindNearest for the entries of the traversal queue
 struct StreamExtendPolicy {
 	static constexpr bool kSignalsDry = true;
-	__device__ __forceinline__ void queue_dry() const { __hip_atomic_store(&T.counts[SC_GATE], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	// (the round comes from memory, once per wave, instead of as a kernel argument: one more live scalar cost k_extend_s 12 bytes of scratch)
+	__device__ __forceinline__ void queue_dry() const { __hip_atomic_store(&T.counts[SC_GATE], T.counts[SC_ROUND] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 	const DScene& S;
 	const StreamState& T;
 	int parity, last;
 	int* flag;
-	int round;
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
 	{
 		const int e = (int)ld_stream(T.traceQ + work);
@@ -288,33 +289,14 @@ struct StreamExtendPolicy {
 	}
 };
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S, StreamState T, int round, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S, StreamState T, int parity, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	StreamExtendPolicy pol{ S, T, round & 1, last, &T.counts[SC_FLAG], round };
+	StreamExtendPolicy pol{ S, T, parity, last, &T.counts[SC_FLAG] };
 	trace_persistent<false, COUNT, false>(S, pol, T.counts[SC_TRACE], T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
-	if (COUNT) {
-		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
-		flush_counters(counters, lc, rays, 0);
-	}
-}
-
-// the same two kernels with two rays per lane (trace_persistent<TWO>, rt_scene_dev.h)
-#ifndef RT_TWO_WAVES
-#define RT_TWO_WAVES 5
-#endif
-template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_extend_s2(DScene S, StreamState T, int round, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
-{
-	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS2];
-	LaneCounters lc;
-	lc.clear();
-	uint rays = 0;
-	StreamExtendPolicy pol{ S, T, round & 1, last, &T.counts[SC_FLAG], round };
-	trace_persistent<false, COUNT, false, StreamExtendPolicy, false, false, RT_PAIR_REPEAT, true>(S, pol, T.counts[SC_TRACE], T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) {
 		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
 		flush_counters(counters, lc, rays, 0);
@@ -660,22 +642,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene
 	int* heads = T.heads + RT_HEADS * RT_HEAD_STRIDE;
 	if constexpr (LISTED) {
 		ListedPolicy<StreamConnectPolicy> lp{ pol, T.leftover };
-		trace_persistent<true, COUNT, false, ListedPolicy<StreamConnectPolicy>, false, false, RT_CONNECT_REPEAT>(S, lp, T.counts[SC_LEFTOVER], heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+		trace_persistent<true, COUNT, false, ListedPolicy<StreamConnectPolicy>>(S, lp, T.counts[SC_LEFTOVER], heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	} else
-		trace_persistent<true, COUNT, false, StreamConnectPolicy, false, WIDE, RT_CONNECT_REPEAT, false, WIDE8>(S, pol, nShadow * S.nLights, heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
-	if (COUNT) flush_counters(counters, lc, 0, rays);
-}
-
-template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK, RT_TWO_WAVES) k_connect_s2(DScene S, StreamState T, int round, int refillMin, uint* spill, DCounters* counters)
-{
-	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS2];
-	LaneCounters lc;
-	lc.clear();
-	uint rays = 0;
-	const int nShadow = T.counts[SC_SHADOW + round % 3];
-	StreamConnectPolicy pol{ T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG], nullptr };
-	trace_persistent<true, COUNT, false, StreamConnectPolicy, false, false, RT_CONNECT_REPEAT, true>(S, pol, nShadow * S.nLights, T.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+		trace_persistent<true, COUNT, false, StreamConnectPolicy, false, WIDE8 ? 8 : (WIDE ? 4 : 2)>(S, pol, nShadow * S.nLights, heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -705,7 +674,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DSce
 	lc.clear();
 	uint rays = 0;
 	const int nTrace = T.counts[SC_TRACE], nShadow = T.counts[SC_SHADOW + (round + 2) % 3]; // the shadow records of round - 1
-	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG], round }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG], (refillMin & RT_TUNE_DECIDE_SHADOW) ? &S : nullptr }, nTrace };
+	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG] }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG], (refillMin & RT_TUNE_DECIDE_SHADOW) ? &S : nullptr }, nTrace };
 	trace_persistent<false, false, false, StreamTraversePolicy, true>(S, pol, nTrace + nShadow * S.nLights, T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 }
 

@@ -1039,18 +1039,17 @@ def test_fused_traversal_launch_equals_separate_launches(name, kw, w, h, frames,
 def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
     """The dense path pipeline (csrc/rt_stream.h, the default: entries of a round are the survivors of the round before,
     every producer writes to compacted positions; RT_FUSE=0 runs it one kernel at a time) and its producer-side ray
-    decisions (RT_DECIDE: generate / shade answer a ray whose first traversal step leaves nothing to visit), also with two
-    rays per lane in its traversal kernels (RT_TWO, trace_persistent<TWO>), and the opt-in one-launch form
+    decisions (RT_DECIDE: generate / shade answer a ray whose first traversal step leaves nothing to visit), and the opt-in one-launch form
     (csrc/rt_mega.h k_path_mega, RT_MEGA_PATH_MAX: a lane keeps its sample for all hit levels), against the slot pipeline (RT_STREAM=0): identical accumulator bits -- per sample the arithmetic is the same, only where the path
     state lives differs -- the oracle's frame, identical frames from row shards, identical Sample() values for
     caller-supplied rays at every depth, and the same number of FindNearest / IsOccluded queries."""
     out, rays = {}, {}
     pO = pD = None
     for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_gated", {"RT_FUSE": "3"}), ("stream_one_launch_per_round", {"RT_FUSE": "1"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
-                     ("stream_two_rays", {"RT_TWO": "3", "RT_FUSE": "2"}), ("one_launch", {"RT_MEGA_PATH_MAX": "4194304"}),
+                     ("one_launch", {"RT_MEGA_PATH_MAX": "4194304"}),
                      ("stream_decide_shadow", {"RT_DECIDE_SHADOW": "1", "RT_FUSE": "0"}), ("stream_decide_shadow_one_launch_per_round", {"RT_DECIDE_SHADOW": "1", "RT_FUSE": "1"}),
                      ("stream_gamma_at_the_store", {"RT_DEFER_GAMMA": "0"})):
-        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_TWO", "RT_DECIDE_SHADOW", "RT_DEFER_GAMMA"):
+        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_DECIDE_SHADOW", "RT_DEFER_GAMMA"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("RT_MEGA_PATH_MAX", "0")
         for k, v in env.items():
@@ -1079,7 +1078,7 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
                 pO, pD = pO[::7].copy(), pD[::7].copy()
             out[key + "_sample"] = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 99) for depth in (0, 1, 4)]
         r.close()
-    for key in ("stream", "stream_serial", "stream_gated", "stream_one_launch_per_round", "stream_nodecide", "stream_two_rays", "one_launch",
+    for key in ("stream", "stream_serial", "stream_gated", "stream_one_launch_per_round", "stream_nodecide", "one_launch",
                 "stream_decide_shadow", "stream_decide_shadow_one_launch_per_round", "stream_gamma_at_the_store"):
         assert np.array_equal(out["slot"].view(np.uint32), out[key].view(np.uint32)), key
         assert rays[key] == rays["slot"], (key, rays[key], rays["slot"])
