@@ -58,27 +58,14 @@ __device__ __forceinline__ int f2i(float f)
 // definition is used by every CPU implementation this path is compared with.
 // They are real functions, not inlined: the double-precision library bodies pushed k_shade to 128 VGPRs (its bound; four
 // waves per SIMD) and k_light to 181 (two); called, the kernels need 89 and 114 (five and four waves) and the shading
-// side of a bench step takes 15.6 instead of 16.5 ms.  RT_INLINE_MATH restores the inlined form.
-#ifdef RT_INLINE_MATH
-#define RT_MATH_FN __device__ __forceinline__
-#else
+// side of a bench step takes 15.6 instead of 16.5 ms.
 #define RT_MATH_FN __device__ __noinline__
-#endif
-#ifdef RT_EXPERIMENT_F32_MATH // measurement only (results differ from the oracle's): what would single-precision transcendentals buy?
-RT_MATH_FN float x_cosf(float x) { return cosf(x); }
-RT_MATH_FN float x_sinf(float x) { return sinf(x); }
-RT_MATH_FN float x_acosf(float x) { return acosf(x); }
-RT_MATH_FN float x_asinf(float x) { return asinf(x); }
-RT_MATH_FN float x_expf(float x) { return expf(x); }
-RT_MATH_FN float x_powf(float a, float b) { return powf(a, b); }
-#else
 RT_MATH_FN float x_cosf(float x) { return (float)cos((double)x); }
 RT_MATH_FN float x_sinf(float x) { return (float)sin((double)x); }
 RT_MATH_FN float x_acosf(float x) { return (float)acos((double)x); }
 RT_MATH_FN float x_asinf(float x) { return (float)asin((double)x); }
 RT_MATH_FN float x_expf(float x) { return (float)exp((double)x); }
 RT_MATH_FN float x_powf(float a, float b) { return (float)pow((double)a, (double)b); }
-#endif
 
 #define RT_PI 3.14159265358979323846264f
 #define RT_INVPI 0.31830988618379067153777f

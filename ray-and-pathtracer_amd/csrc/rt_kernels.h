@@ -442,25 +442,11 @@ __global__ void k_round_begin(Queues Q, int poolFollowsEnded, int allActive, int
 		for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) Q.heads[h * RT_HEAD_STRIDE] = 0;
 }
 
-// Path state is streamed (each element read or written once per launch) while the scene -- a few MB -- has to stay in
-// the 4 MB L2 of every XCD: a traversal step waits for the slowest of its lanes, and with ~35 lanes per step one L2 miss
-// among them is the rule once streaming has pushed scene lines out.  The traversal kernels therefore mark their
-// path-state accesses non-temporal (nt: no retention priority in L2).  RT_NO_NT: measurement builds without the hint.
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-typedef int nt_i2 __attribute__((ext_vector_type(2)));
-#ifdef RT_NT_LOADS
-__device__ __forceinline__ float4 ld_stream(const float4* p) { const nt_f4 v = __builtin_nontemporal_load((const nt_f4*)p); return make_float4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ uint ld_stream(const uint* p) { return __builtin_nontemporal_load(p); }
-#else
+// Path-state accesses of the traversal kernels go through these two (non-temporal variants were measured and lost: a refill
+// takes ~20 consecutive queue entries, so a ray's line is used by two or three refills and must stay cached;
+// profiles/r02_sweep_nontemporal.txt, profiles/patches/measurement_builds.diff).
 template <class T> __device__ __forceinline__ T ld_stream(const T* p) { return *p; }
-#endif
-#ifdef RT_NT_STORES
-__device__ __forceinline__ void st_stream(float4* p, const float4& v) { nt_f4 t; t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w; __builtin_nontemporal_store(t, (nt_f4*)p); }
-__device__ __forceinline__ void st_stream(int2* p, const int2& v) { nt_i2 t; t.x = v.x, t.y = v.y; __builtin_nontemporal_store(t, (nt_i2*)p); }
-__device__ __forceinline__ void st_stream(unsigned char* p, unsigned char v) { __builtin_nontemporal_store(v, p); }
-#else
 template <class T> __device__ __forceinline__ void st_stream(T* p, const T& v) { *p = v; }
-#endif
 
 // extend: Scene::FindNearest for every active slot.  t_min is Trace's 1e-6 or Sample's 0.001
 // (renderer.cpp:24, :131); it applies to lights and brute-force primitives, the BVH uses 0.0001.

@@ -80,14 +80,7 @@ namespace rtd {
 //   the rest             the block's copy of the TLAS (pairs, reach records, instance transforms), when it fits
 // rows = 16 without a TLAS copy; a copy takes rows away down to RT_STACK_ROWS_MIN (the 16 instances of config 5: 13 rows;
 // measured there: 13 rows cost nothing, the copy takes 4 % off the frame set); a TLAS too large for that stays in global memory.
-#ifndef RT_DRAIN_PREFETCH
-#define RT_DRAIN_PREFETCH 0 // the drain touches the lines of both children of a pair (trace_persistent): measured slower, see there
-#endif
-#if RT_DRAIN_PREFETCH
-#define RT_LDS_WORDS 5696 // + the 64 words of trace_persistent's pfDump = 5760
-#else
 #define RT_LDS_WORDS 5760 // 18 allocation granules of 320 words
-#endif
 #define RT_STACK_ROWS_MAX 16
 #ifndef RT_STACK_ROWS_MIN
 #define RT_STACK_ROWS_MIN 8
@@ -174,19 +167,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4f lds_v4f;
 __device__ __forceinline__ float4 ld_lds(const lds_v4f* p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 typedef __attribute__((address_space(1))) uint glb_uint;
-// read-only scene data at a wave-uniform address: address space 4 makes the load a scalar one (s_load_dwordx4/x16)
-typedef __attribute__((address_space(4))) v4f c_float4;
-__device__ __forceinline__ float4 ld_c(const c_float4* p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
-template <class T> __device__ __forceinline__ const T* uniform_ptr(const T* p)
-{
-	const unsigned long long a = (unsigned long long)p;
-	const uint lo = (uint)__builtin_amdgcn_readfirstlane((int)(uint)a), hi = (uint)__builtin_amdgcn_readfirstlane((int)(uint)(a >> 32));
-	return (const T*)(((unsigned long long)hi << 32) | lo);
-}
-#ifndef RT_SCALAR_LONE
-#define RT_SCALAR_LONE 0 // a lone lane's records through the scalar cache: measured level (the round trip is the L2's, whichever path asks)
-#endif
-
 struct Stack {
 	lds_uint* lds;    // &ldsStack[0][threadIdx.x]
 	glb_uint* spill;  // &spill[0][global lane]
@@ -324,9 +304,6 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #ifndef RT_SHORT_QUEUE_RAYS
 #define RT_SHORT_QUEUE_RAYS 32 // queue entries per wave below which further waves of the grid do not take part
 #endif
-#ifndef RT_FETCH_STEP
-#define RT_FETCH_STEP 0 // 1: pair and leaf records fetched by one step kind (measured: extend 27.6 -> 32.3 ms, see FETCH below)
-#endif
 #ifndef RT_PAIR_REPEAT
 #define RT_PAIR_REPEAT 4 // pair steps per iteration at most (unrolled)
 #endif
@@ -460,14 +437,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	int inst = -1;
 	bool laneAny = ANY;  // MIXED: this lane's work item is an occlusion query
 	bool clean = false; // the current (world or object space) ray cannot produce a NaN slab product
-#ifdef RT_EXPERIMENT_EXTRA_LOADS
-	uint xdummy = 0;
-#endif
-#if RT_DRAIN_PREFETCH
-	// where the drain's line touches land (LDS-DMA: a load without a destination register -- a register would have to stay
-	// reserved until the load lands, which the compiler cannot be told).  Never read; the four waves of the block share it.
-	__shared__ uint pfDump[64];
-#endif
 
 	// next node for this lane: pop the stack; an empty stack ends the ray, the sentinel leaves the instance
 	auto pop_next = [&]() {
@@ -496,13 +465,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			else link = lk + 1;
 		}
 	};
-	// FETCH (experiment, off): a leaf's primitive record can be fetched by the same four loads as a pair record (another
-	// base address per lane), which makes "pair" and "leaf" ONE step kind and saves the leaf steps' load instructions
-	// (the texture addresser spends ~16 cycles per dwordx4 instruction whatever the number of enabled lanes).  It loses:
-	// the triangle arithmetic then runs in every pair step for the ~5 lanes that happen to be at a leaf instead of every
-	// few iterations for ~13 (extend 27.6 -> 32.3 ms, connect 10.3 -> 12.5 ms).
-	constexpr bool FETCH = RT_FETCH_STEP && !ANYWIDE;
-
 	while (true) {
 		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
 		bool idle = work < 0;
@@ -611,9 +573,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			if (exhausted && !signalled) {
 				signalled = true;
 				if (lane == 0) pol.queue_dry();
-#ifdef RT_DRAIN_PRIO
-				__builtin_amdgcn_s_setprio(RT_DRAIN_PRIO); // the draining waves ahead of the kernel that fills the drain
-#endif
 			}
 		}
 		const bool stepping = work >= 0 && link != RT_LINK_DONE;
@@ -622,10 +581,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_TAIL_PROBE
 				if (lane == 0) atomicMax(&g_tailProbe[2], __builtin_amdgcn_s_memrealtime());
 #endif
-#ifdef RT_EXPERIMENT_EXTRA_LOADS
-				if (xdummy == 0x7fc12345u && n < 0) *overflow = 3; // keeps the register allocated to the loads
-#endif
-
 #ifdef RT_SECTION_PROBE
 				if (lane == 0) secAcc[7] = RT_SEC_NOW() - secStart;
 				if (lane < 14) atomicAdd(&g_sectionProbe[lane], (unsigned long long)secAcc[lane]);
@@ -652,26 +607,25 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			const bool live = work >= 0 && lk != RT_LINK_DONE;
 			const bool wantPair = live && !(lk & (RT_LEAF_BIT | RT_INST_BIT));
 			const bool isLeaf = live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
-			const bool wantFetch = wantPair || (FETCH && isLeaf);
-			const int nP = __popcll(__ballot(wantFetch));
+			const int nP = __popcll(__ballot(wantPair));
 			if (nP == 0) break;
 			if (rep == 0) {
 				if (nP < stepMin) {
 					// fewer than stepMin: only if nothing else is wanted more
-					const int nL = FETCH ? 0 : __popcll(__ballot(isLeaf));
+					const int nL = __popcll(__ballot(isLeaf));
 					const int nN = __popcll(__ballot(live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT)));
 					const int nE = __popcll(__ballot(live && lk == RT_LINK_EXIT));
 					if (nP < nL || nP < nN || nP < nE) break;
 				}
 			} else if (nP < pairAgain) break;
-			if (wantFetch) {
+			if (wantPair) {
 #ifdef RT_STEP_COUNT
 				nsteps++;
 #endif
 				// one sibling pair: of the BLAS (bvh.cpp:638-654 / :788-804) or, outside an instance in TLAS
 				// mode, of the TLAS (tlas.cpp:77-91 / :106-120) -- same test, same ordering rule
-				if (COUNT && wantPair) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
-				const bool atTlas = wantPair && S.useTLAS && inst < 0;
+				if (COUNT) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
+				const bool atTlas = S.useTLAS && inst < 0;
 				if (WIDE8 && !atTlas) {
 					if (lk & RT_BOX_BIT) {
 						// a leaf the 8-wide nodes named: its own, exact box decides whether bvh::BIsOccluded visits it
@@ -747,15 +701,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 						r0 = ld_lds(qr), r1 = ld_lds(qr + 1), r2 = ld_lds(qr + 2);
 					}
 				} else {
-					const float4* p = FETCH && !wantPair ? S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT) : S.pairs + 4 * (size_t)lk;
-#if RT_SCALAR_LONE
-					if (nP == 1) {
-						// a lone lane (the drain of a launch: one ray per wave, one dependent step after the other): its record comes
-						// through the scalar cache -- one s_load_dwordx16 instead of four trips through the texture addresser
-						const c_float4* ps = (const c_float4*)uniform_ptr(p);
-						a0 = ld_c(ps), a1 = ld_c(ps + 1), b0 = ld_c(ps + 2), b1 = ld_c(ps + 3);
-					} else
-#endif
+					const float4* p = S.pairs + 4 * (size_t)lk;
 					a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
 					if (useReach) {
 						const float4* q = S.reach + 3 * (size_t)(lk - S.tlasBase);
@@ -765,54 +711,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				RT_SEC_WAIT();
 				RT_SEC_ADD(1, secT);
 				const unsigned long long secT2 = RT_SEC_NOW();
-#if RT_DRAIN_PREFETCH
-				// Experiment, off (profiles/r03_lone_step.txt): in the drain of a launch -- the queue is dry, this wave's last rays make one
-				// dependent step after the other in a nearly empty machine, ~0.6 us per step -- touch the lines of BOTH children's
-				// records as soon as a pair record is here (LDS-DMA, one dword each into an LDS word nobody reads: no destination
-				// register to keep reserved), so that the next step's round trip overlaps this step's arithmetic.  Measured: a lone
-				// lane's step 612 -> 684 ns, every drain-bound number 5-8 % worse.  With the scalar-cache variant (RT_SCALAR_LONE:
-				// level) this says the lone step is not waiting for its record; it is the ~300 instructions of a wave iteration.
-				if (exhausted && !(S.tlasLds && atTlas)) {
-					const uint pc1 = __float_as_uint(a0.w), pc2 = __float_as_uint(b0.w);
-					if (!(pc1 & RT_INST_BIT)) {
-						const float4* q = (pc1 & RT_LEAF_BIT) ? S.prims + 4 * (size_t)(pc1 & ~RT_LEAF_BIT) : S.pairs + 4 * (size_t)pc1;
-						__builtin_amdgcn_global_load_lds((const glb_uint*)q, (lds_uint*)pfDump, 4, 0, 0);
-					}
-					if (!(pc2 & RT_INST_BIT)) {
-						const float4* q = (pc2 & RT_LEAF_BIT) ? S.prims + 4 * (size_t)(pc2 & ~RT_LEAF_BIT) : S.pairs + 4 * (size_t)pc2;
-						__builtin_amdgcn_global_load_lds((const glb_uint*)q, (lds_uint*)pfDump, 4, 0, 0);
-					}
-				}
-#endif
-#ifdef RT_EXPERIMENT_EXTRA_LOADS
-				// measurement only: N more loads of a pair record (L1 hits, nobody waits for them): does the
-				// vector-memory path limit this kernel?
-				{
-					const float4* xp = S.pairs + 4 * (size_t)(S.tlasLds && atTlas ? 0u : lk);
-					for (int xl = 0; xl < RT_EXPERIMENT_EXTRA_LOADS; xl++) asm volatile("global_load_dword %0, %1, off offset:%2" : "+v"(xdummy) : "v"(xp), "i"(4 * (xl & 15)));
-				}
-#endif
-#ifdef RT_EXPERIMENT_EXTRA_VALU
-				// measurement only: N more independent VALU instructions per pair step: is the vector ALU the limiter?
-				{
-					float xv0 = rayT, xv1 = O.x, xv2 = O.y, xv3 = O.z;
-					for (int xl = 0; xl < RT_EXPERIMENT_EXTRA_VALU / 4; xl++)
-						asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(xv0), "+v"(xv1), "+v"(xv2), "+v"(xv3));
-					if (xv0 + xv1 + xv2 + xv3 == 123.456f && n < 0) *overflow = 3;
-				}
-#endif
-#ifdef RT_EXPERIMENT_EXTRA_SALU
-				// measurement only: N more scalar instructions per pair step
-				{
-					int xs = n;
-					for (int xl = 0; xl < RT_EXPERIMENT_EXTRA_SALU; xl++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(xs));
-					if (xs == 0x7fffffff && n < 0) *overflow = 3;
-				}
-#endif
-				if (FETCH && !wantPair) {
-					leaf_test(lk, a0, a1, b0, b1);
-					continue;
-				}
 				float dist1, dist2;
 				if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
 				else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
@@ -838,12 +736,12 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		bool wantLeaf = live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
 		bool wantExit = live && lk == RT_LINK_EXIT;
 		bool wantEnter = live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT);
-		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(live && !(lk & (RT_LEAF_BIT | RT_INST_BIT)))); // FETCH: max(nL, nP) stands for their sum below
+		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(live && !(lk & (RT_LEAF_BIT | RT_INST_BIT))));
 		const int nN = __popcll(__ballot(wantEnter)), nE = __popcll(__ballot(wantExit));
 		int most = nL > nP ? nL : nP;
 		most = nN > most ? nN : most;
 		most = nE > most ? nE : most;
-		const bool runLeaf = !FETCH && nL > 0 && (nL >= stepMin || nL == most);
+		const bool runLeaf = nL > 0 && (nL >= stepMin || nL == most);
 		const bool runEnter = nN > 0 && (nN >= stepMinXform || nN == most);
 		const bool runExit = nE > 0 && (nE >= stepMinXform || nE == most);
 		if (most == 0 && __ballot(live) != 0) {
@@ -859,17 +757,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		if (runEnter && wantEnter) nenter++;
 #endif
 		if (runLeaf && wantLeaf) {
-			// a leaf step of its own (the wide walk): all four vectors of the record in one go (nearly every record is a triangle)
+			// one primitive of a leaf: all four vectors of the record in one go (nearly every record is a triangle)
 			const float4* rec = S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT);
 			const unsigned long long secT = RT_SEC_NOW();
 			RT_SEC_COUNT(10);
 			float4 r0, r1, r2, r3;
-#if RT_SCALAR_LONE
-			if (nL == 1) {
-				const c_float4* rs = (const c_float4*)uniform_ptr(rec);
-				r0 = ld_c(rs), r1 = ld_c(rs + 1), r2 = ld_c(rs + 2), r3 = ld_c(rs + 3);
-			} else
-#endif
 			r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
 			RT_SEC_WAIT();
 			RT_SEC_ADD(3, secT);

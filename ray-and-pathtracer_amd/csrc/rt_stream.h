@@ -397,9 +397,6 @@ __device__ __forceinline__ void load_tables(DScene& S, ShadeTables& L, int enabl
 
 // shade: everything Sample does at the hit of entry e except the occlusion-dependent direct terms (renderer.cpp:133-233).
 // fresh: first segment of a sample (entry index = sample of the batch; W = 1, L = 0, E evaluated, nothing read).
-#ifndef RT_SHADE_PREFETCH
-#define RT_SHADE_PREFETCH 0
-#endif
 #ifndef RT_SHADE_S_WAVES
 #define RT_SHADE_S_WAVES 5
 #endif
@@ -418,40 +415,8 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 	const int n = T.counts[SC_N + round % 3];
 	const size_t cap = (size_t)T.cap;
 	const int nIter = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
-#if RT_SHADE_PREFETCH
-	// Software pipelining (measurement build, off): the loads of the NEXT entry go out before this entry is shaded and its outputs
-	// are stored, so that they are older than the stores in the in-order vmcnt counter and are waited for alone.  The idea was
-	// that every iteration pays a store round trip plus a load round trip before its first arithmetic (waves waiting 54-66 % of
-	// their cycles, VALU pipes 0.31-0.39 busy, 0.34-0.44 of the HBM peak).  Measured: the 23 extra registers cost the fifth wave
-	// and shade + light goes 12.07 -> 12.93 ms (five waves with 64 B of scratch: 14.16) -- whatever the kernel waits for, it is not
-	// that (profiles/r03_ab_shade_prefetch.txt).
-	struct ShadeIn { float4 o4, d4, hn, e4, w4, l4; int2 id, p; uint c; };
-	auto fetch = [&](int e, ShadeIn& x) {
-		x.c = 0, x.p = make_int2(0, 0);
-		if (e < n) {
-			x.c = T.cls[parity][e];
-			x.o4 = T.O[parity][e], x.d4 = T.D[parity][e], x.hn = T.hitN[parity][e], x.id = T.hitId[parity][e], x.p = T.pos[e];
-			if (!fresh) x.e4 = T.E[parity][e], x.w4 = T.W[parity][e], x.l4 = T.L[parity][e];
-		}
-	};
-	ShadeIn nxt;
-	fetch((int)(blockIdx.x * blockDim.x + threadIdx.x), nxt);
-#endif
 	for (int it = 0; it < nIter; it++) {
 		const int e = it * (int)(gridDim.x * blockDim.x) + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-#if RT_SHADE_PREFETCH
-		const ShadeIn cur = nxt;
-		if (it + 1 < nIter) fetch(e + (int)(gridDim.x * blockDim.x), nxt);
-		float4 o4 = cur.o4, d4 = cur.d4, hn = cur.hn, e4 = cur.e4, w4 = cur.w4, l4 = cur.l4;
-		int2 id = cur.id, p = cur.p;
-		const unsigned char c = (unsigned char)cur.c;
-		if (c & CL_LIVE) {
-			if (fresh) {
-				e4 = fresh_energy(C, R, R.sampleFirst + (uint)e);
-				w4 = make_float4(1, 1, 1, 0);
-				l4 = make_float4(0, 0, 0, __uint_as_float(R.sampleFirst + (uint)e));
-			}
-#else
 		// after round 0 every entry is live: all of an entry's loads go out together, the class byte among them (round 0
 		// looks at the class first: the entries of samples finished by generate hold nothing, and they come in long runs)
 		const bool spec = !fresh && e < n;
@@ -470,7 +435,6 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_SHADE_S_WAVES) k_shade_s(DScene S
 				l4 = make_float4(0, 0, 0, __uint_as_float(R.sampleFirst + (uint)e));
 				if (c & CL_CONT) p = T.pos[e];
 			}
-#endif
 			RT_CHECK(!(c & CL_CONT) || (p.x >= 0 && p.x < T.cap && p.y >= 0 && p.y < T.cap), 21, &T.counts[SC_FLAG]);
 			const f3 O = xyz(o4), D = xyz(d4), normal = xyz(hn);
 			const float t = hn.w;
