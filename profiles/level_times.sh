@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 for scene in mixed_small pretty_tlas; do
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/lv_$scene
-  ( cd $GRAFT_REPO_ROOT && RT_MEGA_LEVELS=1 RT_LEVEL_DECIDE=${LD:-1} rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lv_$scene -- python3 profiles/whitted_ticks.py $scene 8 > /dev/null 2>&1 )
+  ( cd $GRAFT_REPO_ROOT && RT_MEGA_LEVELS=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lv_$scene -- python3 profiles/whitted_ticks.py $scene 8 > /dev/null 2>&1 )
   f=$(find $GRAFT_REPO_ROOT/gpurun_out/lv_$scene -name "*kernel_trace.csv" | head -1)
   echo "== $scene"
   python3 - "$f" <<'PY'

@@ -81,7 +81,7 @@ struct rt_ctx {
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
 	std::vector<void*> megaAllocs;
-	int megaLanes = 0, gridMega = 0, gridMegaPath = 0, gridLevel = 0;
+	int megaLanes = 0, gridMega = 0, gridLevel = 0;
 	// Whitted frames by tree levels (rt_mega.h LevelState): queues, term log
 	std::vector<void*> levelAllocs;
 	LevelState V;
@@ -101,10 +101,6 @@ struct rt_ctx {
 	                         // lane that answered its ray there idles until the next refill all the same)
 	int deferGamma = 1;      // RT_DEFER_GAMMA: path-mode samples get their gamma in k_accumulate (rt_kernels.h store_sample)
 	int megaLpt = 1;         // RT_MEGA_LPT: 0 keeps the multiplicative permutation
-	int levelDecide = 0;     // RT_LEVEL_DECIDE: the same in the launches by tree levels (level as well: 3.08 against 3.02 ms)
-	int megaDecide = 0;      // RT_MEGA_DECIDE: the flush answers queries that need no walk (measured: level, the launch is as long as its longest pixel)
-	int megaPathMax = 0;     // RT_MEGA_PATH_MAX: path batches up to this many samples run as one launch too (k_path_mega).  Off: measured slower than
-	                         // the five rounds of rt_stream.h at every size (1080p x 1: 3.33 against 3.01 ms, x 2: 4.92 / 3.88; profiles/r03_tick_time.txt)
 	int useMega = 1;         // RT_MEGA: 1 Whitted frames as one launch (default), 0 the wavefront rounds of rt_kernels.h
 	// Q-learning guided sampling (rt_qlearn.h)
 	QTable Qt;
@@ -316,9 +312,6 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_MEGA_LEVELS")) c->megaLevels = atoi(getenv("RT_MEGA_LEVELS"));
 	if (getenv("RT_DECIDE_SHADOW")) c->decideShadow = atoi(getenv("RT_DECIDE_SHADOW")) != 0;
 	if (getenv("RT_DEFER_GAMMA")) c->deferGamma = atoi(getenv("RT_DEFER_GAMMA")) != 0;
-	if (getenv("RT_MEGA_DECIDE")) c->megaDecide = atoi(getenv("RT_MEGA_DECIDE")) != 0;
-	if (getenv("RT_LEVEL_DECIDE")) c->levelDecide = atoi(getenv("RT_LEVEL_DECIDE")) != 0;
-	if (getenv("RT_MEGA_PATH_MAX")) c->megaPathMax = atoi(getenv("RT_MEGA_PATH_MAX"));
 	memset(&c->M, 0, sizeof(c->M));
 	memset(&c->Qt, 0, sizeof(c->Qt));
 	if (getenv("RT_SHADE_LDS")) c->shadeLds = atoi(getenv("RT_SHADE_LDS")) != 0;
@@ -352,7 +345,6 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridTraverseS = resident((const void*)k_traverse_s);
 		c->gridMega = resident((const void*)k_whitted_mega);
 		c->gridLevel = resident((const void*)k_whitted_level);
-		c->gridMegaPath = resident((const void*)k_path_mega);
 		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : std::min(resident((const void*)k_shade_s<false>), resident((const void*)k_shade_s<true>));
 		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
@@ -1534,8 +1526,8 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 		while (gcd(p, nTiles) != 1) p += 2;
 		R.permMul = p;
 	}
-	const int gridMax = R.mode == RT_MODE_WHITTED ? c->gridMega : c->gridMegaPath;
-	const int lanes = std::max(std::max(c->gridMega, c->gridMegaPath), c->gridLevel) * RT_BLOCK; // run_levels indexes the same arrays by lane of ITS grid
+	const int gridMax = c->gridMega;
+	const int lanes = std::max(c->gridMega, c->gridLevel) * RT_BLOCK; // run_levels indexes the same arrays by lane of ITS grid
 	if (c->megaLanes < lanes) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		free_pool(c->megaAllocs);
@@ -1620,8 +1612,7 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 	tail_probe_reset(c->stream);
 #endif
 	prof_begin(c, K_EXTEND);
-	if (R.mode == RT_MODE_WHITTED) hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->megaDecide, c->spill, c->flags);
-	else hipLaunchKernelGGL(k_path_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
+	hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
 	prof_end(c);
 #ifdef RT_TAIL_PROBE
 	tail_probe_print(c->stream, "mega", 0);
@@ -1669,7 +1660,7 @@ static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int
 		if (level > 0) (void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		V.level = level;
 		const int grid = level == 0 ? std::min(grid0, c->gridLevel) : c->gridLevel;
-		hipLaunchKernelGGL(k_whitted_level, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M0, V, tuning(c, (c->refillMin & ~0xFF) | refill), c->levelDecide, c->spill, c->flags);
+		hipLaunchKernelGGL(k_whitted_level, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M0, V, tuning(c, (c->refillMin & ~0xFF) | refill), c->spill, c->flags);
 	}
 	hipLaunchKernelGGL(k_whitted_reduce, dim3((R.nSamples + 255) / 256), dim3(256), 0, c->stream, R, V);
 	prof_end(c);
@@ -1958,7 +1949,7 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 		}
 		if (mode == RT_MODE_PATH && c->Qt.on && !stream_eligible(c, mode, total))
 			return fail(c, RT_E_UNSUPPORTED, "rt_render: the Q-learning sampler needs a path batch with an entry per sample (within the slot budget, no RT_COUNT_REFERENCE)");
-		if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && !c->Qt.on && c->S.nLights <= 8 && total <= (size_t)c->megaPathMax))) {
+		if (c->useMega && !c->counting && mode == RT_MODE_WHITTED) {
 			rc = run_mega(c, R);
 			if (rc != RT_OK) return rc;
 			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
@@ -2033,7 +2024,7 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 	if (mode == RT_MODE_PATH && c->pathUnsupported) {
 		hipLaunchKernelGGL(k_sample_general, dim3(c->gridBlocks), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, c->spill, c->flags + 1);
 		rc = check_overflow(c);
-	} else if (c->useMega && !c->counting && (mode == RT_MODE_WHITTED || (!c->pathUnsupported && !c->Qt.on && c->S.nLights <= 8 && n <= c->megaPathMax))) {
+	} else if (c->useMega && !c->counting && mode == RT_MODE_WHITTED) {
 		rc = run_mega(c, R);
 	} else if (stream_eligible(c, mode, (size_t)n)) {
 		rc = ensure_stream_state(c, n);
@@ -2439,9 +2430,9 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d decide_shadow=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d mega_decide=%d mega_path_max=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d decide_shadow=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->decideShadow, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->megaDecide, c->megaPathMax, c->Qt.on,
+	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();

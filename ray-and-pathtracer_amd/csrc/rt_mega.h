@@ -103,8 +103,6 @@ struct WhittedMegaPolicy {
 	const MegaState& M;
 	int gl;     // this lane's column in M
 	int* flag;
-	int decide; // queries whose first traversal step leaves nothing to visit are answered in the flush (ray_decided)
-	mutable bool startsDone = false; // the work item just loaded is such a query
 
 	__device__ __forceinline__ bool any_of(int) const { return false; } // a pixel starts with Scene::FindNearest
 	// Work item -> sample.  Consecutive work items are handed to the lanes of one wave, and a pixel's cost is its tree: 1 segment
@@ -152,10 +150,8 @@ struct WhittedMegaPolicy {
 		M.E[gl] = mk4(E, __int_as_float(0));
 		M.L[gl] = make_float4(0, 0, 0, __uint_as_float((uint)__builtin_amdgcn_s_memrealtime())); // w: when the lane took the sample
 		new_segment(O, D, tmax, head);
-		startsDone = decide && ray_decided(S, O, D, tmax); // a pixel of the sky or the floor: straight to the flush, see advance()
 		return true;
 	}
-	__device__ __forceinline__ bool starts_done() const { return startsDone; }
 	__device__ __forceinline__ void push(int& np, const f3& O, const f3& D, const f3& W, const f3& E, int depth) const
 	{
 		if (np >= RT_PEND_CAP) { *flag = 2; return; }
@@ -287,20 +283,12 @@ struct WhittedMegaPolicy {
 		if (M.cost) M.cost[sid - R.sampleFirst] = (uint)__builtin_amdgcn_s_memrealtime() - __float_as_uint(l4.w);
 		return false;
 	}
-	// The flush: the body of Trace for the query that ended -- and for every further query of the pixel that its producer can
-	// answer itself, because the first traversal step (the root pair's boxes, in TLAS mode the reach boxes) would leave it nothing
-	// to visit: the result is then what the head tests left (nearest hit) or "visible" (shadow query), exactly what the walk
-	// returns after that step (ray_decided, rt_stream.h).  A floor pixel -- primary ray, one shadow query per light -- or a
-	// reflection into the sky never enters the walk; a lane leaves the flush with a query that needs the walk, or free.
-	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res0, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
+	// The flush: the body of Trace for the query that ended.  (Answering the pixel's further queries here when their first
+	// traversal step would leave nothing to visit was measured level -- the launch is as long as its longest pixel -- and taken
+	// out: profiles/patches/mega_decide_and_path_mega.diff.)
+	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
 	{
-		HitRef res = res0;
-		for (;;) {
-			if (!advance_once(work, wasAny, res, O, D, tmax, head, nextAny)) return false;
-			if (!decide || !ray_decided(S, O, D, tmax)) return true;
-			wasAny = nextAny, res = head, res.t = tmax;
-			head.kind = -1, head.prim = 0, head.inst = -1;
-		}
+		return advance_once(work, wasAny, res, O, D, tmax, head, nextAny);
 	}
 };
 
@@ -342,8 +330,6 @@ struct WhittedLevelPolicy {
 	int gl;
 	int* flag;
 	lds_int* res; // this wave's reservation in the next level's queue: [0] next slot, [1] end
-	int decide;   // queries whose first traversal step leaves nothing to visit are answered in the flush (ray_decided)
-	mutable bool startsDone = false;
 
 	__device__ __forceinline__ bool any_of(int) const { return false; }
 	__device__ __forceinline__ bool sample_of(int work, uint& sid) const
@@ -385,10 +371,8 @@ struct WhittedLevelPolicy {
 			M.L[gl] = make_float4(s2.w, s3.w, s1.w, 0);
 		}
 		new_segment(O, D, tmax, head);
-		startsDone = decide && ray_decided(S, O, D, tmax);
 		return true;
 	}
-	__device__ __forceinline__ bool starts_done() const { return startsDone; }
 	// the one term of this segment, under its key, at the front of its sample's list
 	__device__ __forceinline__ void log_term(int work, unsigned long long key, uint sid, const f3& v) const
 	{
@@ -450,23 +434,15 @@ struct WhittedLevelPolicy {
 		O = I + dir * 1e-4f, D = dir, tmax = sqrtf(len2), nextAny = true;
 		return true;
 	}
-	// as WhittedMegaPolicy::advance: a shadow query of the light loop that needs no walk is answered at once
-	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& resIn, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
+	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
 	{
-		HitRef res = resIn;
-		for (;;) {
-			if (!advance_once(work, wasAny, res, O, D, tmax, head, nextAny)) {
-				// level 0: how long the lane held the camera ray and its light loop -- the next frame's order (k_mega_order)
-				if (V.level == 0 && M.cost) {
-					const float4 l4 = M.L[gl];
-					M.cost[__float_as_uint(l4.z) - R.sampleFirst] = (uint)__builtin_amdgcn_s_memrealtime() - __float_as_uint(l4.w);
-				}
-				return false;
-			}
-			if (!decide || !ray_decided(S, O, D, tmax)) return true;
-			wasAny = nextAny, res = head, res.t = tmax;
-			head.kind = -1, head.prim = 0, head.inst = -1;
+		if (advance_once(work, wasAny, res, O, D, tmax, head, nextAny)) return true;
+		// level 0: how long the lane held the camera ray and its light loop -- the next frame's order (k_mega_order)
+		if (V.level == 0 && M.cost) {
+			const float4 l4 = M.L[gl];
+			M.cost[__float_as_uint(l4.z) - R.sampleFirst] = (uint)__builtin_amdgcn_s_memrealtime() - __float_as_uint(l4.w);
 		}
+		return false;
 	}
 	__device__ __forceinline__ bool advance_once(int work, bool wasAny, const HitRef& res0, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
 	{
@@ -553,202 +529,20 @@ struct WhittedLevelPolicy {
 	}
 };
 
-// Renderer::Sample (path mode, renderer.cpp:128-236) the same way, for batches the size of a Tick: a frame of the dense
-// wavefront (rt_stream.h) is five rounds whose traversal launches are mostly drain at 2 M samples (a path Tick of the bench
-// scene: 2.2 of 2.95 ms).  A lane keeps its sample for all five hit levels; the random stream of the sample is drawn in the
-// order Sample draws it (light positions, then the hemisphere ray, at the diffuse hit; the shadow queries follow one by one),
-// and the terms enter the radiance in the order the wavefront kernels add them: the frame is theirs bit for bit.
-// M.pend holds, per lane, the continuation of the diffuse hit whose light loop is running ([0..2]: next ray and weight) and the
-// sampled light positions ([4 + light]).
-struct PathMegaPolicy {
-	static constexpr bool kAdvance = true;
-	const DScene& S;
-	const DCamera& C;
-	const RenderParams& R;
-	const MegaState& M;
-	int gl;
-	int* flag;
-
-	__device__ __forceinline__ bool any_of(int) const { return false; }
-	__device__ __forceinline__ bool sample_of(int work, uint& sid) const
-	{
-		uint w = (uint)work;
-		if (R.permMul) {
-			const uint sh = R.permShift, nTiles = (R.nSamples + (1u << sh) - 1) >> sh;
-			w = ((uint)(((unsigned long long)(w >> sh) * R.permMul) % nTiles) << sh) + (w & ((1u << sh) - 1));
-		}
-		sid = R.sampleFirst + w;
-		return w < R.nSamples;
-	}
-	__device__ __forceinline__ void new_segment(const f3& O, const f3& D, float& tmax, HitRef& head) const
-	{
-		float rayT = 1e34f;
-		head.kind = -1, head.inst = -1, head.prim = 0, head.t = 0;
-		LaneCounters unused;
-		find_nearest_head<false>(S, O, D, 0.001f, rayT, head, unused); // renderer.cpp:131
-		M.O[gl] = mk4(O, 0.0f), M.D[gl] = mk4(D, 0.0f);
-		tmax = rayT;
-	}
-	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
-	{
-		uint sid;
-		if (!sample_of(work, sid)) return false;
-		f3 E(1.0f);
-		uint seed;
-		if (R.customO) {
-			O = f3(R.customO[3 * sid], R.customO[3 * sid + 1], R.customO[3 * sid + 2]);
-			D = f3(R.customD[3 * sid], R.customD[3 * sid + 1], R.customD[3 * sid + 2]);
-			E = f3(R.customE[0], R.customE[1], R.customE[2]);
-			seed = StreamSeed(R.seedBase + sid);
-		} else sample_primary(C, R, sid, O, D, seed);
-		M.W[gl] = make_float4(1, 1, 1, __int_as_float(start_depth(R)));
-		M.E[gl] = mk4(E, __uint_as_float(seed));
-		M.L[gl] = make_float4(0, 0, 0, 0);
-		new_segment(O, D, tmax, head);
-		return true;
-	}
-	__device__ __forceinline__ float4* cont() const { return M.pend + (size_t)gl * RT_PEND_CAP * 4; }
-	// the shadow query towards the sampled position of light i (renderer.cpp:161-165; as StreamConnectPolicy::load)
-	__device__ __forceinline__ void shadow_query(int i, const f3& I, f3& O, f3& D, float& tmax, bool& nextAny) const
-	{
-		const f3 pickedPos = xyz(cont()[4 + i]);
-		f3 dir = pickedPos - I;
-		const float len2 = dot(dir, dir);
-		dir = normalize(dir);
-		O = I + dir * 1e-4f, D = dir, tmax = sqrtf(len2), nextAny = true;
-	}
-	__device__ __forceinline__ bool advance(int work, bool wasAny, const HitRef& res, f3& O, f3& D, float& tmax, HitRef& head, bool& nextAny) const
-	{
-		const float4 w4 = M.W[gl], e4 = M.E[gl], l4 = M.L[gl];
-		f3 W = xyz(w4), E = xyz(e4), Lsum = xyz(l4);
-		const int depth = __float_as_int(w4.w);
-		uint seed = __float_as_uint(e4.w);
-		const f3 rayO = xyz(M.O[gl]), rayD = xyz(M.D[gl]);
-		const int nDepth = depth - 1;
-		const bool childTraces = nDepth >= 0; // Sample(depth < 0) = 0.05 (renderer.cpp:129)
-		bool segmentEnds = true;
-		f3 nO(0.0f), nD(0.0f), nW(0.0f);
-		nextAny = false;
-		if (!wasAny) {
-			// ---- Sample at the hit of this segment (k_shade_s) ----
-			int objIdx, matId;
-			f3 normal;
-			resolve_hit(S, res, rayO, rayD, objIdx, matId, normal);
-			const float t = res.t;
-			const f3 I = rayO + t * rayD;
-			if (objIdx == -1) Lsum = Lsum + W * sky_color(S, rayD);
-			else if (objIdx >= 11 && objIdx < 11 + S.nLights) Lsum = Lsum + W * light_intensity(S.lights[objIdx - 11], I, normal, I);
-			else {
-				const DMaterial m = S.mats[matId];
-				const f3 col(m.col[0], m.col[1], m.col[2]);
-				if (m.type == 3) { // GLASS, renderer.cpp:198-233
-					const float kr = glass_fresnel(normalize(rayD), normalize(normal), m.ir);
-					const bool outside = dot(rayD, normal) < 0;
-					const f3 bias = 0.0001f * normal;
-					const f3 norm = outside ? normal : -normal;
-					const float r = !outside ? m.ir : (1 / m.ir);
-					if (outside) {
-						const float ax = m.absorption[0] * -t, ay = m.absorption[1] * -t, az = m.absorption[2] * -t;
-						if (ax != 0) E.x *= x_expf(ax);
-						if (ay != 0) E.y *= x_expf(ay);
-						if (az != 0) E.z *= x_expf(az);
-					}
-					const bool refr = kr < RandomFloat(seed);
-					if (refr) {
-						nD = normalize(glass_refract(rayD, norm, r));
-						nO = outside ? I - bias : I + bias;
-						const f3 tempCol = col * E;
-						nW = W * (tempCol * (1 - kr));
-					} else {
-						nD = normalize(reflect(rayD, norm));
-						nO = outside ? I + bias : I - bias;
-						nW = W * (col * kr);
-					}
-					if (childTraces) segmentEnds = false;
-					else Lsum = Lsum + nW * f3(0.05f);
-				} else if (m.type == 2) { // METAL, renderer.cpp:192-197
-					nO = I + normal * 0.001f, nD = reflect(rayD, normal);
-					nW = W * col;
-					if (childTraces) segmentEnds = false;
-					else Lsum = Lsum + nW * f3(0.05f);
-				} else { // DIFFUSE, renderer.cpp:156-191: every draw of this hit now, the shadow queries one by one afterwards
-					float4* ct = cont();
-					for (int i = 0; i < S.nLights; i++) ct[4 + i] = mk4(light_position(S.lights[i], false, seed), 0.0f);
-					const f3 albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
-					const f3 rayToHemi = RandomInHemisphere(seed, normal);
-					const f3 cos_i(dot(rayToHemi, normal));
-					nO = I, nD = rayToHemi;
-					nW = W * ((2 * (col * cos_i)) * albedo);
-					if (!childTraces) Lsum = Lsum + nW * f3(0.05f);
-					if (S.nLights > 0) {
-						ct[0] = mk4(nO, 0.0f), ct[1] = mk4(nD, 0.0f), ct[2] = mk4(nW, 0.0f);
-						M.hI[gl] = mk4(I, __int_as_float(matId));
-						M.hN[gl] = mk4(normal, __int_as_float(0));
-						M.hS[gl] = make_float4(0, 0, 0, 0);
-						M.E[gl] = mk4(E, __uint_as_float(seed));
-						M.L[gl] = mk4(Lsum, 0.0f);
-						shadow_query(0, I, O, D, tmax, nextAny);
-						return true;
-					}
-					if (childTraces) segmentEnds = false;
-				}
-			}
-		} else {
-			// ---- the occlusion answer for light i of the diffuse hit (k_light_s) ----
-			const float4 i4 = M.hI[gl], n4 = M.hN[gl], s4 = M.hS[gl];
-			const f3 I = xyz(i4), normal = xyz(n4);
-			f3 direct = xyz(s4);
-			const int i = __float_as_int(n4.w);
-			const DMaterial m = S.mats[__float_as_int(i4.w)];
-			const f3 col(m.col[0], m.col[1], m.col[2]);
-			if (res.kind != 1) { // visible: scatter only now (renderer.cpp:166-169)
-				const f3 pickedPos = xyz(cont()[4 + i]);
-				const f3 lightRayDirection = normalize(pickedPos - I);
-				const f3 att = diffuse_scatter(m, rayD, lightRayDirection, light_intensity(S.lights[i], I, normal, pickedPos), normal, E);
-				direct = direct + (1 - m.shinieness) * col * att * E;
-			}
-			if (i + 1 < S.nLights) {
-				M.E[gl] = mk4(E, e4.w);
-				M.hN[gl] = mk4(normal, __int_as_float(i + 1));
-				M.hS[gl] = mk4(direct, 0.0f);
-				shadow_query(i + 1, I, O, D, tmax, nextAny);
-				return true;
-			}
-			const f3 albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
-			Lsum = Lsum + W * ((direct * RT_INVPI) * albedo);
-			const float4* ct = cont();
-			nO = xyz(ct[0]), nD = xyz(ct[1]), nW = xyz(ct[2]);
-			if (childTraces) segmentEnds = false;
-		}
-		if (!segmentEnds) {
-			M.W[gl] = mk4(nW, __int_as_float(nDepth));
-			M.E[gl] = mk4(E, __uint_as_float(seed));
-			M.L[gl] = mk4(Lsum, 0.0f);
-			O = nO, D = nD;
-			new_segment(O, D, tmax, head);
-			return true;
-		}
-		uint sid;
-		sample_of(work, sid);
-		store_sample(R, sid, Lsum);
-		return false;
-	}
-};
-
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 4 // measured: 3 waves (no spill) and 5 are slower, profiles/r03_tick_mega.txt
 #endif
-__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, int decide, uint* spill, int* work)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, uint* spill, int* work)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	WhittedMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], decide };
+	WhittedMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1] };
 	trace_persistent<false, false, false, WhittedMegaPolicy, true>(S, pol, M.nWork, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScene S, DCamera C, RenderParams R, MegaState M, LevelState V, int refillMin, int decide, uint* spill, int* work)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScene S, DCamera C, RenderParams R, MegaState M, LevelState V, int refillMin, uint* spill, int* work)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	__shared__ int reservation[RT_BLOCK / 64][2];
@@ -757,7 +551,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScen
 	uint rays = 0;
 	lds_int* res = (lds_int*)&reservation[threadIdx.x >> 6][0];
 	if ((threadIdx.x & 63) == 0) res[0] = 0, res[1] = 0;
-	WhittedLevelPolicy pol{ S, C, R, M, V, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], res, decide };
+	WhittedLevelPolicy pol{ S, C, R, M, V, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], res };
 	const int n = V.level == 0 ? M.nWork : (V.count[V.level] < V.qcap ? V.count[V.level] : V.qcap);
 	trace_persistent<false, false, false, WhittedLevelPolicy, true>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 	// the slots this wave reserved and did not fill are nothing to trace
@@ -784,16 +578,6 @@ __global__ void k_whitted_reduce(RenderParams R, LevelState V)
 		last = bestKey, first = false;
 	}
 	store_sample(R, R.sampleFirst + s, L);
-}
-
-__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_path_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, uint* spill, int* work)
-{
-	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
-	LaneCounters lc;
-	lc.clear();
-	uint rays = 0;
-	PathMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1] };
-	trace_persistent<false, false, false, PathMegaPolicy, true>(S, pol, M.nWork, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
 }
 
 } // namespace rtd

@@ -206,10 +206,11 @@ def test_whitted_frame(name, kw, w, h, scenes, oracle_api, host_api):
 
 @pytest.mark.parametrize("name,kw,w,h", RENDER_SCENES)
 @pytest.mark.parametrize("frames", [1, 4, 16])
-@pytest.mark.parametrize("pipeline", ["one_launch", "stream"])
+@pytest.mark.parametrize("pipeline", ["slot", "stream"])
 def test_path_frames(name, kw, w, h, frames, pipeline, scenes, oracle_api, host_api, monkeypatch):
-    # "stream": the dense wavefront (csrc/rt_stream.h, the default); "one_launch": a lane keeps its sample for all hit levels (csrc/rt_mega.h k_path_mega, opt-in)
-    monkeypatch.setenv("RT_MEGA_PATH_MAX", "0" if pipeline == "stream" else "4194304")
+    # "stream": the dense wavefront (csrc/rt_stream.h, the default); "slot": the slot wavefront of csrc/rt_kernels.h (what batches
+    # above the slot budget and RT_COUNT_REFERENCE launches run)
+    monkeypatch.setenv("RT_STREAM", "1" if pipeline == "stream" else "0")
     o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
     check_frames(orr, r, "path", frames, host_api)
     r.close()
@@ -1039,19 +1040,16 @@ def test_fused_traversal_launch_equals_separate_launches(name, kw, w, h, frames,
 def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
     """The dense path pipeline (csrc/rt_stream.h, the default: entries of a round are the survivors of the round before,
     every producer writes to compacted positions; RT_FUSE=0 runs it one kernel at a time) and its producer-side ray
-    decisions (RT_DECIDE: generate / shade answer a ray whose first traversal step leaves nothing to visit), and the opt-in one-launch form
-    (csrc/rt_mega.h k_path_mega, RT_MEGA_PATH_MAX: a lane keeps its sample for all hit levels), against the slot pipeline (RT_STREAM=0): identical accumulator bits -- per sample the arithmetic is the same, only where the path
+    decisions (RT_DECIDE: generate / shade answer a ray whose first traversal step leaves nothing to visit), against the slot pipeline (RT_STREAM=0): identical accumulator bits -- per sample the arithmetic is the same, only where the path
     state lives differs -- the oracle's frame, identical frames from row shards, identical Sample() values for
     caller-supplied rays at every depth, and the same number of FindNearest / IsOccluded queries."""
     out, rays = {}, {}
     pO = pD = None
     for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_gated", {"RT_FUSE": "3"}), ("stream_one_launch_per_round", {"RT_FUSE": "1"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
-                     ("one_launch", {"RT_MEGA_PATH_MAX": "4194304"}),
                      ("stream_decide_shadow", {"RT_DECIDE_SHADOW": "1", "RT_FUSE": "0"}), ("stream_decide_shadow_one_launch_per_round", {"RT_DECIDE_SHADOW": "1", "RT_FUSE": "1"}),
                      ("stream_gamma_at_the_store", {"RT_DEFER_GAMMA": "0"})):
         for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_DECIDE_SHADOW", "RT_DEFER_GAMMA"):
             monkeypatch.delenv(k, raising=False)
-        monkeypatch.setenv("RT_MEGA_PATH_MAX", "0")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
@@ -1072,17 +1070,17 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
             r.render_rows(host_api.RT_MODE_PATH, 0, frames, 0, 2, (h + 1) // 2)
             r.render_rows(host_api.RT_MODE_PATH, 0, frames, 1, 2, h // 2)
             assert np.array_equal(r.accumulator().view(np.uint32), out[key].view(np.uint32))
-        if key in ("slot", "stream", "one_launch"):
+        if key in ("slot", "stream"):
             if pO is None:
                 pO, pD = orr.primary_rays()
                 pO, pD = pO[::7].copy(), pD[::7].copy()
             out[key + "_sample"] = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 99) for depth in (0, 1, 4)]
         r.close()
-    for key in ("stream", "stream_serial", "stream_gated", "stream_one_launch_per_round", "stream_nodecide", "one_launch",
+    for key in ("stream", "stream_serial", "stream_gated", "stream_one_launch_per_round", "stream_nodecide",
                 "stream_decide_shadow", "stream_decide_shadow_one_launch_per_round", "stream_gamma_at_the_store"):
         assert np.array_equal(out["slot"].view(np.uint32), out[key].view(np.uint32)), key
         assert rays[key] == rays["slot"], (key, rays[key], rays["slot"])
-    for other in ("stream_sample", "one_launch_sample"):
+    for other in ("stream_sample",):
         for a, b in zip(out["slot_sample"], out[other]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), other
 
@@ -1155,8 +1153,8 @@ def test_whitted_longest_first_order(name, kw, w, h, scenes, oracle_api, host_ap
     not a multiple of the 8-pixel tile nor of the padded queue."""
     frames = {}
     for key, env in (("rounds", {"RT_MEGA": "0"}), ("plain", {"RT_MEGA_LEVELS": "0", "RT_MEGA_LPT": "0"}), ("lpt", {"RT_MEGA_LEVELS": "0"}),
-                     ("lpt_decide", {"RT_MEGA_LEVELS": "0", "RT_MEGA_DECIDE": "1"}), ("levels", {"RT_MEGA_LEVELS": "1"}), ("levels_decide", {"RT_MEGA_LEVELS": "1", "RT_LEVEL_DECIDE": "1"}), ("auto", {})):
-        for k in ("RT_MEGA", "RT_MEGA_LPT", "RT_MEGA_DECIDE", "RT_MEGA_LEVELS", "RT_LEVEL_DECIDE"):
+                     ("levels", {"RT_MEGA_LEVELS": "1"}), ("auto", {})):
+        for k in ("RT_MEGA", "RT_MEGA_LPT", "RT_MEGA_LEVELS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1184,7 +1182,7 @@ def test_whitted_longest_first_order(name, kw, w, h, scenes, oracle_api, host_ap
         for g in got[1:]:
             assert np.array_equal(g.view(np.uint32), got[0].view(np.uint32)), key
         frames[key] = got[0]
-    for key in ("plain", "lpt", "lpt_decide", "levels", "levels_decide", "auto"):
+    for key in ("plain", "lpt", "levels", "auto"):
         assert np.array_equal(frames[key].view(np.uint32), frames["rounds"].view(np.uint32)), key
 
 
