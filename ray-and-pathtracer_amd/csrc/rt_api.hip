@@ -22,7 +22,6 @@ struct Timer {
 	hipEvent_t a = nullptr, b = nullptr;
 };
 
-#define RT_MAX_POOLS 4
 struct rt_ctx {
 	int device = 0, width = 0, height = 0;
 	hipStream_t stream = nullptr;
@@ -47,25 +46,17 @@ struct rt_ctx {
 	// accumulator
 	float4* accum = nullptr;
 	bool accumOwned = true;
-	// path state: up to RT_MAX_POOLS independent sample pools, each with its own slots, queues, stream
-	// and stack spill area, so that one pool's kernels fill the machine while another's drain
-	struct Pool {
+	// the slot wavefront of rt_kernels.h (Whitted rounds with RT_MEGA=0, path batches above the slot budget, RT_COUNT_REFERENCE
+	// launches, RT_STREAM=0): slots, status bytes, queues; it runs on the context's stream
+	struct SlotState {
 		PathState P;
 		Queues Q;
 		int stateSlots = 0, stateLights = -1;
 		bool statePend = false, stateWide = false;
 		std::vector<void*> allocs;
-		hipStream_t stream = nullptr; // pool 0 runs on the context's stream
-		uint* spill = nullptr;
-		hipEvent_t done = nullptr;
-		// the second stream of the two-stream round loop (run_rounds_fused, RT_FUSE=2): connect(r) + light(r) beside extend(r + 1)
-		hipStream_t sideStream = nullptr;
-		uint* sideSpill = nullptr;
-		hipEvent_t sideFork = nullptr, sideJoin = nullptr;
 	};
-	Pool pools[RT_MAX_POOLS];
-	int fuseTraversal = -1;  // RT_FUSE: how extend(r + 1) and connect(r) share a round (run_rounds_fused): -1 / 2 two kernels on two
-	                         // streams, 1 one launch (k_traverse), 0 the plain loop (run_rounds)
+	SlotState slot;
+	int fuseTraversal = -1;  // RT_FUSE: how connect(r) + light(r) share the machine with round r + 1 in the dense pipeline (run_rounds_stream)
 
 	// the dense path-mode pipeline (rt_stream.h): its state, the second stream for connect + light, and whether it is on
 	StreamState T;
@@ -96,9 +87,6 @@ struct rt_ctx {
 	uint* megaCost = nullptr; uint* megaOrder = nullptr; uint* megaHist = nullptr;
 	size_t megaCostCap = 0;
 	unsigned megaCostSamples = 0, megaCostFirst = 0; // the batch megaCost describes (0 samples: nothing yet)
-	int decideShadow = 0;    // RT_DECIDE_SHADOW: the dense pipeline's connect answers shadow rays that need no walk when it loads them (rt_stream.h
-	                         // StreamConnectPolicy).  Off: measured slower (connect 8.7 -> 9.15 ms: the test moves from a pair step into the refill, and a
-	                         // lane that answered its ray there idles until the next refill all the same)
 	int deferGamma = 1;      // RT_DEFER_GAMMA: path-mode samples get their gamma in k_accumulate (rt_kernels.h store_sample)
 	int megaLpt = 1;         // RT_MEGA_LPT: 0 keeps the multiplicative permutation
 	int useMega = 1;         // RT_MEGA: 1 Whitted frames as one launch (default), 0 the wavefront rounds of rt_kernels.h
@@ -110,13 +98,11 @@ struct rt_ctx {
 	int decideRays = 1;      // RT_DECIDE: producers answer rays whose first traversal step leaves nothing to visit (rt_stream.h ray_decided)
 	int gridTraverseS = 0;
 	int gridExtendS = 0, gridConnectS = 0, gridConnectWideS = 0, gridLeftoverS = 0, gridConnectWide8S = 0;
-	int nPoolsWanted = 1; // RT_POOLS; measured: 2 pools overlap their kernels but do not shorten the frame
-	hipEvent_t fork = nullptr;
-	// traversal stack spill of pool 0 and of the batch queries + flags
+	// traversal stack spill of the context's stream (rounds and batch queries) + flags
 	uint* spill = nullptr;
 	int gridBlocks = 0;
 	std::vector<int> matTypes; // material types of the uploaded scene (measurement builds)
-	int gridExtend = 0, gridConnect = 0, gridQuery = 0, gridTraverse = 0, gridConnectWide = 0, gridLeftover = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
+	int gridExtend = 0, gridConnect = 0, gridQuery = 0, gridConnectWide = 0, gridLeftover = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
 	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
 	int refillAny = 24; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int pairAgain = 16; // lanes that must still want a pair step for an iteration to repeat it (RT_PAIRAGAIN); tuning bits 20-26
@@ -185,7 +171,6 @@ static void prof_collect(rt_ctx* c)
 {
 	if (c->timers.empty()) return;
 	(void)hipStreamSynchronize(c->stream);
-	for (int k = 1; k < RT_MAX_POOLS; k++) if (c->pools[k].stream) (void)hipStreamSynchronize(c->pools[k].stream);
 	rt_kernel_time* slot[5] = { &c->prof.generate, &c->prof.extend, &c->prof.shade, &c->prof.connect, &c->prof.query };
 	for (size_t i = 0; i < c->timers.size(); i++) {
 		float ms = 0;
@@ -302,22 +287,18 @@ rt_ctx* rt_create(int device, int width, int height)
 	rt_ctx* c = new rt_ctx();
 	c->device = device, c->width = width, c->height = height;
 	memset(&c->S, 0, sizeof(c->S));
-	for (int k = 0; k < RT_MAX_POOLS; k++) memset(&c->pools[k].P, 0, sizeof(PathState)), memset(&c->pools[k].Q, 0, sizeof(Queues));
-	if (getenv("RT_POOLS")) c->nPoolsWanted = atoi(getenv("RT_POOLS"));
+	memset(&c->slot.P, 0, sizeof(PathState)), memset(&c->slot.Q, 0, sizeof(Queues));
 	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 3 ? 2 : f); } // 0..3 (dense pipeline: 1 = one traversal launch per round); anything else: the default
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
 	if (getenv("RT_MEGA_LPT")) c->megaLpt = atoi(getenv("RT_MEGA_LPT")) != 0;
 	if (getenv("RT_MEGA_LEVELS")) c->megaLevels = atoi(getenv("RT_MEGA_LEVELS"));
-	if (getenv("RT_DECIDE_SHADOW")) c->decideShadow = atoi(getenv("RT_DECIDE_SHADOW")) != 0;
 	if (getenv("RT_DEFER_GAMMA")) c->deferGamma = atoi(getenv("RT_DEFER_GAMMA")) != 0;
 	memset(&c->M, 0, sizeof(c->M));
 	memset(&c->Qt, 0, sizeof(c->Qt));
 	if (getenv("RT_SHADE_LDS")) c->shadeLds = atoi(getenv("RT_SHADE_LDS")) != 0;
 	memset(&c->T, 0, sizeof(c->T));
-	if (c->nPoolsWanted < 1) c->nPoolsWanted = 1;
-	if (c->nPoolsWanted > RT_MAX_POOLS) c->nPoolsWanted = RT_MAX_POOLS;
 	memset(&c->prof, 0, sizeof(c->prof));
 	memset(&c->C, 0, sizeof(c->C));
 	bool ok = hipStreamCreate(&c->stream) == hipSuccess;
@@ -334,7 +315,6 @@ rt_ctx* rt_create(int device, int width, int height)
 		const int e0 = std::min(resident((const void*)k_extend<false, false>), resident((const void*)k_extend<false, true>)), e1 = std::min(resident((const void*)k_extend<true, false>), resident((const void*)k_extend<true, true>));
 		const int c0 = resident((const void*)k_connect<false>), c1 = resident((const void*)k_connect<true>);
 		c->gridExtend = e0 < e1 ? e0 : e1, c->gridConnect = c0 < c1 ? c0 : c1;
-		c->gridTraverse = resident((const void*)k_traverse);
 		c->gridConnectWide = resident((const void*)k_connect<false, true>);
 		c->gridLeftover = std::min(resident((const void*)k_connect<false, false, true>), prop.multiProcessorCount); // a short list: one block per CU is plenty
 		c->gridExtendS = std::min(resident((const void*)k_extend_s<false>), resident((const void*)k_extend_s<true>));
@@ -370,11 +350,9 @@ rt_ctx* rt_create(int device, int width, int height)
 	ok = ok && hipMemset(c->flags, 0, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->counters, 2 * sizeof(DCounters)) == hipSuccess;
 	ok = ok && hipMemset(c->counters, 0, 2 * sizeof(DCounters)) == hipSuccess;
-	ok = ok && hipHostMalloc((void**)&c->hostCounts, 16 * RT_MAX_POOLS * sizeof(int)) == hipSuccess;
+	ok = ok && hipHostMalloc((void**)&c->hostCounts, 16 * sizeof(int)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->gammaLut, 256 * sizeof(float)) == hipSuccess;
 	if (ok) hipLaunchKernelGGL(k_gamma_lut, dim3(1), dim3(256), 0, c->stream, c->gammaLut);
-	ok = ok && hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess;
-	c->pools[0].stream = c->stream, c->pools[0].spill = c->spill;
 	if (!ok) { fail(nullptr, RT_E_HIP, "rt_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); rt_destroy(c); return nullptr; }
 	// default camera = Camera::Camera (camera.h:10-22) for this aspect
 	const float aspect = (float)width / (float)height;
@@ -394,21 +372,7 @@ void rt_destroy(rt_ctx* c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	prof_collect(c);
 	free_pool(c->sceneAllocs);
-	for (int k = 0; k < RT_MAX_POOLS; k++) {
-		rt_ctx::Pool& pl = c->pools[k];
-		if (k > 0 && pl.stream) { (void)hipStreamSynchronize(pl.stream); (void)hipStreamDestroy(pl.stream); }
-		if (k > 0 && pl.spill) (void)hipFree(pl.spill);
-		if (pl.done) (void)hipEventDestroy(pl.done);
-		free_pool(pl.allocs);
-	}
-	if (c->fork) (void)hipEventDestroy(c->fork);
-	for (int k = 0; k < RT_MAX_POOLS; k++) {
-		rt_ctx::Pool& pl = c->pools[k];
-		if (pl.sideStream) { (void)hipStreamSynchronize(pl.sideStream); (void)hipStreamDestroy(pl.sideStream); }
-		if (pl.sideSpill) (void)hipFree(pl.sideSpill);
-		if (pl.sideFork) (void)hipEventDestroy(pl.sideFork);
-		if (pl.sideJoin) (void)hipEventDestroy(pl.sideJoin);
-	}
+	free_pool(c->slot.allocs);
 	free_pool(c->streamAllocs);
 	free_pool(c->megaAllocs);
 	free_pool(c->megaOrderAllocs);
@@ -1203,16 +1167,12 @@ int rt_set_time(rt_ctx* c, float t)
 static int check_overflow(rt_ctx* c);
 
 // ---- path state -------------------------------------------------------------------------------
-static int ensure_state(rt_ctx* c, int k, int nSlots, bool pend)
+static int ensure_state(rt_ctx* c, int nSlots, bool pend)
 {
-	rt_ctx::Pool& pl = c->pools[k];
-	if (!pl.stream) HIPCHK(c, hipStreamCreate(&pl.stream));
-	if (!pl.done) HIPCHK(c, hipEventCreateWithFlags(&pl.done, hipEventDisableTiming));
-	if (!pl.spill) HIPCHK(c, hipMalloc((void**)&pl.spill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
+	rt_ctx::SlotState& pl = c->slot;
 	const bool wide = c->S.wide != nullptr; // the 4-wide occlusion walk hands rays back through Q.leftover: allocated only for scenes that have it
 	if (pl.stateSlots >= nSlots && pl.stateLights == c->S.nLights && (pl.statePend || !pend) && (pl.stateWide || !wide)) { pl.P.nSlots = nSlots; return RT_OK; }
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	HIPCHK(c, hipStreamSynchronize(pl.stream));
 	free_pool(pl.allocs);
 	pl.stateSlots = 0;
 	PathState P;
@@ -1272,238 +1232,97 @@ static void launch_connect(rt_ctx* c, hipStream_t st, const PathState& P, const 
 		hipLaunchKernelGGL((k_connect<false, false, true>), dim3(c->gridLeftover), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
 	}
 }
-// The round loop shared by rt_render_rows and rt_trace_batch.  The batch's samples are split over
-// nPools pools (R[k].sampleFirst / nSamples); every pool runs the same sequence of kernels on its own
-// stream, so while one pool's traversal launch drains (its longest rays finish alone, at memory latency
-// per step) or its small kernels start up, the other pools' kernels fill the machine.  The context's
-// stream waits for all pools at the end.
-static int run_rounds(rt_ctx* c, const RenderParams* Rs, int nPools, int maxRounds, int knownRounds)
+// The round loop of the slot wavefront (rt_kernels.h), shared by rt_render_rows and rt_trace_batch: Whitted rounds (RT_MEGA=0 and
+// counting launches), path batches with fewer slots than samples, RT_COUNT_REFERENCE launches, RT_STREAM=0.  One kernel at a time on
+// the context's stream.  (Several sample pools on separate streams, and extend(r + 1) beside connect(r) on two streams or as one
+// launch, were measured on this pipeline in rounds 1-2 and superseded by the dense pipeline of rt_stream.h:
+// profiles/patches/slot_pipeline_pools_and_fusing.diff.)
+static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds, int knownRounds)
 {
-	// knownRounds > 0: the caller knows how many rounds empty every pool (path mode with a slot per sample:
+	// knownRounds > 0: the caller knows how many rounds empty the slots (path mode with a slot per sample:
 	// one round per path segment, depth + 1 of them), so no queue length is read back before the end
 	if (knownRounds > 0) maxRounds = knownRounds;
-	const int mode = Rs[0].mode;
+	const int mode = R.mode;
 	const float t_min = mode == RT_MODE_WHITTED ? (float)1e-6 : 0.001f; // renderer.cpp:24, :131
 	const int grid = c->gridBlocks;
-	PathState P[RT_MAX_POOLS];
-	bool live[RT_MAX_POOLS];
-	// pools start after everything already queued on the context's stream
-	HIPCHK(c, hipEventRecord(c->fork, c->stream));
-	for (int k = 0; k < nPools; k++) {
-		rt_ctx::Pool& pl = c->pools[k];
-		P[k] = pl.P;
-		if (mode != RT_MODE_WHITTED) P[k].pend = nullptr, P[k].pendCount = nullptr;
-		live[k] = true;
-		if (k > 0) HIPCHK(c, hipStreamWaitEvent(pl.stream, c->fork, 0));
-		prof_begin(c, K_GENERATE, pl.stream);
-		hipLaunchKernelGGL(k_generate, dim3((P[k].nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, pl.stream, c->S, c->C, Rs[k], P[k], pl.Q);
-		prof_end(c, pl.stream);
-	}
+	PathState P = c->slot.P;
+	if (mode != RT_MODE_WHITTED) P.pend = nullptr, P.pendCount = nullptr;
+	const Queues Q = c->slot.Q;
+	hipStream_t st = c->stream;
+	prof_begin(c, K_GENERATE, st);
+	hipLaunchKernelGGL(k_generate, dim3((P.nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q);
+	prof_end(c, st);
 	int parity = 0, rc = RT_OK;
 	for (int round = 0; round < maxRounds && rc == RT_OK; round++) {
-		for (int k = 0; k < nPools; k++) {
-			if (!live[k]) continue;
-			rt_ctx::Pool& pl = c->pools[k];
-			const Queues Q = pl.Q;
-			hipStream_t st = pl.stream;
-			// round 0 of a batch with a slot per sample: every slot is ACTIVE, so no queue is built and extend /
-			// shade address slots directly
-			const int allActive = round == 0 && Rs[k].finishInline ? P[k].nSlots : 0;
-			hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, P[k].pendCount ? 0 : 1, allActive, 3);
-			if (!allActive) hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ACTIVE, Q.active, &Q.counts[0]);
+		// round 0 of a batch with a slot per sample: every slot is ACTIVE, so no queue is built and extend /
+		// shade address slots directly
+		const int allActive = round == 0 && R.finishInline ? P.nSlots : 0;
+		hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, P.pendCount ? 0 : 1, allActive, 3);
+		if (!allActive) hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
 #ifdef RT_TAIL_PROBE
-			tail_probe_reset(st);
+		tail_probe_reset(st);
 #endif
 #ifdef RT_SECTION_PROBE
-			section_probe_reset(st);
+		section_probe_reset(st);
 #endif
 #ifdef RT_STEP_COUNT
-			step_count_begin(c, st, P[k].nSlots);
+		step_count_begin(c, st, P.nSlots);
 #endif
-			prof_begin(c, K_EXTEND, st);
-			{
-				auto extendKernel = c->counting ? (allActive ? k_extend<true, true> : k_extend<true, false>) : (allActive ? k_extend<false, true> : k_extend<false, false>);
-				hipLaunchKernelGGL(extendKernel, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P[k], Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
-			}
-			prof_end(c, st);
-#ifdef RT_TAIL_PROBE
-			tail_probe_print(st, "extend", round);
-#endif
-#ifdef RT_SECTION_PROBE
-			section_probe_print(st, "extend", round);
-#endif
-#ifdef RT_STEP_COUNT
-			step_count_print(c, st, P[k], parity, round, c->matTypes);
-#endif
-			prof_begin(c, K_SHADE, st);
-			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, Rs[k], P[k], Q, parity, round == 0 && Rs[k].finishInline ? 1 : 0);
-			prof_end(c, st);
-			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
-#ifdef RT_TAIL_PROBE
-			tail_probe_reset(st);
-#endif
-#ifdef RT_SECTION_PROBE
-			section_probe_reset(st);
-#endif
-			prof_begin(c, K_CONNECT, st);
-			launch_connect(c, st, P[k], Q, parity, pl.spill);
-			prof_end(c, st);
-#ifdef RT_TAIL_PROBE
-			tail_probe_print(st, "connect", round);
-#endif
-#ifdef RT_SECTION_PROBE
-			section_probe_print(st, "connect", round);
-#endif
-			prof_begin(c, K_SHADE, st);
-			hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, Rs[k], P[k], Q, parity);
-			if (!Rs[k].finishInline) {
-				hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P[k], (int)ST_ENDED, Q.ended, &Q.counts[1]);
-				hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, Rs[k], P[k], Q, parity);
-			}
-			prof_end(c, st);
+		prof_begin(c, K_EXTEND, st);
+		{
+			auto extendKernel = c->counting ? (allActive ? k_extend<true, true> : k_extend<true, false>) : (allActive ? k_extend<false, true> : k_extend<false, false>);
+			hipLaunchKernelGGL(extendKernel, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		}
+		prof_end(c, st);
+#ifdef RT_TAIL_PROBE
+		tail_probe_print(st, "extend", round);
+#endif
+#ifdef RT_SECTION_PROBE
+		section_probe_print(st, "extend", round);
+#endif
+#ifdef RT_STEP_COUNT
+		step_count_print(c, st, P, parity, round, c->matTypes);
+#endif
+		prof_begin(c, K_SHADE, st);
+		hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q, parity, round == 0 && R.finishInline ? 1 : 0);
+		prof_end(c, st);
+		hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
+#ifdef RT_TAIL_PROBE
+		tail_probe_reset(st);
+#endif
+#ifdef RT_SECTION_PROBE
+		section_probe_reset(st);
+#endif
+		prof_begin(c, K_CONNECT, st);
+		launch_connect(c, st, P, Q, parity, c->spill);
+		prof_end(c, st);
+#ifdef RT_TAIL_PROBE
+		tail_probe_print(st, "connect", round);
+#endif
+#ifdef RT_SECTION_PROBE
+		section_probe_print(st, "connect", round);
+#endif
+		prof_begin(c, K_SHADE, st);
+		hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, R, P, Q, parity);
+		if (!R.finishInline) {
+			hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_ENDED, Q.ended, &Q.counts[1]);
+			hipLaunchKernelGGL(k_finish, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q, parity);
+		}
+		prof_end(c, st);
 		parity = 1 - parity;
-		// look at the queue lengths every few rounds (one small D2H copy + sync per pool); a pool stops when its queue is empty
+		// look at the queue lengths every few rounds (one small D2H copy + sync); the loop stops when the active queue is empty
 		if ((knownRounds <= 0 && (round & 3) == 3) || round + 1 == maxRounds) {
-			for (int k = 0; k < nPools; k++)
-				if (live[k]) HIPCHK(c, hipMemcpyAsync(c->hostCounts + 16 * k, c->pools[k].Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->pools[k].stream));
-			bool any = false;
-			for (int k = 0; k < nPools; k++) {
-				if (!live[k]) continue;
-				HIPCHK(c, hipStreamSynchronize(c->pools[k].stream));
-				const int* hc = c->hostCounts + 16 * k;
-				if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
-				else if (hc[3] == 2) rc = fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
-				else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
-	else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
-				if (hc[3] != 0) (void)hipMemsetAsync(c->pools[k].Q.counts + 3, 0, sizeof(int), c->pools[k].stream);
-				if (hc[0] == 0 || knownRounds > 0) live[k] = false;
-				any = any || live[k];
-			}
-			if (rc != RT_OK || !any) break;
+			HIPCHK(c, hipMemcpyAsync(c->hostCounts, Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+			HIPCHK(c, hipStreamSynchronize(st));
+			const int* hc = c->hostCounts;
+			if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
+			else if (hc[3] == 2) rc = fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
+			else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
+			else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
+			if (hc[3] != 0) (void)hipMemsetAsync(Q.counts + 3, 0, sizeof(int), st);
+			if (rc != RT_OK || hc[0] == 0 || knownRounds > 0) break;
 			if (round + 1 == maxRounds) rc = fail(c, RT_E_STATE, "paths still active after %d rounds", maxRounds);
 		}
-	}
-	// join: the context's stream continues after every pool
-	for (int k = 1; k < nPools; k++) {
-		(void)hipEventRecord(c->pools[k].done, c->pools[k].stream);
-		(void)hipStreamWaitEvent(c->stream, c->pools[k].done, 0);
-	}
-	if (rc != RT_OK) {
-		for (int k = 1; k < nPools; k++) (void)hipStreamSynchronize(c->pools[k].stream);
-		return rc;
-	}
-	HIPCHK(c, hipGetLastError());
-	return RT_OK;
-}
-
-// Path mode with a slot per sample: exactly 'rounds' rounds, nothing to resume, no finish pass.  The only consumer of
-// connect(r) is light(r), and extend(r + 1) needs neither, so the two overlap: mode 2 (default) runs connect(r) and
-// light(r) on the pool's second stream beside extend(r + 1) -- each kernel's drain (a persistent traversal launch ends
-// several hundred microseconds after its queue ran dry, whatever the queue held) is covered by the other's work; mode 1
-// puts both kinds of rays into ONE launch over one work list (k_traverse; loses on large batches: waves that mix
-// nearest and any-hit lanes).  light(r) still needs the hit of round r while extend(r + 1) writes the hits of round
-// r + 1: hitN / hitId are double buffered by round parity like the rays.  Not used by counting launches (their
-// tallies are kept per kind of query).  Several pools (RT_POOLS) take turns round by round; measured slower than one.
-//   generate | begin extend(0) shade(0) cs(0) | begin ca(1) {extend(1) || connect(0) light(0)} shade(1) cs(1) | ...
-//   ... | connect(R-1) light(R-1)
-static int run_rounds_fused(rt_ctx* c, const RenderParams* Rs, int nPools, int rounds, int mode)
-{
-	const float t_min = 0.001f; // renderer.cpp:131
-	const int grid = c->gridBlocks;
-	const bool twoStreams = mode == 2;
-	PathState Ps[RT_MAX_POOLS];
-	// pools start after everything already queued on the context's stream
-	HIPCHK(c, hipEventRecord(c->fork, c->stream));
-	for (int k = 0; k < nPools; k++) {
-		rt_ctx::Pool& pl = c->pools[k];
-		Ps[k] = pl.P;
-		Ps[k].pend = nullptr, Ps[k].pendCount = nullptr;
-		if (k > 0) HIPCHK(c, hipStreamWaitEvent(pl.stream, c->fork, 0));
-		if (twoStreams && !pl.sideStream) {
-			HIPCHK(c, hipStreamCreate(&pl.sideStream));
-			HIPCHK(c, hipMalloc((void**)&pl.sideSpill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)));
-			HIPCHK(c, hipEventCreateWithFlags(&pl.sideFork, hipEventDisableTiming));
-			HIPCHK(c, hipEventCreateWithFlags(&pl.sideJoin, hipEventDisableTiming));
-		}
-		prof_begin(c, K_GENERATE, pl.stream);
-		hipLaunchKernelGGL(k_generate, dim3((Ps[k].nSlots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, pl.stream, c->S, c->C, Rs[k], Ps[k], pl.Q);
-		prof_end(c, pl.stream);
-	}
-	for (int round = 0; round <= rounds; round++) {
-		const int parity = round & 1;
-		for (int k = 0; k < nPools; k++) {
-			rt_ctx::Pool& pl = c->pools[k];
-			const PathState& P = Ps[k];
-			const Queues Q = pl.Q;
-			const RenderParams& R = Rs[k];
-			hipStream_t st = pl.stream;
-			bool lightDone = false;
-			if (round == 0) {
-				hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, P.nSlots, 3);
-				prof_begin(c, K_EXTEND, st);
-				hipLaunchKernelGGL((k_extend<false, true>), dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
-				prof_end(c, st);
-			} else if (round < rounds) {
-				hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
-				hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_ACTIVE, Q.active, &Q.counts[0]);
-				if (twoStreams) {
-					// connect(r - 1) and light(r - 1) on the side stream, extend(r) here: two kernels, each with its own kind of lanes
-					hipStream_t sb = pl.sideStream;
-					HIPCHK(c, hipEventRecord(pl.sideFork, st));
-					HIPCHK(c, hipStreamWaitEvent(sb, pl.sideFork, 0));
-					prof_begin(c, K_CONNECT, sb);
-					launch_connect(c, sb, P, Q, 1 - parity, pl.sideSpill);
-					prof_end(c, sb);
-					prof_begin(c, K_SHADE, sb);
-					hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, sb, c->S, R, P, Q, 1 - parity);
-					prof_end(c, sb);
-					HIPCHK(c, hipEventRecord(pl.sideJoin, sb));
-					prof_begin(c, K_EXTEND, st);
-					hipLaunchKernelGGL((k_extend<false, false>), dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill, c->counters);
-					prof_end(c, st);
-					HIPCHK(c, hipStreamWaitEvent(st, pl.sideJoin, 0));
-					lightDone = true;
-				} else {
-					prof_begin(c, K_EXTEND, st);
-					hipLaunchKernelGGL(k_traverse, dim3(c->gridTraverse), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), pl.spill);
-					prof_end(c, st);
-				}
-			} else {
-				// the shadow rays of the last round have no extend to share a launch with
-				hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 1, 0, 1);
-				prof_begin(c, K_CONNECT, st);
-				launch_connect(c, st, P, Q, 1 - parity, pl.spill);
-				prof_end(c, st);
-			}
-			if (round > 0 && !lightDone) {
-				prof_begin(c, K_SHADE, st);
-				hipLaunchKernelGGL(k_light, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, R, P, Q, 1 - parity);
-				prof_end(c, st);
-			}
-			if (round < rounds) {
-				prof_begin(c, K_SHADE, st);
-				hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, st, c->S, c->C, R, P, Q, parity, round == 0 ? 1 : 0);
-				prof_end(c, st);
-				hipLaunchKernelGGL(k_round_begin, dim3(1), dim3(1), 0, st, Q, 0, 0, 2);
-				hipLaunchKernelGGL(k_compact, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, P, (int)ST_SHADOW, Q.shadow, &Q.counts[2]);
-			}
-		}
-	}
-	int rc = RT_OK;
-	for (int k = 0; k < nPools; k++) HIPCHK(c, hipMemcpyAsync(c->hostCounts + 16 * k, c->pools[k].Q.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, c->pools[k].stream));
-	for (int k = 0; k < nPools; k++) {
-		HIPCHK(c, hipStreamSynchronize(c->pools[k].stream));
-		const int* hc = c->hostCounts + 16 * k;
-		if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
-		else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
-		else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
-		if (hc[3] != 0) (void)hipMemsetAsync(c->pools[k].Q.counts + 3, 0, sizeof(int), c->pools[k].stream);
-	}
-	// join: the context's stream continues after every pool
-	for (int k = 1; k < nPools; k++) {
-		(void)hipEventRecord(c->pools[k].done, c->pools[k].stream);
-		(void)hipStreamWaitEvent(c->stream, c->pools[k].done, 0);
 	}
 	if (rc != RT_OK) return rc;
 	HIPCHK(c, hipGetLastError());
@@ -1720,7 +1539,7 @@ static int ensure_stream_state(rt_ctx* c, int n)
 }
 static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int round, uint* spill)
 {
-	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27) | (c->decideShadow ? RT_TUNE_DECIDE_SHADOW : 0);
+	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27);
 	if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
 	else if (c->S.wide8) {
 		// the 8-wide quantised walk, then the binary walk over the rays it handed back (not clean: normally none)
@@ -1787,7 +1606,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		tail_probe_reset(st);
 #endif
 		prof_begin(c, K_EXTEND, st);
-		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin) | (c->decideShadow ? RT_TUNE_DECIDE_SHADOW : 0), c->spill);
+		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill);
 		else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
 		prof_end(c, st);
@@ -1843,41 +1662,14 @@ static bool stream_eligible(const rt_ctx* c, int mode, size_t samples)
 	return (c->useStream || c->Qt.on) && mode == RT_MODE_PATH && !c->pathUnsupported && c->counting != RT_COUNT_REFERENCE && samples <= (size_t)slot_budget(c);
 }
 
-// Which round loop a path batch with a slot per sample takes, whatever its size: 0 the plain one (run_rounds), 1 extend(r + 1)
-// and connect(r) as ONE launch (k_traverse), 2 as two kernels on two streams (the default).  Measured (r02_ab_fuse2.txt, r02_ab_fuse3.txt):
-// 2 beats 1 at every size (1/8 frame 9.22 -> 9.02 ms) and 0 up to the full frame (32 spp: 29.1 -> 28.5 ms, 64 spp:
-// 54.4 -> 53.3 ms); config 5's 132 M-sample batches are level (2.96 s either way).  With 2 the kernel times bench.py
-// reports per kind overlap (RT_FUSE=0 for unoverlapped ones).
-static int fuse_mode(const rt_ctx* c, size_t samples)
+// Size the slots of the slot wavefront for 'total' samples: one each while the budget lasts.
+static int setup_slots(rt_ctx* c, size_t total, bool pend, int& slots, bool& slotPerSample)
 {
-	if (c->counting) return 0;
-	int m = c->fuseTraversal < 0 || c->fuseTraversal > 2 ? 2 : c->fuseTraversal; // 3 (the gated second stream) exists in the dense pipeline only
-	// mode 1 indexes rays and shadow rays of a round in ONE int work list: slots * (lights + 1) must stay below 2^31
-	if (m == 1 && samples * (size_t)(c->S.nLights + 1) > (size_t)0x7FFFFFFF) m = 2;
-	return m;
-}
-
-// Split 'total' samples over the pools and size their slots.
-static int setup_pools(rt_ctx* c, size_t total, bool pend, const RenderParams& base, RenderParams* Rs, int& nPools, int& maxSlots, bool& slotPerSample)
-{
-	slotPerSample = true;
-	nPools = total >= ((size_t)1 << 20) ? c->nPoolsWanted : 1; // small batches: one pool
-	const size_t per = (total + nPools - 1) / nPools;
-	maxSlots = 0;
-	size_t first = 0;
-	for (int k = 0; k < nPools; k++) {
-		const size_t cnt = first + per <= total ? per : total - first;
-		const size_t budget = (size_t)slot_budget(c) / nPools;
-		const int slots = (int)(cnt < budget ? cnt : budget);
-		int rc = ensure_state(c, k, slots > 0 ? slots : 1, pend);
-		if (rc != RT_OK) return rc;
-		Rs[k] = base;
-		Rs[k].sampleFirst = (uint)first, Rs[k].nSamples = (uint)cnt;
-		if ((size_t)slots < cnt) slotPerSample = false;
-		if (slots > maxSlots) maxSlots = slots;
-		first += cnt;
-	}
-	return RT_OK;
+	const size_t budget = (size_t)slot_budget(c);
+	slots = (int)(total < budget ? total : budget);
+	if (slots < 1) slots = 1;
+	slotPerSample = (size_t)slots >= total;
+	return ensure_state(c, slots, pend);
 }
 
 static int slot_budget(const rt_ctx* c)
@@ -1964,16 +1756,15 @@ int rt_render_rows(rt_ctx* c, int mode, uint32_t frame0, int nframes, uint32_t s
 			hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 			continue;
 		}
-		RenderParams Rs[RT_MAX_POOLS];
-		int nPools = 1, slots = 1;
+		int slots = 1;
 		bool slotPerSample = false;
-		rc = setup_pools(c, total, mode == RT_MODE_WHITTED, R, Rs, nPools, slots, slotPerSample);
+		rc = setup_slots(c, total, mode == RT_MODE_WHITTED, slots, slotPerSample);
 		if (rc != RT_OK) return rc;
 		const int seg = segments_per_sample(mode, mode == RT_MODE_PATH ? 4 : max_depth, c->S.nLights);
-		const int maxRounds = (int)((total / nPools + slots) / slots) * seg + seg + 4;
+		const int maxRounds = (int)((total + slots) / slots) * seg + seg + 4;
 		const bool direct = mode == RT_MODE_PATH && slotPerSample;
-		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
-		rc = direct && fuse_mode(c, total) ? run_rounds_fused(c, Rs, nPools, seg, fuse_mode(c, total)) : run_rounds(c, Rs, nPools, maxRounds, direct ? seg : 0);
+		R.finishInline = direct ? 1 : 0;
+		rc = run_rounds(c, R, maxRounds, direct ? seg : 0);
 		if (rc != RT_OK) return rc;
 		hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((tilePixels + 255) / 256)), dim3(256), 0, c->stream, c->C, R, bf);
 	}
@@ -2031,14 +1822,13 @@ int rt_trace_batch_energy(rt_ctx* c, int mode, int n, const float* O, const floa
 		R.finishInline = 1;
 		if (rc == RT_OK) rc = run_rounds_stream(c, R, depth + 1);
 	} else {
-		RenderParams Rs[RT_MAX_POOLS];
-		int nPools = 1, slots = 1;
+		int slots = 1;
 		bool slotPerSample = false;
-		rc = setup_pools(c, (size_t)n, mode == RT_MODE_WHITTED, R, Rs, nPools, slots, slotPerSample);
+		rc = setup_slots(c, (size_t)n, mode == RT_MODE_WHITTED, slots, slotPerSample);
 		const int seg = segments_per_sample(mode, depth, c->S.nLights);
 		const bool direct = mode == RT_MODE_PATH && slotPerSample;
-		for (int k = 0; k < nPools; k++) Rs[k].finishInline = direct ? 1 : 0;
-		if (rc == RT_OK) rc = direct && fuse_mode(c, (size_t)n) ? run_rounds_fused(c, Rs, nPools, seg, fuse_mode(c, (size_t)n)) : run_rounds(c, Rs, nPools, ((n / nPools + slots) / slots) * seg + seg + 4, direct ? seg : 0);
+		R.finishInline = direct ? 1 : 0;
+		if (rc == RT_OK) rc = run_rounds(c, R, ((n + slots) / slots) * seg + seg + 4, direct ? seg : 0);
 	}
 	if (rc == RT_OK) {
 		std::vector<float> out4((size_t)4 * n);
@@ -2430,8 +2220,8 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d decide_shadow=%d fuse=%d pools=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
-	         c->useStream, c->decideRays, c->decideShadow, c->fuseTraversal, c->nPoolsWanted, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	         c->useStream, c->decideRays, c->fuseTraversal, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
 	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;

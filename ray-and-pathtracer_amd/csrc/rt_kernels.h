@@ -38,8 +38,8 @@ struct DCamera {
 struct PathState {
 	float4* O[2];    // ray origin xyz, w = ray.t on entry (tmax); double buffered by round parity
 	float4* D[2];    // ray direction xyz
-	float4* hitN[2]; // hit normal xyz, w = t; double buffered by round parity like the rays: light of round r still reads
-	int2* hitId[2];  // objIdx, material           its hit after k_traverse wrote the hits of round r + 1 (run_rounds_fused)
+	float4* hitN[2]; // hit normal xyz, w = t; double buffered by round parity like the rays
+	int2* hitId[2];  // objIdx, material
 	float4* W;       // path weight xyz, w = depth (int bits)
 	float4* E;       // energy xyz, w = RNG state (uint bits)
 	float4* L;       // radiance of the current sample xyz, w = sample id in the pool (uint bits)
@@ -682,37 +682,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
-// traverse: extend of round r + 1 and connect of round r in ONE persistent launch (path mode with a slot per sample:
-// both only need shade(r), and neither needs the other).  Work items [0, nActive) are the active queue's rays
-// (nearest hit, the long ones: they start first), [nActive, nActive + nShadow * nLights) the shadow rays.
-struct TraversePolicy {
-	ExtendPolicy<false> ext;
-	ConnectPolicy con;
-	int nActive;
-	__device__ __forceinline__ bool any_of(int work) const { return work >= nActive; }
-	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
-	{
-		if (work < nActive) return ext.load(work, O, D, tmax, head);
-		return con.load(work - nActive, O, D, tmax, head);
-	}
-	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& O, const f3& D) const { ext.store(work, hit, O, D); }
-	__device__ __forceinline__ void store(int work, bool occluded) const { con.store(work - nActive, occluded); }
-};
 #ifndef RT_TRAVERSE_WAVES
-#define RT_TRAVERSE_WAVES 7
+#define RT_TRAVERSE_WAVES 7 // k_traverse_s (rt_stream.h)
 #endif
-__global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse(DScene S, PathState P, Queues Q, int parityExtend, float t_min, int refillMin, uint* spill)
-{
-	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
-	LaneCounters lc;
-	lc.clear();
-	uint rays = 0;
-	const int nActive = Q.counts[0];
-	RT_CHECK((long long)nActive + (long long)Q.counts[2] * S.nLights <= 0x7FFFFFFFll, 15, &Q.counts[3]); // fuse_mode() keeps such batches out of this launch
-	TraversePolicy pol{ { S, P, Q.active, parityExtend, &Q.counts[3] }, { P, Q.shadow, 1 - parityExtend, S.nLights, &Q.counts[3], Q.leftover, &Q.counts[8] }, nActive };
-	trace_persistent<false, false, false, TraversePolicy, true>(S, pol, nActive + Q.counts[2] * S.nLights, Q.heads, t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
-}
-
 // light: the direct-light terms of a diffuse hit, in light order.
 // Whitted (renderer.cpp:89-105): scatter first (energy changes even when occluded), then the
 // occlusion test.  Path (renderer.cpp:158-176): occlusion test first, scatter only when visible.

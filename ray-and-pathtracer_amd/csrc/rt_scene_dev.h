@@ -299,7 +299,6 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // reservation by what is left there (256 entries early on, 64 near the end), and moves on to the other
 // sub-queues when its own is empty.
 #define RT_TUNE_CULL_COUNTED 0x10000 // 'tuning' bit: a counting launch drops unreachable TLAS children like a timed one
-#define RT_TUNE_DECIDE_SHADOW 0x20000 // 'tuning' bit: the dense pipeline's connect policy answers shadow rays that need no walk when it loads them
 #define RT_HEADS 16
 #ifndef RT_SHORT_QUEUE_RAYS
 #define RT_SHORT_QUEUE_RAYS 32 // queue entries per wave below which further waves of the grid do not take part

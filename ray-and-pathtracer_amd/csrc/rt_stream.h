@@ -567,7 +567,6 @@ struct StreamConnectPolicy {
 	const StreamState& T;
 	int nShadow;
 	int* flag;
-	const DScene* decideIn; // non-null: load() answers the shadow rays whose first traversal step leaves nothing to visit (ray_decided)
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef&) const
 	{
 		const int li = work / nShadow, s = work - li * nShadow;
@@ -578,13 +577,6 @@ struct StreamConnectPolicy {
 		const float len2 = dot(lightRayDirection, lightRayDirection);
 		lightRayDirection = normalize(lightRayDirection);
 		O = I + lightRayDirection * 1e-4f, D = lightRayDirection, tmax = sqrtf(len2);
-		// Scene::IsOccluded walks the BVH / TLAS only (no head tests): a ray that the root pair's boxes (and, in TLAS mode, the
-		// reach boxes) leave nothing to visit is visible.  Answered here, where all the lanes that just took a work item run the
-		// same test together, instead of as a pair step of its own followed by a flush.  Measured: slower (RT_DECIDE_SHADOW, off).
-		if (decideIn && ray_decided(*decideIn, O, D, tmax)) {
-			st_stream(T.vis + ((size_t)li * (size_t)T.cap + (size_t)s), (unsigned char)0);
-			return false;
-		}
 		return true;
 	}
 	__device__ __forceinline__ void store(int work, bool occluded) const
@@ -602,7 +594,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene
 	lc.clear();
 	uint rays = 0;
 	const int nShadow = T.counts[SC_SHADOW + round % 3];
-	StreamConnectPolicy pol{ T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG], !COUNT && (refillMin & RT_TUNE_DECIDE_SHADOW) ? &S : nullptr };
+	StreamConnectPolicy pol{ T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] };
 	int* heads = T.heads + RT_HEADS * RT_HEAD_STRIDE;
 	if constexpr (LISTED) {
 		ListedPolicy<StreamConnectPolicy> lp{ pol, T.leftover };
@@ -638,7 +630,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DSce
 	lc.clear();
 	uint rays = 0;
 	const int nTrace = T.counts[SC_TRACE], nShadow = T.counts[SC_SHADOW + (round + 2) % 3]; // the shadow records of round - 1
-	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG] }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG], (refillMin & RT_TUNE_DECIDE_SHADOW) ? &S : nullptr }, nTrace };
+	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG] }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] }, nTrace };
 	trace_persistent<false, false, false, StreamTraversePolicy, true>(S, pol, nTrace + nShadow * S.nLights, T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 }
 

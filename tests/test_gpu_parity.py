@@ -1009,32 +1009,6 @@ def test_fewer_slots_than_samples(slots, name, kw, scenes, oracle_api, host_api,
     assert np.array_equal(r.accumulator().view(np.uint32), few.view(np.uint32))
 
 
-@pytest.mark.parametrize("name,kw,w,h,frames", [("pretty_tlas", {"n_instances": 4}, 160, 90, 7), ("mixed_small", {}, 96, 64, 5), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72, 3)])
-def test_fused_traversal_launch_equals_separate_launches(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
-    """The slot pipeline (RT_STREAM=0, csrc/rt_kernels.h): path batches with a slot per sample overlap extend(r + 1) with
-    connect(r) + light(r) (csrc/rt_api.hip run_rounds_fused) at every batch size: as two kernels on two streams
-    (RT_FUSE=2, the default), optionally as ONE launch over one work list (RT_FUSE=1, k_traverse); counting launches keep
-    the plain round loop (RT_FUSE=0).  All three must produce the same accumulator bits, and the oracle's frame."""
-    monkeypatch.setenv("RT_STREAM", "0")
-    out = {}
-    for fuse in ("0", "1", "2"):
-        monkeypatch.setenv("RT_FUSE", fuse)
-        o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
-        r.clear()
-        r.render(host_api.RT_MODE_PATH, 0, frames)
-        out[fuse] = r.accumulator().copy()
-        if fuse != "0":
-            check_frames(orr, r, "path", frames, host_api)
-            # rows shards through the fused path too
-            r.clear()
-            r.render_rows(host_api.RT_MODE_PATH, 0, frames, 0, 2, (h + 1) // 2)
-            r.render_rows(host_api.RT_MODE_PATH, 0, frames, 1, 2, h // 2)
-            assert np.array_equal(r.accumulator().view(np.uint32), out[fuse].view(np.uint32))
-        r.close()
-    assert np.array_equal(out["0"].view(np.uint32), out["1"].view(np.uint32))
-    assert np.array_equal(out["0"].view(np.uint32), out["2"].view(np.uint32))
-
-
 @pytest.mark.parametrize("name,kw,w,h,frames", [("pretty_tlas", {"n_instances": 4}, 160, 90, 7), ("mixed_small", {}, 96, 64, 5), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72, 3),
                                                ("tower", {}, 120, 68, 3), ("scene3", {}, 100, 60, 4), ("background", {}, 90, 60, 3)])
 def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
@@ -1045,10 +1019,9 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
     caller-supplied rays at every depth, and the same number of FindNearest / IsOccluded queries."""
     out, rays = {}, {}
     pO = pD = None
-    for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_gated", {"RT_FUSE": "3"}), ("stream_one_launch_per_round", {"RT_FUSE": "1"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
-                     ("stream_decide_shadow", {"RT_DECIDE_SHADOW": "1", "RT_FUSE": "0"}), ("stream_decide_shadow_one_launch_per_round", {"RT_DECIDE_SHADOW": "1", "RT_FUSE": "1"}),
+    for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_gated", {"RT_FUSE": "3"}), ("stream_two_streams", {"RT_FUSE": "2"}), ("stream_one_launch_per_round", {"RT_FUSE": "1"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
                      ("stream_gamma_at_the_store", {"RT_DEFER_GAMMA": "0"})):
-        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_DECIDE_SHADOW", "RT_DEFER_GAMMA"):
+        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_DEFER_GAMMA"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1076,8 +1049,7 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
                 pO, pD = pO[::7].copy(), pD[::7].copy()
             out[key + "_sample"] = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 99) for depth in (0, 1, 4)]
         r.close()
-    for key in ("stream", "stream_serial", "stream_gated", "stream_one_launch_per_round", "stream_nodecide",
-                "stream_decide_shadow", "stream_decide_shadow_one_launch_per_round", "stream_gamma_at_the_store"):
+    for key in ("stream", "stream_serial", "stream_gated", "stream_two_streams", "stream_one_launch_per_round", "stream_nodecide", "stream_gamma_at_the_store"):
         assert np.array_equal(out["slot"].view(np.uint32), out[key].view(np.uint32)), key
         assert rays[key] == rays["slot"], (key, rays[key], rays["slot"])
     for other in ("stream_sample",):
@@ -1283,25 +1255,6 @@ def test_qlearning_sampler(name, kw, w, h, box, mask, scenes, oracle_api, host_a
     r.clear(); r.render(host_api.RT_MODE_PATH, 0, 24)
     assert np.array_equal((r.accumulator()[..., :3] / 24).view(np.uint32), plain.view(np.uint32))  # off again: the plain sampler's frame
     r.close()
-
-
-def test_sample_pools_on_separate_streams(scenes, oracle_api, host_api, monkeypatch):
-    """RT_POOLS > 1 splits a batch of >= 1M samples over independent pools that run on their own streams
-    (csrc/rt_api.hip run_rounds); the frame must be the one a single pool renders, bit for bit.  A new
-    context per setting: the pool count is read at rt_create."""
-    frames = []
-    for pools in ("1", "3"):
-        monkeypatch.setenv("RT_POOLS", pools)
-        r = host_api.HostRenderer(320, 200)
-        d = scenes.REGISTRY["pretty_tlas"](r.scene, n_instances=4)
-        r.commit()
-        c = d["camera"]
-        r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
-        r.render(host_api.RT_MODE_PATH, 0, 17)  # 1,088,000 samples
-        frames.append(r.accumulator().copy())
-        r.close()
-    assert np.isfinite(frames[0][..., :3]).mean() > 0.5
-    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
 
 
 # ---- rt_build_bvh: bvh::Build (binned SAH) on the device, SURVEY.md section 8f N1 ----------------------
