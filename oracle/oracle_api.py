@@ -283,6 +283,12 @@ class OracleRenderer:
         sums, cnts = np.ascontiguousarray(sums, np.int64), np.ascontiguousarray(cnts, np.uint32)
         self.L.orc_qlearn_set(self.h, _p(sums), _p(cnts))
 
+    def qlearn_set_table(self, table):
+        """load a [grid^3, 64] table (e.g. the one the device learned: rt_qlearn_get_table); band sums and V rows follow"""
+        table = np.ascontiguousarray(table, np.float32)
+        assert table.shape == (self._qgrid ** 3, 64)
+        self.L.orc_qlearn_set_table(self.h, _p(table))
+
     def qlearn_state(self):
         """(sums int64, counts uint32, table float32), each [grid^3, 64]"""
         n = self._qgrid ** 3

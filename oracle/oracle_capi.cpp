@@ -358,6 +358,7 @@ void orc_qlearn_get(void* h, long long* sums, unsigned* counts, float* table)
 	if (counts) memcpy(counts, q.cnt.data(), cells * 64 * 4);
 	if (table) for (size_t c = 0; c < cells; c++) memcpy(table + c * 64, &q.q[c * 72 + 8], 64 * 4);
 }
+void orc_qlearn_set_table(void* h, const float* table) { ((OrcRenderer*)h)->r.ql.set_table(table); }
 void orc_qlearn_set(void* h, const long long* sums, const unsigned* counts)
 {
 	QLearn& q = ((OrcRenderer*)h)->r.ql;

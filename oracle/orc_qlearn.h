@@ -5,7 +5,9 @@
 // direction according to the QValue of neighboring points; store and update directions with a corresponding probability per
 // sampling point").  Same definitions, same operand order: cells of a grid^3 box, 64 equal-area direction patches per cell
 // (8 bands in z x 8 sectors in phi), P(patch) = (1 - eps) Q / sum Q + eps / 64, rewards summed as 48.16 fixed-point
-// integers per (cell, patch) and folded into Q <- (1 - alpha) Q + alpha mean between batches.
+// integers per (cell, patch) and folded into Q <- (1 - alpha) Q + alpha mean between batches.  The reward a diffuse surface
+// hands back is rho / 16 * V[cell][patch(normal)], V[cell][m] = sum_p Q[cell][p] max(0, d_m . d_p) over the patch centres
+// (the normal quantised to the patch it points into; V follows every change of Q).
 #pragma once
 #include "orc_math.h"
 #include <cmath>
@@ -21,6 +23,8 @@ struct QLearn {
 	float eps = 0, alpha = 0, qMin = 1e-4f;
 	uint learnMask = 0;          // a sample pays rewards iff (its stream's state after the pixel jitter) & learnMask == 0
 	std::vector<float> q;        // [cells][72]: 8 band sums, then 64 values
+	std::vector<float> v;        // [cells][64]: V[cell][m] = sum_p Q[cell][p] * wgt[m][p]
+	float wgt[64 * 64];          // max(0, d_m . d_p) of the patch centres
 	std::vector<long long> sum;  // [cells][64]
 	std::vector<uint> cnt;       // [cells][64]
 	float3 centre[64];
@@ -33,6 +37,19 @@ struct QLearn {
 		const float s = sqrtf(t_fmaxf(0.f, 1 - z * z));
 		return float3(s * x_cosf(phi), s * x_sinf(phi), z);
 	}
+	// the patch a unit vector points into: band from z, sector from the signs and the larger of |x|, |y|
+	static int patch_of(const float3& n)
+	{
+		const float fz = (n.z + 1) * 4;
+		const int i = fz > 0 ? (fz < 8 ? (int)fz : 7) : 0;
+		const float ax = fabsf(n.x), ay = fabsf(n.y);
+		int j;
+		if (n.y >= 0) j = n.x > 0 ? (ay < ax ? 0 : 1) : (ax < ay ? 2 : 3);
+		else j = n.x < 0 ? (ay < ax ? 4 : 5) : (ax < ay ? 6 : 7);
+		if (n.x == 0 && n.y == 0) j = 0;
+		return 8 * i + j;
+	}
+	// band sums and V row of a cell from its 64 values
 	void rebuild_bands(size_t cell)
 	{
 		float* row = &q[cell * 72];
@@ -41,14 +58,30 @@ struct QLearn {
 			for (int j = 0; j < 8; j++) b = b + row[8 + 8 * i + j];
 			row[i] = b;
 		}
+		for (int m = 0; m < 64; m++) {
+			float s = 0;
+			for (int p = 0; p < 64; p++) s = s + row[8 + p] * wgt[m * 64 + p];
+			v[cell * 64 + m] = s;
+		}
+	}
+	// load a table (e.g. one the device learned): cells * 64 values
+	void set_table(const float* table)
+	{
+		const size_t cells = (size_t)grid * grid * grid;
+		for (size_t c = 0; c < cells; c++) {
+			for (int p = 0; p < 64; p++) q[c * 72 + 8 + p] = table[c * 64 + p];
+			rebuild_bands(c);
+		}
 	}
 	void enable(int g, const float* l, const float* h, float a, float e, float qInit, uint mask = 0)
 	{
 		on = true, grid = g, alpha = a, eps = e, learnMask = mask;
 		for (int k = 0; k < 3; k++) lo[k] = l[k], inv[k] = (float)g / (h[k] - l[k]);
 		const size_t cells = (size_t)g * g * g;
-		q.assign(cells * 72, 0.0f), sum.assign(cells * 64, 0), cnt.assign(cells * 64, 0);
+		q.assign(cells * 72, 0.0f), v.assign(cells * 64, 0.0f), sum.assign(cells * 64, 0), cnt.assign(cells * 64, 0);
 		for (int p = 0; p < 64; p++) centre[p] = direction(p >> 3, p & 7, 0.5f, 0.5f);
+		for (int m = 0; m < 64; m++)
+			for (int p = 0; p < 64; p++) wgt[m * 64 + p] = t_fmaxf(0.f, dot(direction(m >> 3, m & 7, 0.5f, 0.5f), direction(p >> 3, p & 7, 0.5f, 0.5f)));
 		for (size_t c = 0; c < cells; c++) {
 			for (int p = 0; p < 64; p++) q[c * 72 + 8 + p] = qInit;
 			rebuild_bands(c);
@@ -79,12 +112,7 @@ struct QLearn {
 			for (int i = 0; i < 8; i++) T = T + row[i];
 			return rho * (T * (1.0f / 64));
 		}
-		float s = 0;
-		for (int p = 0; p < 64; p++) {
-			const float cs = dot(centre[p], normal);
-			s = s + row[8 + p] * t_fmaxf(0.f, cs);
-		}
-		return rho * (s * (1.0f / 16));
+		return rho * (v[(size_t)c * 64 + patch_of(normal)] * (1.0f / 16));
 	}
 	float3 sample(int c, uint& seed, float& P, int& patch) const
 	{

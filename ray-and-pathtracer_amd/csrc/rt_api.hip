@@ -2150,15 +2150,18 @@ int rt_qlearn_enable(rt_ctx* c, const rt_qlearn_params* p)
 	memset(&Q, 0, sizeof(Q));
 	const size_t cells = (size_t)p->grid * p->grid * p->grid;
 	float4* centre = nullptr;
+	float* wgt = nullptr;
 	HIPCHK(c, dalloc(c->qAllocs, &Q.q, cells * RT_Q_ROW));
+	HIPCHK(c, dalloc(c->qAllocs, &Q.v, cells * RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &Q.sum, cells * RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &Q.cnt, cells * RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &centre, (size_t)RT_Q_PATCHES));
-	Q.centre = centre, Q.grid = p->grid, Q.on = 1;
+	HIPCHK(c, dalloc(c->qAllocs, &wgt, (size_t)RT_Q_PATCHES * RT_Q_PATCHES));
+	Q.centre = centre, Q.wgt = wgt, Q.grid = p->grid, Q.on = 1;
 	for (int a = 0; a < 3; a++) Q.lo[a] = p->lo[a], Q.inv[a] = (float)p->grid / (p->hi[a] - p->lo[a]);
 	Q.eps = p->epsilon, Q.alpha = p->alpha, Q.qMin = 1e-4f, Q.learnMask = p->learn_mask;
-	const int threads = (int)std::max(cells, (size_t)RT_Q_PATCHES);
-	hipLaunchKernelGGL(k_q_init, dim3((threads + 255) / 256), dim3(256), 0, c->stream, Q, p->q_init, centre);
+	hipLaunchKernelGGL(k_q_weights, dim3(RT_Q_PATCHES), dim3(RT_Q_PATCHES), 0, c->stream, centre, wgt);
+	hipLaunchKernelGGL(k_q_init, dim3(((int)cells + 63) / 64), dim3(64), 0, c->stream, Q, p->q_init);
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	c->Qt = Q;
 	return RT_OK;
@@ -2168,7 +2171,7 @@ int rt_qlearn_apply(rt_ctx* c)
 	if (!c || !c->Qt.on) return fail(c, RT_E_STATE, "rt_qlearn_apply: the sampler is off");
 	HIPCHK(c, hipSetDevice(c->device));
 	const int cells = c->Qt.grid * c->Qt.grid * c->Qt.grid;
-	hipLaunchKernelGGL(k_q_apply, dim3((cells + 255) / 256), dim3(256), 0, c->stream, c->Qt);
+	hipLaunchKernelGGL(k_q_apply, dim3((cells + 63) / 64), dim3(64), 0, c->stream, c->Qt); // a 64 x 64 product per cell: one wave per block spreads the cells over the CUs
 	HIPCHK(c, hipGetLastError());
 	return RT_OK;
 }

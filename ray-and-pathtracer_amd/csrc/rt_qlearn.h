@@ -13,10 +13,14 @@
 //                        estimator's factor 2 = 1 / (pi pdf) of the uniform hemisphere becomes 1 / (16 P); a direction
 //                        below the surface contributes nothing and teaches the patch a reward of 0
 //   update (eq. 8)       when the scattered ray's hit y is shaded: reward = what y emits towards x (sky, light) or, for a
-//                        surface, the expected reflected Q at y: rho / 16 * sum_p Q[cell(y)][p] max(0, n_y . d_p) (diffuse),
-//                        luminance(col) * mean Q[cell(y)] (specular).  Rewards are summed as 48.16 fixed-point INTEGERS with a
-//                        count per (cell, patch); rt_qlearn_apply folds them into Q <- (1 - alpha) Q + alpha mean between
-//                        batches.  Within a batch Q is read-only.
+//                        surface, the expected reflected Q at y: rho / 16 * V[cell(y)][patch(n_y)] (diffuse) with
+//                        V[cell][m] = sum_p Q[cell][p] max(0, d_m . d_p) over the 64 patch centres -- the integral of eq. 8 with the
+//                        normal quantised to the patch it points into; luminance(col) * mean Q[cell(y)] (specular).  V is
+//                        recomputed whenever Q changes (k_q_init, k_q_apply: a 64 x 64 product per cell, microseconds), so a hit
+//                        reads ONE value where round 3 read the cell's 64 and took 64 dot products (config 5: shade 1.16 s of
+//                        2.20 s).  Rewards are summed as 48.16 fixed-point INTEGERS with a count per (cell, patch);
+//                        rt_qlearn_apply folds them into Q <- (1 - alpha) Q + alpha mean between batches.  Within a batch Q
+//                        and V are read-only.
 // Why integers: sums of integers do not depend on the order in which lanes, waves or GPUs add them, so a frame is
 // reproducible, equals the CPU statement's, and -- with the sums all-reduced between ranks before the apply (bench.py) -- does
 // not depend on how the rows were sharded.  The rule this picks for "per-pixel streams must stay independent of sharding":
@@ -30,6 +34,8 @@ namespace rtd {
 #define RT_Q_ROW 72 // floats per cell: 8 band sums, then 64 values (band-major)
 struct QTable {
 	float* q;            // [cells][RT_Q_ROW]
+	float* v;            // [cells][64] V[cell][m] = sum_p Q[cell][p] * wgt[m][p]: the expected reflected Q for a normal in patch m
+	const float* wgt;    // [64][64] max(0, d_m . d_p) of the patch centres
 	long long* sum;      // [cells][64] rewards of the current batch, 48.16 fixed point
 	uint* cnt;           // [cells][64]
 	const float4* centre; // [64] patch centre directions
@@ -59,19 +65,50 @@ __device__ __forceinline__ f3 q_direction(int i, int j, float u1, float u2)
 	const float s = sqrtf(t_fmaxf(0.f, 1 - z * z));
 	return f3(s * x_cosf(phi), s * x_sinf(phi), z);
 }
-__global__ void k_q_init(QTable Q, float qInit, float4* centre)
+// the patch a unit vector points into: band from z, sector from the signs and the larger of |x|, |y| (the sector boundaries are
+// the multiples of 45 degrees: no arc tangent needed)
+__device__ __forceinline__ int q_patch_of(const f3& n)
 {
-	const int cells = Q.grid * Q.grid * Q.grid;
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t < RT_Q_PATCHES) centre[t] = mk4(q_direction(t >> 3, t & 7, 0.5f, 0.5f), 0.0f);
-	if (t >= cells) return;
+	const float fz = (n.z + 1) * 4;
+	const int i = fz > 0 ? (fz < 8 ? (int)fz : 7) : 0; // NaN -> 0
+	const float ax = fabsf(n.x), ay = fabsf(n.y);
+	int j;
+	if (n.y >= 0) j = n.x > 0 ? (ay < ax ? 0 : 1) : (ax < ay ? 2 : 3);
+	else j = n.x < 0 ? (ay < ax ? 4 : 5) : (ax < ay ? 6 : 7);
+	if (n.x == 0 && n.y == 0) j = 0;
+	return 8 * i + j;
+}
+// the band sums and the V row of cell t from its 64 values, in patch order
+__device__ __forceinline__ void q_derive(const QTable& Q, int t)
+{
 	float* row = Q.q + (size_t)t * RT_Q_ROW;
-	for (int p = 0; p < RT_Q_PATCHES; p++) row[8 + p] = qInit, Q.sum[(size_t)t * RT_Q_PATCHES + p] = 0, Q.cnt[(size_t)t * RT_Q_PATCHES + p] = 0;
 	for (int i = 0; i < 8; i++) {
 		float b = 0;
 		for (int j = 0; j < 8; j++) b = b + row[8 + 8 * i + j];
 		row[i] = b;
 	}
+	for (int m = 0; m < RT_Q_PATCHES; m++) {
+		float s = 0;
+		for (int p = 0; p < RT_Q_PATCHES; p++) s = s + row[8 + p] * Q.wgt[m * RT_Q_PATCHES + p];
+		Q.v[(size_t)t * RT_Q_PATCHES + m] = s;
+	}
+}
+// patch centres and their pairwise weights max(0, d_m . d_p) (before k_q_init: one launch of 64 x 64 threads)
+__global__ void k_q_weights(float4* centre, float* wgt)
+{
+	const int m = blockIdx.x, p = threadIdx.x;
+	const f3 dm = q_direction(m >> 3, m & 7, 0.5f, 0.5f), dp = q_direction(p >> 3, p & 7, 0.5f, 0.5f);
+	if (m == 0) centre[p] = mk4(dp, 0.0f);
+	wgt[m * RT_Q_PATCHES + p] = t_fmaxf(0.f, dot(dm, dp));
+}
+__global__ void k_q_init(QTable Q, float qInit)
+{
+	const int cells = Q.grid * Q.grid * Q.grid;
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= cells) return;
+	float* row = Q.q + (size_t)t * RT_Q_ROW;
+	for (int p = 0; p < RT_Q_PATCHES; p++) row[8 + p] = qInit, Q.sum[(size_t)t * RT_Q_PATCHES + p] = 0, Q.cnt[(size_t)t * RT_Q_PATCHES + p] = 0;
+	q_derive(Q, t);
 }
 // fold the batch's rewards into the table: one thread per cell
 __global__ void k_q_apply(QTable Q)
@@ -89,11 +126,7 @@ __global__ void k_q_apply(QTable Q)
 			Q.sum[k] = 0, Q.cnt[k] = 0;
 		}
 	}
-	for (int i = 0; i < 8; i++) {
-		float b = 0;
-		for (int j = 0; j < 8; j++) b = b + row[8 + 8 * i + j];
-		row[i] = b;
-	}
+	q_derive(Q, t);
 }
 
 // the reward a scattered ray brings back to (cell, patch) = key - 1
@@ -103,27 +136,18 @@ __device__ __forceinline__ void q_reward(const QTable& Q, uint key, float R)
 	atomicAdd((unsigned long long*)&Q.sum[key - 1], (unsigned long long)__float2ll_rn(R * 65536.0f));
 	atomicAdd(&Q.cnt[key - 1], 1u);
 }
-// expected reflected Q at a surface hit (the integral of eq. 8 over the 64 patches).  A cell's row is 288 bytes, 16-byte aligned:
-// the values are fetched four at a time (16 loads instead of 64) and added in patch order all the same.
+// expected reflected Q at a surface hit (the integral of eq. 8 over the 64 patches): one value of the cell's V row for a diffuse
+// surface, the mean of the cell's Q for a specular one
 __device__ __forceinline__ float q_expected(const QTable& Q, int cell, const f3& normal, float rho, bool diffuse)
 {
-	const float4* row4 = (const float4*)(Q.q + (size_t)cell * RT_Q_ROW);
 	if (!diffuse) {
+		const float4* row4 = (const float4*)(Q.q + (size_t)cell * RT_Q_ROW);
 		const float4 b0 = row4[0], b1 = row4[1];
 		float T = 0;
 		T = T + b0.x, T = T + b0.y, T = T + b0.z, T = T + b0.w, T = T + b1.x, T = T + b1.y, T = T + b1.z, T = T + b1.w;
 		return rho * (T * (1.0f / 64));
 	}
-	float s = 0;
-#pragma unroll 4
-	for (int k = 0; k < RT_Q_PATCHES / 4; k++) {
-		const float4 v = row4[2 + k];
-		s = s + v.x * t_fmaxf(0.f, dot(xyz(Q.centre[4 * k]), normal));
-		s = s + v.y * t_fmaxf(0.f, dot(xyz(Q.centre[4 * k + 1]), normal));
-		s = s + v.z * t_fmaxf(0.f, dot(xyz(Q.centre[4 * k + 2]), normal));
-		s = s + v.w * t_fmaxf(0.f, dot(xyz(Q.centre[4 * k + 3]), normal));
-	}
-	return rho * (s * (1.0f / 16));
+	return rho * (Q.v[(size_t)cell * RT_Q_PATCHES + q_patch_of(normal)] * (1.0f / 16));
 }
 // the guided pick at a diffuse hit: four draws (mixture, patch, two inside the patch)
 __device__ __forceinline__ f3 q_sample(const QTable& Q, int cell, uint& seed, float& P, int& patch)
