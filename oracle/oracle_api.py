@@ -289,6 +289,15 @@ class OracleRenderer:
         assert table.shape == (self._qgrid ** 3, 64)
         self.L.orc_qlearn_set_table(self.h, _p(table))
 
+    def qlearn_v(self):
+        """(V rows [grid^3, 64], patch centres [64, 3])"""
+        v, c = np.zeros((self._qgrid ** 3, 64), np.float32), np.zeros((64, 3), np.float32)
+        self.L.orc_qlearn_get_v(self.h, _p(v), _p(c))
+        return v, c
+
+    def qlearn_patch_of(self, n):
+        return int(self.L.orc_qlearn_patch_of(_f3(n)))
+
     def qlearn_state(self):
         """(sums int64, counts uint32, table float32), each [grid^3, 64]"""
         n = self._qgrid ** 3

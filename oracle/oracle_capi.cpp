@@ -359,6 +359,13 @@ void orc_qlearn_get(void* h, long long* sums, unsigned* counts, float* table)
 	if (table) for (size_t c = 0; c < cells; c++) memcpy(table + c * 64, &q.q[c * 72 + 8], 64 * 4);
 }
 void orc_qlearn_set_table(void* h, const float* table) { ((OrcRenderer*)h)->r.ql.set_table(table); }
+int orc_qlearn_patch_of(const float* n) { return QLearn::patch_of(float3(n[0], n[1], n[2])); }
+void orc_qlearn_get_v(void* h, float* v, float* centres)
+{
+	const QLearn& q = ((OrcRenderer*)h)->r.ql;
+	memcpy(v, q.v.data(), q.v.size() * 4);
+	for (int p = 0; p < 64; p++) centres[3 * p] = q.centre[p].x, centres[3 * p + 1] = q.centre[p].y, centres[3 * p + 2] = q.centre[p].z;
+}
 void orc_qlearn_set(void* h, const long long* sums, const unsigned* counts)
 {
 	QLearn& q = ((OrcRenderer*)h)->r.ql;

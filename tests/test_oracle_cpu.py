@@ -171,6 +171,24 @@ def test_qlearning_sampler_cpu(scenes, oracle_api):
         tab = r.qlearn_state()[2]
         runs[threads] = (r.accumulator().copy(), tab.copy())
         assert tab.min() > 0 and tab.min() < 0.9 < 1.1 < tab.max()
+        if threads == 1:
+            # the V rows a diffuse hit's reward reads: V[cell][m] = sum_p Q[cell][p] max(0, d_m . d_p) over the patch centres, following
+            # every update of Q and a loaded table; a patch centre lies in its own patch, as do directions next to the sector boundaries
+            v, cen = r.qlearn_v()
+            wgt = np.maximum(0.0, cen.astype(np.float64) @ cen.astype(np.float64).T)
+            assert np.allclose(v, tab.astype(np.float64) @ wgt.T, rtol=1e-5, atol=1e-6)
+            assert [r.qlearn_patch_of(c) for c in cen] == list(range(64))
+            for j in range(8):
+                for dphi in (0.01, 0.77):
+                    phi = (j + 0) * np.pi / 4 + dphi
+                    assert r.qlearn_patch_of((0.6 * np.cos(phi), 0.6 * np.sin(phi), -0.8)) == 8 * 0 + j
+                    assert r.qlearn_patch_of((0.6 * np.cos(phi), 0.6 * np.sin(phi), 0.8)) == 8 * 7 + j
+            assert r.qlearn_patch_of((0, 0, 1)) == 56 and r.qlearn_patch_of((0, 0, -1)) == 0 and r.qlearn_patch_of((float("nan"),) * 3) in range(64)
+            r.qlearn_set_table(np.full_like(tab, 2.0))
+            v2, _ = r.qlearn_v()
+            assert np.allclose(v2, 2.0 * wgt.sum(1)[None, :], rtol=1e-5)
+            r.qlearn_set_table(tab)
+            assert np.array_equal(r.qlearn_v()[0].view(np.uint32), v.view(np.uint32))
         r.close(); s.close()
     assert np.array_equal(runs[1][1].view(np.uint32), runs[4][1].view(np.uint32))
     assert np.array_equal(runs[1][0].view(np.uint32), runs[4][0].view(np.uint32))
