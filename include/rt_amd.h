@@ -270,10 +270,6 @@ int rt_get_counters_split(rt_ctx* ctx, rt_counters* nearest, rt_counters* occlud
 int rt_set_profiling(rt_ctx* ctx, int profiling);
 int rt_get_profile(rt_ctx* ctx, rt_profile* out, int reset);
 int rt_synchronize(rt_ctx* ctx);
-/* The dense path pipeline holds connect(r) + light(r) on a second stream at a gate that extend(r + 1) opens when its queue runs
- * dry (batches below 100 M samples).  waits: gate launches that found the gate closed and waited for it; timeouts: gate launches
- * that gave up after 50 ms (the streams did not overlap) -- after the first one the context stops gating. */
-int rt_get_gate_stats(rt_ctx* ctx, uint64_t* waits_out, uint64_t* timeouts_out);
 /* What the library was built with (the -D flags given to the build and the compile-time tuning macros), and the tuning a
  * context resolved from its environment at rt_create (RT_* variables): measurement files are stamped with both, so that
  * counters taken on one build / tuning are not priced against timings of another.  Static / context-owned strings. */

@@ -66,8 +66,6 @@ struct rt_ctx {
 	hipStream_t streamSide = nullptr;
 	uint* streamSideSpill = nullptr;
 	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
-	bool gateBroken = false; // a k_gate launch timed out: this context's two streams do not overlap, no more gating
-	unsigned long long gateWaits = 0, gateTimeouts = 0; // rt_get_gate_stats
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
@@ -107,6 +105,8 @@ struct rt_ctx {
 	int refillAny = 24; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
 	int pairAgain = 16; // lanes that must still want a pair step for an iteration to repeat it (RT_PAIRAGAIN); tuning bits 20-26
 	int stepMinAny = 8, pairAgainAny = 16; // the any-hit kernel's RT_STEPMIN / RT_PAIRAGAIN (RT_STEPMIN_ANY, RT_PAIRAGAIN_ANY)
+	int drainLanes = 4, drainLanesAny = 4; // RT_DRAIN_LANES / RT_DRAIN_LANES_ANY: once a wave's queue is dry, this many live lanes (1, 2, 4 .. 64; 0: never) leave the
+	                                       // scheduled state machine for the plain per-lane walk (trace_persistent "the drain")
 	int stepMinXform = 0; // RT_STEPMIN_XFORM: lanes that must want an instance entry / exit before it runs (0: the same as RT_STEPMIN)
 	float* gammaLut = nullptr; // DScene::gammaLut
 	int* flags = nullptr; // [0] overflow for batch queries
@@ -148,7 +148,7 @@ static void free_pool(std::vector<void*>& pool)
 	pool.clear();
 }
 
-static int tuning(const rt_ctx* c, int base) { return base | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgain << 20) | (c->stepMinXform << 27); }
+static int tuning(const rt_ctx* c, int base) { return base | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgain << 20) | (c->stepMinXform << 27) | RT_TUNE_DRAIN(c->drainLanes); }
 
 // ---- profiling helpers ---------------------------------------------------------------------
 enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_CONNECT, K_QUERY };
@@ -288,7 +288,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	c->device = device, c->width = width, c->height = height;
 	memset(&c->S, 0, sizeof(c->S));
 	memset(&c->slot.P, 0, sizeof(PathState)), memset(&c->slot.Q, 0, sizeof(Queues));
-	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 3 ? 2 : f); } // 0..3 (dense pipeline: 1 = one traversal launch per round); anything else: the default
+	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0 one kernel at a time, 1 one traversal launch per round, 2 connect + light on a second stream; negative: the default by batch size
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
@@ -340,6 +340,8 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (c->refillAny < 1 || c->refillAny > 64) c->refillAny = 24;
 	if (getenv("RT_PAIRAGAIN")) c->pairAgain = atoi(getenv("RT_PAIRAGAIN"));
 	if (c->pairAgain < 1 || c->pairAgain > 65) c->pairAgain = 16;
+	if (getenv("RT_DRAIN_LANES")) c->drainLanes = c->drainLanesAny = atoi(getenv("RT_DRAIN_LANES"));
+	if (getenv("RT_DRAIN_LANES_ANY")) c->drainLanesAny = atoi(getenv("RT_DRAIN_LANES_ANY"));
 	if (getenv("RT_STEPMIN_XFORM")) c->stepMinXform = atoi(getenv("RT_STEPMIN_XFORM"));
 	if (c->stepMinXform < 0 || c->stepMinXform > 15) c->stepMinXform = 0;
 	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 8; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8;
@@ -1223,7 +1225,7 @@ static int slot_budget(const rt_ctx* c);
 static void launch_connect(rt_ctx* c, hipStream_t st, const PathState& P, const Queues& Q, int parity, uint* spill)
 {
 	// the any-hit walk has its own thresholds (RT_REFILL_ANY, RT_STEPMIN_ANY, RT_PAIRAGAIN_ANY)
-	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27);
+	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27) | RT_TUNE_DRAIN(c->drainLanesAny);
 	if (c->counting) hipLaunchKernelGGL((k_connect<true>), dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
 	else if (!c->S.wide) hipLaunchKernelGGL((k_connect<false>), dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
 	else {
@@ -1539,7 +1541,7 @@ static int ensure_stream_state(rt_ctx* c, int n)
 }
 static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int round, uint* spill)
 {
-	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27);
+	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27) | RT_TUNE_DRAIN(c->drainLanesAny);
 	if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
 	else if (c->S.wide8) {
 		// the 8-wide quantised walk, then the binary walk over the rays it handed back (not clean: normally none)
@@ -1561,14 +1563,14 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 {
 	const float t_min = 0.001f; // renderer.cpp:131
 	const int grid = c->gridBlocks;
-	// How connect(r) + light(r) share the machine with round r + 1 (profiles/r03_ab_stream_fuse.txt, r03_ab_gate.txt): one kernel at
-	// a time (RT_FUSE=0) pays every traversal launch's drain in full; both streams started together (RT_FUSE=2) make the two
-	// persistent kernels share the machine for their whole length (good below ~100 M samples per batch: 1/8 frame 9.85 -> 8.97 ms;
-	// bad above: full frame 50.82 -> 51.16); the default (RT_FUSE=3) holds the second stream at a gate that extend(r + 1) opens
-	// when its queue runs dry, so connect(r) fills that drain and nothing else: 8.92 / 26.68 / 50.52 ms at 1/8, 1/2 and the full frame,
-	// the best of the three at every size (by 0.3-1 %: a drain that shares the machine gets longer).  Default: the gate below 100 M
-	// samples per batch; above, one kernel at a time -- 0.6 % slower there, but every kernel's time and counters are its own, which
-	// is what the roofline block of the bench line is made of.
+	// How connect(r) + light(r) share the machine with round r + 1 (profiles/r03_ab_stream_fuse.txt, r04_ab_gate.txt): one kernel at a
+	// time (RT_FUSE=0) pays every traversal launch's drain in full; both streams started together (RT_FUSE=2) make the two persistent
+	// kernels share the machine for their whole length: good below ~100 M samples per batch (1/8 frame 11.0 -> 10.1 ms, 33 M samples
+	// 17.1 -> 16.4), level or slightly worse above, where the default therefore keeps one kernel at a time -- every kernel's time and
+	// counters are then its own, which is what the roofline block of the bench line is made of.  (Holding the second stream at a gate
+	// until extend(r + 1) has found its queue dry, so that connect(r) fills that drain and nothing else, was round 3's default below
+	// 100 M samples -- with a gate that never waited, ADVICE.md r3.  Made to wait, it is no better than no gate at any size
+	// (10.37 against 10.10 ms, 16.36 / 16.39, 85.2 / 83.6): taken out, profiles/patches/gate.diff.)
 	// Small batches (RT_FUSE=1; default below RT_MIXED_MAX samples): extend(r) and connect(r - 1) as ONE launch (k_traverse_s), one drain
 	// per round instead of two.
 	// Measured (profiles/r03_ab_one_launch_per_round.txt, 1080p x spp): 1: 3.73 -> 3.24 ms, 2: 4.50 -> 4.18, 4: 6.10 -> 6.02, 8: 9.00 -> 9.08, 16: 14.8 -> 15.8.
@@ -1576,7 +1578,6 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	const bool mixed = !c->counting && (c->fuseTraversal == 1 || (c->fuseTraversal < 0 && R.nSamples < mixedMax)) &&
 	                   (unsigned long long)R.nSamples * (unsigned)(c->S.nLights + 1) < 0x7FFFFFFFull;
 	const bool twoStreams = !mixed && (c->fuseTraversal < 0 ? R.nSamples < 100000000u : c->fuseTraversal != 0);
-	const bool gated = twoStreams && !c->gateBroken && (c->fuseTraversal < 0 || c->fuseTraversal == 3); // connect(r) + light(r) wait at a gate that extend(r + 1) opens when its queue runs dry
 	const StreamState& T = c->T;
 	hipStream_t st = c->stream, sb = twoStreams ? c->streamSide : c->stream;
 	const int cnt = c->counting ? 1 : 0;
@@ -1585,20 +1586,6 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	hipLaunchKernelGGL(k_generate_s, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, rounds == 1 ? 1 : 0, c->decideRays, cnt);
 	prof_end(c, st);
 	bool pendingJoin = false;
-	int sideRound = -1; // connect + light of this round still have to be submitted to the second stream
-	hipError_t sideErr = hipSuccess;
-	auto side_launch = [&](int r, bool gate) {
-		const int lastR = r + 1 == rounds ? 1 : 0;
-		if (twoStreams) { const hipError_t e = hipStreamWaitEvent(sb, c->streamFork, 0); if (e != hipSuccess) sideErr = e; }
-		if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sb, T.counts, r + 2); // opened by extend(r + 1), already submitted on the main stream
-		prof_begin(c, K_CONNECT, sb);
-		launch_connect_s(c, sb, T, r, twoStreams ? c->streamSideSpill : c->spill);
-		prof_end(c, sb);
-		prof_begin(c, K_SHADE, sb);
-		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, r, lastR, c->shadeLds);
-		prof_end(c, sb);
-		if (twoStreams) { const hipError_t e = hipEventRecord(c->streamJoin, sb); if (e != hipSuccess) sideErr = e; pendingJoin = true; }
-	};
 	for (int round = 0; round < rounds; round++) {
 		const int last = round + 1 == rounds ? 1 : 0, lastNext = round + 2 == rounds ? 1 : 0;
 		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
@@ -1613,12 +1600,6 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 #ifdef RT_TAIL_PROBE
 		tail_probe_print(st, "extend_s", round);
 #endif
-		if (sideRound >= 0) {
-			// connect + light of the round before, on the second stream: submitted only now, BEHIND extend(round), so that the gate
-			// can never sit in front of the kernel that opens it (two HIP streams may share one hardware queue)
-			side_launch(sideRound, gated);
-			sideRound = -1;
-		}
 		if (mixed && round > 0) { // the shadow answers of the round before came with this round's hits
 			prof_begin(c, K_SHADE, st);
 			hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, st, c->S, R, T, round - 1, 0, c->shadeLds);
@@ -1631,21 +1612,23 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		else hipLaunchKernelGGL(k_shade_s<false>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt, c->Qt);
 		prof_end(c, st);
 		if (mixed && !last) continue; // this round's shadow rays ride in the next round's traversal launch
-		if (twoStreams) HIPCHK(c, hipEventRecord(c->streamFork, st));
-		if (twoStreams && !last) sideRound = round; // submitted behind extend(round + 1)
-		else side_launch(round, false);
+		if (twoStreams) {
+			HIPCHK(c, hipEventRecord(c->streamFork, st));
+			HIPCHK(c, hipStreamWaitEvent(sb, c->streamFork, 0));
+		}
+		prof_begin(c, K_CONNECT, sb);
+		launch_connect_s(c, sb, T, round, twoStreams ? c->streamSideSpill : c->spill);
+		prof_end(c, sb);
+		prof_begin(c, K_SHADE, sb);
+		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, round, last, c->shadeLds);
+		prof_end(c, sb);
+		if (twoStreams) { HIPCHK(c, hipEventRecord(c->streamJoin, sb)); pendingJoin = true; }
 	}
-	if (sideErr != hipSuccess) return fail(c, RT_E_HIP, "second stream of the round loop: %s", hipGetErrorString(sideErr));
 	if (pendingJoin) HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0));
 	if (cnt) hipLaunchKernelGGL(k_fold_decided, dim3(1), dim3(1), 0, st, c->S, T.counts, c->counters);
-	HIPCHK(c, hipMemcpyAsync(c->hostCounts, T.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(c, hipMemcpyAsync(c->hostCounts, T.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
 	HIPCHK(c, hipStreamSynchronize(st));
 	const int* hc = c->hostCounts;
-	if (gated) {
-		c->gateWaits += (unsigned long long)hc[SC_GATE_WAITS], c->gateTimeouts += (unsigned long long)hc[SC_GATE_TIMEOUTS];
-		if (hc[SC_GATE_TIMEOUTS] > 0) c->gateBroken = true; // the two streams did not run side by side: both streams at once (RT_FUSE=2) from now on
-		if (hc[SC_GATE_WAITS] | hc[SC_GATE_TIMEOUTS]) (void)hipMemsetAsync(T.counts + SC_GATE_WAITS, 0, 2 * sizeof(int), st);
-	}
 	int rc = RT_OK;
 	if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 	else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
@@ -2223,20 +2206,12 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->fuseTraversal, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
+	         c->pairAgain, c->pairAgainAny, c->drainLanes, c->drainLanesAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();
-}
-
-int rt_get_gate_stats(rt_ctx* c, uint64_t* waits, uint64_t* timeouts)
-{
-	if (!c) return RT_E_ARG;
-	if (waits) *waits = c->gateWaits;
-	if (timeouts) *timeouts = c->gateTimeouts;
-	return RT_OK;
 }
 
 int rt_synchronize(rt_ctx* c)

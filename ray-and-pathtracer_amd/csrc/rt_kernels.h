@@ -184,12 +184,20 @@ __device__ __forceinline__ f3 sky_color(const DScene& S, const f3& D)
 	if (!p) return f3(0.0f);
 	return f3((float)p[0], (float)p[1], (float)p[2]) / 255;
 }
+// The gamma itself is the device library's single-precision powf (round 4; the reference's expression is a double-precision
+// pow rounded to float, which is what this was until round 3: 200 M double-precision pow per bench step, 1.45 ms of k_accumulate).
+// It is an OUTPUT transform: its value goes into the accumulator and nowhere else -- no ray, no texel index, no random draw
+// depends on it, so no hit id can move.  Error against the rounded double-precision value: <= 2 ulp (2.4e-7 relative; measured
+// on the 256 sky values: tests/test_gpu_parity.py::test_gamma_of_finished_samples), 400 x inside the 1e-4 radiance bar.  ONE
+// function everywhere a finished sample is made (here, k_accumulate, k_gamma_lut), so the knobs that move the gamma between
+// kernels still give identical bits.
+__device__ __forceinline__ float gamma_powf(float x) { return powf(x, RT_GAMMA); }
 // gammaLut[b] = the finished path-mode sample of radiance b / 255 (store_sample: pow(c, GAMMA) per channel, renderer.cpp:279-282)
 __global__ void k_gamma_lut(float* lut)
 {
 	const int b = (int)threadIdx.x;
 	const f3 c = f3((float)b, (float)b, (float)b) / 255;
-	lut[b] = x_powf(c.x * 1, RT_GAMMA);
+	lut[b] = gamma_powf(c.x * 1);
 }
 
 // diffuse::scatter (template/scene.h:605-620): att out, energy in/out
@@ -393,13 +401,15 @@ __device__ __forceinline__ void start_sample(const DScene& S, const DCamera& C, 
 // the others wait) at five waves per SIMD, and their registers are part of those kernels' floor; k_accumulate reads every
 // sample anyway, dense and with the whole machine: the sample is stored raw with w = 1 and gets its gamma there (w = 0: the
 // value is final -- the sky texel table of generate).  Same bits, same order of the accumulator's additions.
-__device__ __forceinline__ float4 gamma_sample(const f3& L) { return make_float4(x_powf(L.x * 1, RT_GAMMA), x_powf(L.y * 1, RT_GAMMA), x_powf(L.z * 1, RT_GAMMA), 0.0f); }
+__device__ __forceinline__ float4 gamma_sample(const f3& L) { return make_float4(gamma_powf(L.x * 1), gamma_powf(L.y * 1), gamma_powf(L.z * 1), 0.0f); }
+// the same as a called function: the kernels that store finished samples (RT_DEFER_GAMMA=0, the slot pipeline) do not carry three inlined copies
+__device__ __noinline__ void store_gamma_sample(float4* dst, float x, float y, float z) { *dst = gamma_sample(f3(x, y, z)); }
 __device__ __forceinline__ void store_sample(const RenderParams& R, uint sid, const f3& L)
 {
 	if (R.customOut) R.customOut[sid] = mk4(L, 0.0f);
 	else if (R.mode == 0) R.samples[sid] = make_float4(L.x / (float)1, L.y / (float)1, L.z / (float)1, 0.0f);
 	else if (R.deferGamma) R.samples[sid] = mk4(L, 1.0f);
-	else R.samples[sid] = gamma_sample(L);
+	else store_gamma_sample(R.samples + sid, L.x, L.y, L.z);
 }
 
 __device__ __forceinline__ void push_pending(PathState& P, int slot, const f3& O, const f3& D, const f3& W, const f3& E, int depth, int* overflow)

@@ -80,7 +80,9 @@ namespace rtd {
 //   the rest             the block's copy of the TLAS (pairs, reach records, instance transforms), when it fits
 // rows = 16 without a TLAS copy; a copy takes rows away down to RT_STACK_ROWS_MIN (the 16 instances of config 5: 13 rows;
 // measured there: 13 rows cost nothing, the copy takes 4 % off the frame set); a TLAS too large for that stays in global memory.
+#ifndef RT_LDS_WORDS
 #define RT_LDS_WORDS 5760 // 18 allocation granules of 320 words
+#endif
 #define RT_STACK_ROWS_MAX 16
 #ifndef RT_STACK_ROWS_MIN
 #define RT_STACK_ROWS_MIN 8
@@ -169,12 +171,12 @@ __device__ __forceinline__ float4 ld_lds(const lds_v4f* p) { const v4f v = *p; r
 typedef __attribute__((address_space(1))) uint glb_uint;
 struct Stack {
 	lds_uint* lds;    // &ldsStack[0][threadIdx.x]
-	glb_uint* spill;  // &spill[0][global lane]
+	glb_uint* spill;  // the grid's spill buffer, [entry][global lane] (wave-uniform: the lane's column is added where an entry is touched)
 	uint spillStride; // lanes in the grid
 	uint rows;        // entries held in LDS
 	uint sp;
 	int* overflow;
-	__device__ __forceinline__ size_t spill_at(uint entry) const { return (size_t)entry * spillStride; }
+	__device__ __forceinline__ size_t spill_at(uint entry) const { return (size_t)entry * spillStride + (blockIdx.x * blockDim.x + threadIdx.x); }
 	__device__ __forceinline__ void push(uint v)
 	{
 		RT_CHECK(sp <= RT_STACK_MAX, 1, overflow);
@@ -198,7 +200,7 @@ __device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* ove
 	st.rows = rows;
 	st.lds = (lds_uint*)ldsBase + threadIdx.x;
 	st.spillStride = gridDim.x * blockDim.x;
-	st.spill = (glb_uint*)spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	st.spill = (glb_uint*)spill;
 	st.sp = 0;
 	st.overflow = overflow;
 	return st;
@@ -299,7 +301,11 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // reservation by what is left there (256 entries early on, 64 near the end), and moves on to the other
 // sub-queues when its own is empty.
 #define RT_TUNE_CULL_COUNTED 0x10000 // 'tuning' bit: a counting launch drops unreachable TLAS children like a timed one
+#define RT_TUNE_DRAIN(lanes) ((lanes) <= 0 ? 0 : ((lanes) >= 64 ? 7 : (32 - __builtin_clz((unsigned)(lanes)))) << 17) // 'tuning' bits 17-19: the drain loop takes over at 1, 2, 4 .. 64 live lanes
 #define RT_HEADS 16
+#ifndef RT_NO_DRAIN_LOOP
+#define RT_NO_DRAIN_LOOP 0 // measurement builds: 1 keeps the drain in the scheduled machine
+#endif
 #ifndef RT_SHORT_QUEUE_RAYS
 #define RT_SHORT_QUEUE_RAYS 32 // queue entries per wave below which further waves of the grid do not take part
 #endif
@@ -333,7 +339,7 @@ __device__ unsigned long long g_sectionProbe[16];
 // points inside divergent code cost no vector registers)
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 #define RT_SEC_NOW() __builtin_readcyclecounter()
-#define RT_SEC_PUT(k, v) do { const unsigned long long secV = (v); if ((__ballot(true) & below) == 0) secAcc[k] += secV; } while (0)
+#define RT_SEC_PUT(k, v) do { const unsigned long long secV = (v); if (bits_below(__ballot(true)) == 0) secAcc[k] += secV; } while (0)
 #define RT_SEC_ADD(k, t0) RT_SEC_PUT(k, __builtin_readcyclecounter() - (t0))
 #define RT_SEC_COUNT(k) RT_SEC_PUT(k, 1ull)
 #define RT_SEC_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
@@ -353,10 +359,6 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 // SAME work item; false: the work item is complete and the lane is free.  Needs MIXED (the lane's kind of query changes).
 // Such a policy may also offer 'bool starts_done()': true after load() means the query just loaded needs no walk (its result is
 // what load() left in the head candidate) and goes to the next flush as it is.
-// A policy with 'static constexpr bool kSignalsDry = true' is told once per wave when the wave finds the queue dry
-// (void queue_dry()): the dense pipeline's extend opens a gate for the kernel that is to fill its drain (rt_stream.h k_gate).
-template <class P, class = void> struct pol_signals { static constexpr bool value = false; };
-template <class P> struct pol_signals<P, decltype((void)P::kSignalsDry)> { static constexpr bool value = P::kSignalsDry; };
 template <class P, class = void> struct pol_starts_done { static constexpr bool value = false; };
 template <class P> struct pol_starts_done<P, decltype((void)&P::starts_done)> { static constexpr bool value = true; };
 template <class P, class = void> struct pol_advances { static constexpr bool value = false; };
@@ -373,11 +375,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	constexpr bool WIDE = WIDTH == 4, WIDE8 = WIDTH == 8;
 	constexpr bool ANYWIDE = WIDE || WIDE8; // a wide walk: rays that are not clean go back to the binary walk
 	constexpr int REPEAT = ANY && !MIXED ? RT_CONNECT_REPEAT : RT_PAIR_REPEAT; // pair steps per iteration at most
+	constexpr bool DRAINS = !ANYWIDE && !pol_advances<Policy>::value && !RT_NO_DRAIN_LOOP; // the last rays of a wave leave the machine for a plain per-lane loop
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
 	const int refillMin = tuning & 0xFF, stepMinBusy = (tuning >> 8) & 0xFF, pairAgainBusy = (tuning >> 20) & 0x7F;
 	const int stepMinXformBusy = ((tuning >> 27) & 0xF) ? ((tuning >> 27) & 0xF) : stepMinBusy; // entry / exit: arithmetic and LDS only when the TLAS is in LDS
-	const uint lane = threadIdx.x & 63;
-	const unsigned long long below = (1ull << lane) - 1;
+	const int drainLanes = ((tuning >> 17) & 7) ? 1 << (((tuning >> 17) & 7) - 1) : 0; // RT_TUNE_DRAIN: live lanes of a wave whose queue is dry at which they leave the scheduled machine (0: never)
+	// (lane and the bits below it are recomputed where they are used: two instructions there instead of three registers kept live
+	// across the hottest loop of the library, which has none to spare at seven waves per SIMD)
+#define lane (threadIdx.x & 63)
+	auto bits_below = [](unsigned long long m) __attribute__((always_inline)) { return (int)__builtin_amdgcn_mbcnt_hi((uint)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint)m, 0u)); }; // set bits of m below this lane
 	// sub-queue h = [h * subLen, (h + 1) * subLen) cut at n; all of this is wave-uniform (SGPRs)
 	const int waveId = (int)(blockIdx.x * (blockDim.x >> 6)) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int subLen = ((n + RT_HEADS - 1) / RT_HEADS + 63) & ~63;
@@ -422,7 +428,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_STEP_COUNT
 	uint nsteps = 0, nenter = 0;
 #endif
-	bool signalled = false;  // pol.queue_dry() was called (policies with kSignalsDry)
 	int work = -1;           // queue entry this lane is tracing, -1 = idle
 	int chunkNext = 0, chunkEnd = 0; // wave-uniform: reserved, not yet handed out
 	// A short queue does not need the whole grid: a wave beyond one per RT_SHORT_QUEUE_RAYS entries (and beyond one per
@@ -438,14 +443,14 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	bool clean = false; // the current (world or object space) ray cannot produce a NaN slab product
 
 	// next node for this lane: pop the stack; an empty stack ends the ray, the sentinel leaves the instance
-	auto pop_next = [&]() {
+	auto pop_next = [&]() __attribute__((always_inline)) {
 		if (st.sp == 0) { link = RT_LINK_DONE; return; }
 		const uint v = st.pop();
 		link = v == RT_SENTINEL ? RT_LINK_EXIT : v;
 	};
 
 	// one primitive of a leaf (bvh.cpp:616-629 / :770-783) on its record, for the lanes enabled
-	auto leaf_test = [&](uint lk, const float4& r0, const float4& r1, const float4& r2, const float4& r3) {
+	auto leaf_test = [&](uint lk, const float4& r0, const float4& r1, const float4& r2, const float4& r3) __attribute__((always_inline)) {
 		const uint slot = lk & ~RT_LEAF_BIT;
 		const int kl = __float_as_int(r3.w);
 		const int kind = kl & 3;
@@ -464,6 +469,10 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			else link = lk + 1;
 		}
 	};
+	// ---- the four kinds of step live in rt_step_*.inc: the code of one step for the lanes enabled where the file is included, on the
+	// lane's state as it is named here (lk: the link the step is for).  Text inclusion, not lambdas: the scheduled machine below and
+	// the drain loop behind it make the same steps, and with closures the compiler's register allocation of the hot loop moved
+	// (k_extend_s: 0 -> 20 bytes of scratch at its 72 registers, which costs 10 % of the kernel; profiles/r04_ab_drain_loop.txt).
 	while (true) {
 		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
 		bool idle = work < 0;
@@ -537,7 +546,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 						}
 					}
 					if (!exhausted) {
-						const int mine = chunkNext + __popcll(freeMask & below);
+						const int mine = chunkNext + bits_below(freeMask);
 						const int avail = chunkEnd - chunkNext;
 						float tmax = 0;
 						const bool take = mine < chunkEnd && ((freeMask >> lane) & 1);
@@ -568,26 +577,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_TAIL_PROBE
 		if (exhausted && !probed) { probed = true; if (lane == 0) atomicMin(&g_tailProbe[1], __builtin_amdgcn_s_memrealtime()); }
 #endif
-		if constexpr (pol_signals<Policy>::value) {
-			if (exhausted && !signalled) {
-				signalled = true;
-				if (lane == 0) pol.queue_dry();
-			}
-		}
 		const bool stepping = work >= 0 && link != RT_LINK_DONE;
-		if (__ballot(stepping) == 0) {
-			if (exhausted && __ballot(work >= 0) == 0) {
-#ifdef RT_TAIL_PROBE
-				if (lane == 0) atomicMax(&g_tailProbe[2], __builtin_amdgcn_s_memrealtime());
-#endif
-#ifdef RT_SECTION_PROBE
-				if (lane == 0) secAcc[7] = RT_SEC_NOW() - secStart;
-				if (lane < 14) atomicAdd(&g_sectionProbe[lane], (unsigned long long)secAcc[lane]);
-#endif
-				break;
-			}
+		const unsigned long long stepMask = __ballot(stepping);
+		if (stepMask == 0) {
+			if (exhausted && __ballot(work >= 0) == 0) break;
 			continue; // only finished lanes left (they flush above), or nothing was handed out this time
 		}
+
+		// ---- the drain: the last rays of a wave leave the machine (see after the loop) ----
+		if constexpr (DRAINS) { if (exhausted && __popcll(stepMask) <= drainLanes) break; }
 
 		// ---- one iteration of the state machine ----
 		// Four kinds of step, four pieces of code.  A kind that only a few lanes want this iteration
@@ -621,112 +619,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_STEP_COUNT
 				nsteps++;
 #endif
-				// one sibling pair: of the BLAS (bvh.cpp:638-654 / :788-804) or, outside an instance in TLAS
-				// mode, of the TLAS (tlas.cpp:77-91 / :106-120) -- same test, same ordering rule
-				if (COUNT) { if (S.useTLAS && inst < 0) lc.tlasInner++; else lc.inner++; }
-				const bool atTlas = S.useTLAS && inst < 0;
-				if (WIDE8 && !atTlas) {
-					if (lk & RT_BOX_BIT) {
-						// a leaf the 8-wide nodes named: its own, exact box decides whether bvh::BIsOccluded visits it
-						const float4* bx = S.leafBox + 2 * (size_t)(lk & ~RT_BOX_BIT);
-						const float4 lo = bx[0], hi = bx[1];
-						const float dl = intersect_aabb_clean(O, rD, rayT, xyz(lo), xyz(hi));
-						if (dl != 1e30f) link = RT_LEAF_BIT | __float_as_uint(lo.w);
-						else pop_next();
-						continue;
-					}
-					// one 8-wide node: every child whose (outward-rounded) box the ray passes is visited; the nearest one next
-					const uint4* w = S.wide8 + 8 * (size_t)lk;
-					const uint4 h4 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], l0 = w[4], l1 = w[5];
-					const f3 org(__uint_as_float(h4.x), __uint_as_float(h4.y), __uint_as_float(h4.z));
-					const f3 sc(__uint_as_float(((h4.w & 0xFF) - 1u) << 23), __uint_as_float((((h4.w >> 8) & 0xFF) - 1u) << 23), __uint_as_float((((h4.w >> 16) & 0xFF) - 1u) << 23));
-					const uint qlx[2] = { q1.x, q1.y }, qly[2] = { q1.z, q1.w }, qlz[2] = { q2.x, q2.y }, qhx[2] = { q2.z, q2.w }, qhy[2] = { q3.x, q3.y }, qhz[2] = { q3.z, q3.w };
-					const uint cl[8] = { l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w };
-					float best = 1e30f;
-					uint bestLink = 0;
-#pragma unroll
-					for (int j = 0; j < 8; j++) {
-						const int sh = 8 * (j & 3);
-						const f3 blo(__fmaf_rn((float)((qlx[j >> 2] >> sh) & 0xFF), sc.x, org.x), __fmaf_rn((float)((qly[j >> 2] >> sh) & 0xFF), sc.y, org.y), __fmaf_rn((float)((qlz[j >> 2] >> sh) & 0xFF), sc.z, org.z));
-						const f3 bhi(__fmaf_rn((float)((qhx[j >> 2] >> sh) & 0xFF), sc.x, org.x), __fmaf_rn((float)((qhy[j >> 2] >> sh) & 0xFF), sc.y, org.y), __fmaf_rn((float)((qhz[j >> 2] >> sh) & 0xFF), sc.z, org.z));
-						float dj = intersect_aabb_clean(O, rD, rayT, blo, bhi);
-						if (cl[j] == RT_EMPTY) dj = 1e30f;
-						if (dj < best) {
-							if (best != 1e30f) st.push(bestLink);
-							best = dj, bestLink = cl[j];
-						} else if (dj != 1e30f) st.push(cl[j]);
-					}
-					if (best != 1e30f) link = bestLink; else pop_next();
-					continue;
-				}
-				if (WIDE && !atTlas) {
-					// one 4-wide node: every child whose box the ray passes is visited, in any order (a boolean query)
-					const float4* w = S.wide + 8 * (size_t)lk;
-					const float4 mnx = w[0], mny = w[1], mnz = w[2], mxx = w[3], mxy = w[4], mxz = w[5], lkf = w[6];
-					const float bx0[4] = { mnx.x, mnx.y, mnx.z, mnx.w }, by0[4] = { mny.x, mny.y, mny.z, mny.w }, bz0[4] = { mnz.x, mnz.y, mnz.z, mnz.w };
-					const float bx1[4] = { mxx.x, mxx.y, mxx.z, mxx.w }, by1[4] = { mxy.x, mxy.y, mxy.z, mxy.w }, bz1[4] = { mxz.x, mxz.y, mxz.z, mxz.w };
-					const uint cl[4] = { __float_as_uint(lkf.x), __float_as_uint(lkf.y), __float_as_uint(lkf.z), __float_as_uint(lkf.w) };
-					// entry distances (1e30f: missed, or an unused entry -- its inverted box reads as a huge one in a min / max slab test)
-					float td[4];
-					uint tl[4];
-#pragma unroll
-					for (int j = 0; j < 4; j++) {
-						const float dj = intersect_aabb_clean(O, rD, rayT, f3(bx0[j], by0[j], bz0[j]), f3(bx1[j], by1[j], bz1[j]));
-						td[j] = cl[j] != RT_EMPTY ? dj : 1e30f, tl[j] = cl[j];
-					}
-					// nearest first (an occluder is usually found in the first leaf reached): 5-exchange sorting network
-					auto cswap = [&](int a, int b) { const bool sw = td[b] < td[a]; const float ta = td[a]; const uint la = tl[a]; td[a] = sw ? td[b] : ta, tl[a] = sw ? tl[b] : la, td[b] = sw ? ta : td[b], tl[b] = sw ? la : tl[b]; };
-					cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
-					if (td[3] != 1e30f) st.push(tl[3]);
-					if (td[2] != 1e30f) st.push(tl[2]);
-					if (td[1] != 1e30f) st.push(tl[1]);
-					const bool have = td[0] != 1e30f;
-					const uint next = tl[0];
-					if (have) link = next; else pop_next();
-					continue;
-				}
-				const unsigned long long secT = RT_SEC_NOW();
-				RT_SEC_COUNT(9);
-				// TLAS level: the reach record of the pair (see reach[] above) is fetched in the same round trip as the pair
-				// itself (nearly every pair step has a TLAS lane or two among its ~35)
-				const bool useReach = (!COUNT || (tuning & RT_TUNE_CULL_COUNTED)) && atTlas && clean && fabsf(O.x) + fabsf(O.y) + fabsf(O.z) <= S.reachOriginMax;
-				float4 a0, a1, b0, b1, r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
-				if (S.tlasLds && atTlas) {
-					const uint tp = lk - S.tlasBase;
-					const lds_v4f* q = tlasL + 4 * tp;
-					a0 = ld_lds(q), a1 = ld_lds(q + 1), b0 = ld_lds(q + 2), b1 = ld_lds(q + 3);
-					if (useReach) {
-						const lds_v4f* qr = tlasL + 4 * S.tlasPairs + 3 * tp;
-						r0 = ld_lds(qr), r1 = ld_lds(qr + 1), r2 = ld_lds(qr + 2);
-					}
-				} else {
-					const float4* p = S.pairs + 4 * (size_t)lk;
-					a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3];
-					if (useReach) {
-						const float4* q = S.reach + 3 * (size_t)(lk - S.tlasBase);
-						r0 = q[0], r1 = q[1], r2 = q[2];
-					}
-				}
-				RT_SEC_WAIT();
-				RT_SEC_ADD(1, secT);
-				const unsigned long long secT2 = RT_SEC_NOW();
-				float dist1, dist2;
-				if (clean) dist1 = intersect_aabb_clean(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_clean(O, rD, rayT, xyz(b0), xyz(b1));
-				else dist1 = intersect_aabb_exact(O, rD, rayT, xyz(a0), xyz(a1)), dist2 = intersect_aabb_exact(O, rD, rayT, xyz(b0), xyz(b1));
-				uint c1 = __float_as_uint(a0.w), c2 = __float_as_uint(b0.w);
-				if (useReach) {
-					// drop children whose geometry the ray cannot reach
-					if (!box_reachable(O, rD, rayT, xyz(r0), f3(r0.w, r1.x, r1.y))) dist1 = 1e30f;
-					if (!box_reachable(O, rD, rayT, f3(r1.z, r1.w, r2.x), f3(r2.y, r2.z, r2.w))) dist2 = 1e30f;
-				}
-				if (dist1 > dist2) { float td = dist1; dist1 = dist2; dist2 = td; uint tc = c1; c1 = c2; c2 = tc; }
-				if (dist1 == 1e30f) pop_next();
-				else {
-					link = c1;
-					if (dist2 != 1e30f) st.push(c2);
-				}
-				RT_SEC_WAIT();
-				RT_SEC_ADD(2, secT2);
+#include "rt_step_pair.inc"
 			}
 		}
 		// the other kinds, on the links as they are now
@@ -756,74 +649,66 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		if (runEnter && wantEnter) nenter++;
 #endif
 		if (runLeaf && wantLeaf) {
-			// one primitive of a leaf: all four vectors of the record in one go (nearly every record is a triangle)
-			const float4* rec = S.prims + 4 * (size_t)(lk & ~RT_LEAF_BIT);
-			const unsigned long long secT = RT_SEC_NOW();
-			RT_SEC_COUNT(10);
-			float4 r0, r1, r2, r3;
-			r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-			RT_SEC_WAIT();
-			RT_SEC_ADD(3, secT);
-			const unsigned long long secT2 = RT_SEC_NOW();
-			leaf_test(lk, r0, r1, r2, r3);
-			RT_SEC_WAIT();
-			RT_SEC_ADD(4, secT2);
+#include "rt_step_leaf.inc"
 		}
 		if (runEnter && wantEnter) {
-			const unsigned long long secT = RT_SEC_NOW();
-			RT_SEC_COUNT(11);
-			// TLAS leaf: bvhInstance::BIntersect / IsOccluded (bvhInstance.cpp:3-35): ray to object space
-			// with invTransform (direction not renormalised: t is shared by both spaces); the BLAS is
-			// walked above a sentinel on the same stack
-			inst = (int)(lk & ~RT_INST_BIT);
-			RT_CHECK(S.useTLAS && inst >= 0 && inst < 256, 5, overflow);
-			if (COUNT) lc.inst++;
-			float invT[12];
-			uint rootB, rootW;
-			if (S.tlasLds) {
-				const lds_v4f* I = tlasL + 7 * S.tlasPairs + 3 * inst;
-				const v4f m0 = I[0], m1 = I[1], m2 = I[2];
-				invT[0] = m0.x, invT[1] = m0.y, invT[2] = m0.z, invT[3] = m0.w, invT[4] = m1.x, invT[5] = m1.y, invT[6] = m1.z, invT[7] = m1.w;
-				invT[8] = m2.x, invT[9] = m2.y, invT[10] = m2.z, invT[11] = m2.w;
-				rootB = rootW = ((const lds_uint*)(tlasL + 7 * S.tlasPairs + 3 * S.nInst))[inst];
-			} else {
-				const DInstance* I = S.inst + inst;
-#pragma unroll
-				for (int k = 0; k < 12; k++) invT[k] = I->invT[k];
-				rootB = I->rootLink, rootW = WIDE8 ? I->rootWide8 : I->rootWide;
-			}
-			worldRay[0 * RT_BLOCK] = __float_as_uint(O.x), worldRay[1 * RT_BLOCK] = __float_as_uint(O.y), worldRay[2 * RT_BLOCK] = __float_as_uint(O.z);
-			worldRay[3 * RT_BLOCK] = __float_as_uint(D.x), worldRay[4 * RT_BLOCK] = __float_as_uint(D.y), worldRay[5 * RT_BLOCK] = __float_as_uint(D.z);
-			const f3 Oo = xform_pos(invT, O);
-			const f3 Do = xform_vec(invT, D);
-			O = Oo, D = Do, rD = rcp3(Do);
-			clean = ray_is_clean(O, D, rD);
-			link = ANYWIDE ? rootW : rootB;
-			if (link == RT_EMPTY) link = RT_LINK_EXIT;
-			else st.push(RT_SENTINEL);
-			if constexpr (ANYWIDE) { if (!clean) { pol.leftover(work); work = -1; link = RT_LINK_DONE; } } // not clean in object space: the binary walk redoes this ray
-			RT_SEC_WAIT();
-			RT_SEC_ADD(5, secT);
+#include "rt_step_enter.inc"
 		}
 		if (runExit && wantExit) {
-			const unsigned long long secT = RT_SEC_NOW();
-			RT_SEC_COUNT(12);
-			// back to world space (the backup ray of bvhInstance.cpp:6, :20), then the next TLAS entry.  The backup is in
-			// LDS: fetching the ray again from the path state cost two HBM round trips per exit -- a random slot each
-			// time, 0.75 exits per ray -- which was most of this kernel's HBM traffic, and the whole wave waited for them.
-			O = f3(__uint_as_float(worldRay[0 * RT_BLOCK]), __uint_as_float(worldRay[1 * RT_BLOCK]), __uint_as_float(worldRay[2 * RT_BLOCK]));
-			D = f3(__uint_as_float(worldRay[3 * RT_BLOCK]), __uint_as_float(worldRay[4 * RT_BLOCK]), __uint_as_float(worldRay[5 * RT_BLOCK]));
-			rD = rcp3(D);
-			clean = ray_is_clean(O, D, rD);
-			inst = -1;
-			pop_next();
-			RT_SEC_WAIT();
-			RT_SEC_ADD(6, secT);
+#include "rt_step_exit.inc"
 		}
 	}
+	// ---- the drain: the last rays of a wave walk alone ----
+	// Once the queue is dry and only a few lanes still hold a ray, the scheduled machine above is mostly overhead: a wave-64
+	// instruction takes its issue slots whatever the number of enabled lanes, and an iteration of the machine is ~300 of them
+	// (ballots, thresholds, the unrolled repeats) for the one or two steps it makes -- measured: a lone lane's step takes
+	// 0.61-0.65 us and does not wait for memory (DESIGN.md finding 52).  So these lanes leave the loop for good (nothing will be
+	// handed out any more) and each walks its ray to the end in the classic per-lane loop: one plain step after the other, ~100
+	// instructions per step.  Every ray makes the steps it would make in the machine, in the same order: same bits.  The code sits
+	// BEHIND the loop on purpose: inside it (tried first) the hot loop of k_extend_s went from 0 to 92 bytes of scratch at its 72
+	// registers.  The wide walks and the policies that keep a lane for the next query (advance) stay in the machine.
+	if constexpr (DRAINS) {
+		while (work >= 0 && link != RT_LINK_DONE) {
+			const uint lk = link;
+#ifdef RT_STEP_COUNT
+			nsteps++;
+#endif
+			if (!(lk & (RT_LEAF_BIT | RT_INST_BIT))) {
+#include "rt_step_pair.inc"
+			} else if (lk == RT_LINK_EXIT) {
+#include "rt_step_exit.inc"
+			} else if (lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT)) {
+#include "rt_step_leaf.inc"
+			}
+			else if (!(lk & RT_LEAF_BIT)) {
+#ifdef RT_STEP_COUNT
+				nenter++;
+#endif
+#include "rt_step_enter.inc"
+			} else { *overflow = 199; link = RT_LINK_DONE; } // a link no step understands (a corrupt tree): reported as RT_E_STATE
+		}
+		if (work >= 0) {
+#ifdef RT_STEP_COUNT
+			if constexpr (!ANY && !MIXED) { if (g_stepOut) g_stepOut[pol.slot_of(work)] = (nsteps & 0xFFFFu) | (nenter << 16); }
+#endif
+			if constexpr (MIXED) {
+				if (laneAny) pol.store(work, hit.kind == 1);
+				else { hit.t = rayT; pol.store(work, hit, O, D); }
+			} else if constexpr (ANY) pol.store(work, hit.kind == 1);
+			else { hit.t = rayT; pol.store(work, hit, O, D); }
+		}
+	}
+#ifdef RT_TAIL_PROBE
+	if (lane == 0) atomicMax(&g_tailProbe[2], __builtin_amdgcn_s_memrealtime());
+#endif
+#ifdef RT_SECTION_PROBE
+	if (lane == 0) secAcc[7] = RT_SEC_NOW() - secStart;
+	if (lane < 14) atomicAdd(&g_sectionProbe[lane], (unsigned long long)secAcc[lane]);
+#endif
 }
 
 #undef worldRay
+#undef lane
 
 // ---- one ray at a time (the general path-mode kernel) ----------------------------------------------
 // The same walk as trace_persistent for a single ray held by one lane: used by k_sample_general, where
@@ -927,8 +812,8 @@ __device__ __forceinline__ void resolve_hit_lazy(const DScene& S, const HitRef& 
 	const int kind = __float_as_int(r3.w) & 3;
 	if (matType) *matType = (__float_as_int(r3.w) >> RT_TYPE_SHIFT) & 3;
 	if (kind == RT_KIND_TRI) {
-		const float4 r1 = rec[1], r2 = rec[2];
-		normal = f3(r0.w, r1.w, r2.w);
+		// (N.y and N.z alone, not the vectors they ride in: this runs in the traversal kernels' flush, where every register counts)
+		normal = f3(r0.w, ((const float*)rec)[7], ((const float*)rec)[11]);
 		if (hit.inst >= 0) normal = normalize(xform_vec(S.inst[hit.inst].T, normal));
 	} else if (kind == RT_KIND_SPHERE) {
 		const float4 r1 = rec[1];

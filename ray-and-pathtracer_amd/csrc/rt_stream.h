@@ -51,10 +51,6 @@ namespace rtd {
 #define SC_TRACE 7   // length of the traversal queue
 #define SC_LEFTOVER 8 // shadow rays the 4-wide walk handed back
 #define SC_DECIDED 9 // rays answered by their producer (counting launches)
-#define SC_GATE 10   // round + 1 of the last extend launch of this batch that found its queue dry: k_gate(r) lets connect(r) start at r + 2
-#define SC_GATE_WAITS 11    // k_gate launches that found the gate closed when they started (they really waited)
-#define SC_GATE_TIMEOUTS 12 // k_gate launches that gave up (the two streams did not run side by side): the host stops gating
-#define SC_ROUND 13  // the round whose extend runs next / is running (prepare_round): what an extend launch publishes + 1 at SC_GATE
 
 struct StreamState {
 	float4* O[2];     // ray origin xyz, w = ray.t after the head tests        } entry e of round parity p
@@ -178,32 +174,12 @@ __global__ void k_fold_decided(DScene S, int* counts, DCounters* counters)
 __device__ __forceinline__ void prepare_round(const StreamState& T, int next /* the round being prepared */, int n0)
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0) return;
-	if (n0 >= 0) T.counts[SC_N + next % 3] = n0, T.counts[SC_GATE] = 0; // generate: the batch's samples are round 0's entries; no extend of this batch has run dry yet
-	T.counts[SC_TRACE] = 0, T.counts[SC_N + (next + 1) % 3] = 0, T.counts[SC_SHADOW + next % 3] = 0, T.counts[SC_ROUND] = next;
+	if (n0 >= 0) T.counts[SC_N + next % 3] = n0; // generate: the batch's samples are round 0's entries
+	T.counts[SC_TRACE] = 0, T.counts[SC_N + (next + 1) % 3] = 0, T.counts[SC_SHADOW + next % 3] = 0;
 	for (int h = 0; h < RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
 	// connect of the round before 'next' (it starts after the kernel this runs in)
 	T.counts[SC_LEFTOVER] = 0;
 	for (int h = RT_HEADS; h < 2 * RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
-}
-// The gate of the second stream (RT_FUSE=3): one wave waits until extend(r + 1) has found its queue dry, then connect(r) and
-// light(r) -- queued behind this kernel -- fill the drain of extend(r + 1): its longest rays finish alone for 0.5-0.9 ms whatever
-// the launch held, with the machine all but idle (profiles/r03_ab_stream_fuse.txt).  Started together (RT_FUSE=2) the two
-// persistent kernels share the machine for their whole length and both run longer; one after the other (RT_FUSE=0) every drain
-// is paid in full.  Every extend launch publishes its round + 1 when it runs dry (StreamExtendPolicy::queue_dry; generate zeroes
-// the word at the start of a batch), and gate(r) waits for a value >= r + 2: what extend(r) or an earlier batch left there
-// cannot open it.  The host submits gate(r) AFTER extend(r + 1), so streams that share a hardware queue cannot put the waiter in
-// front of the kernel it waits for.  The wait is bounded (50 ms of the 100 MHz clock; a gated batch's extend launch takes a
-// few ms): a timeout is counted, the host reads the count with the batch's flags and stops gating for this context.
-__global__ void k_gate(int* counts, int want)
-{
-	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-	bool waited = false;
-	while (__hip_atomic_load(&counts[SC_GATE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-		waited = true;
-		__builtin_amdgcn_s_sleep(64);
-		if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) { if (threadIdx.x == 0) counts[SC_GATE_TIMEOUTS]++; break; }
-	}
-	if (waited && threadIdx.x == 0) counts[SC_GATE_WAITS]++;
 }
 // connect's work heads alone: the leftover launch of the 4-wide walk goes through its own list with them
 __global__ void k_stream_begin(StreamState T)
@@ -258,9 +234,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_s(DScene S, DCamera C, Re
 
 // extend: Scene::FindNearest for the entries of the traversal queue
 struct StreamExtendPolicy {
-	static constexpr bool kSignalsDry = true;
-	// (the round comes from memory, once per wave, instead of as a kernel argument: one more live scalar cost k_extend_s 12 bytes of scratch)
-	__device__ __forceinline__ void queue_dry() const { __hip_atomic_store(&T.counts[SC_GATE], T.counts[SC_ROUND] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 	const DScene& S;
 	const StreamState& T;
 	int parity, last;

@@ -26,7 +26,7 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
               "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_device_of",
               "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy", "rt_build_info", "rt_tuning_info",
-              "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table", "rt_get_gate_stats"]
+              "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table"]
 
 
 class RtQlearnParams(C.Structure):
@@ -115,7 +115,6 @@ def rt_lib():
         L.rt_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.rt_get_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        L.rt_get_gate_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _rt = L
     return _rt
 
@@ -547,12 +546,6 @@ class HostRenderer:
     def build_info(self):
         """rt_build_info() + rt_tuning_info(): compile flags / compile-time tuning of the library and the tuning this context resolved"""
         return self.rt.rt_build_info().decode() + " | " + self.rt.rt_tuning_info(self.ctx).decode()
-
-    def gate_stats(self):
-        """rt_get_gate_stats: (gate launches that really waited, gate launches that timed out) since rt_create"""
-        w, t = C.c_uint64(0), C.c_uint64(0)
-        self._rt(self.rt.rt_get_gate_stats(self.ctx, C.byref(w), C.byref(t)))
-        return int(w.value), int(t.value)
 
     def set_profiling(self, on):
         self._rt(self.rt.rt_set_profiling(self.ctx, int(on)))
