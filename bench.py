@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--qlearn-mask", type=int, default=3, help="rt_qlearn_params::learn_mask: 3 = every fourth sample pays rewards (all samples pick guided), 0 = all")
     ap.add_argument("--emulate-world", type=int, default=0, help="profiling on ONE GPU: render only the rows rank 0 of an N-rank run renders "
                     "(no process group, no gather): the counters of that share are what rank 0 of the N-GPU run is priced with")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world N: the rows of rank R instead of rank 0's (the N-GPU step is as "
+                    "long as its SLOWEST share: profiles/r04_shares_all_ranks.txt)")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,18 +110,21 @@ def main():
         if world != 1:
             raise SystemExit("bench.py: --emulate-world runs on one rank")
         shard = dpar.RowShard(H, W, 0, 1, acc.device)
-        shard.first, shard.stride, shard.count = dpar.shard_rows(H, 0, args.emulate_world)
+        if not 0 <= args.emulate_rank < args.emulate_world:
+            raise SystemExit("bench.py: --emulate-rank %d of %d" % (args.emulate_rank, args.emulate_world))
+        shard.first, shard.stride, shard.count = dpar.shard_rows(H, args.emulate_rank, args.emulate_world)
     host_staging = None
     if world > 1 and backend != "nccl":
         host_staging = (torch.zeros((H, W, 4), dtype=torch.float32), dpar.RowShard(H, W, rank, world, torch.device("cpu")))
 
     qbox = cfg.get("qbox", ((-12.0, -2.0, -8.0), (12.0, 10.0, 16.0)))
+    timing, timed = {}, [False]  # render / gather split of the timed steps (several ranks)
 
     def step():
         acc.zero_()
         torch.cuda.synchronize()
         if not args.qlearn:
-            dpar.render_step(r, acc, mode, 0, spp, shard, host_staging)
+            dpar.render_step(r, acc, mode, 0, spp, shard, host_staging, timing if timed[0] else None)
             return
         # every step learns from scratch, so that the K timed steps do the same work
         r.qlearn_enable(16, qbox[0], qbox[1], 0.3, 0.2, 1.0, args.qlearn_mask)
@@ -161,20 +166,25 @@ def main():
     r.set_profiling(True)
     r.profile()
     fence()
+    timed[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    timed[0] = False
     prof = r.profile()
     r.set_profiling(False)
 
     red_dev = "cuda" if backend == "nccl" else "cpu"
     t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     cnt = torch.tensor([near["rays_nearest"], occl["rays_occluded"]], dtype=torch.float64, device=red_dev)
+    split = torch.tensor([timing.get("render_s", 0.0), timing.get("gather_s", 0.0)], dtype=torch.float64, device=red_dev)
+    split0 = split.clone()
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(split, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     rays_all = float(cnt.sum().item())  # per step, all ranks
 
@@ -187,7 +197,7 @@ def main():
         launches_per_step = ext["launches"] / args.steps
         avg_ms = ext["ms"] / max(1, ext["launches"])  # HIP events on the kernel's own stream, inside the timed steps
         out = {
-            "metric": ("Mrays/s at %d×%d×%dspp" % (W, H, spp)) + (" (rank 0's rows of a %d-rank shard only: a profiling line)" % args.emulate_world if args.emulate_world > 1 else ""),
+            "metric": ("Mrays/s at %d×%d×%dspp" % (W, H, spp)) + (" (rank %d's rows of a %d-rank shard only: a profiling line)" % (args.emulate_rank, args.emulate_world) if args.emulate_world > 1 else ""),
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -198,6 +208,11 @@ def main():
                        "rays_definition": "value counts primary pixel samples (reference's Mrays/s, renderer.cpp:300); all_rays counts every FindNearest + IsOccluded query"},
             "all_rays_mrays_per_s": round(rays_all / sec_per_step / 1e6, 3),
             "rays_per_step": {"nearest": int(cnt[0].item()), "occluded": int(cnt[1].item())},
+            # several ranks: where a step's time goes on the host's clock -- render = until the rank's own rows are complete, gather =
+            # from there until the exchange has completed on the rank (it includes waiting for the slowest share); rank 0 and the
+            # maximum over the ranks.  null on one rank (nothing is gathered) and under --qlearn (the step is several batches).
+            "render_ms": ({"rank0": round(float(split0[0].item()) / args.steps * 1e3, 3), "max": round(float(split[0].item()) / args.steps * 1e3, 3)} if world > 1 and not args.qlearn else None),
+            "gather_ms": ({"rank0": round(float(split0[1].item()) / args.steps * 1e3, 3), "max": round(float(split[1].item()) / args.steps * 1e3, 3)} if world > 1 and not args.qlearn else None),
             "roofline": roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, args.emulate_world if args.emulate_world > 1 else world,
                                        {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]},
                                        r.build_info(), sec_per_step, prof["connect"]),
@@ -270,9 +285,9 @@ def roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, w
         pj = json.load(open(ppath))
     except Exception:
         pj = None
-    rb["note"] = ("batches below 100 M samples (and RT_FUSE=2 / 3) run connect(r) + light(r) on a second stream, held at a gate until extend(r + 1) has "
-                  "found its queue dry: the kernel times of kernel_ms_per_step then overlap and do not add up to the step, and avg_launch_ms is the "
-                  "extend launches' own duration with that company; batches of 100 M samples and more (the default workload) run one kernel at a time")
+    rb["note"] = ("batches below 100 M samples (and RT_FUSE=2) run connect(r) + light(r) on a second stream beside round r + 1: the kernel times of "
+                  "kernel_ms_per_step then overlap and do not add up to the step, and avg_launch_ms is the extend launches' own duration with that "
+                  "company; batches of 100 M samples and more (the default workload) run one kernel at a time")
     # with N ranks the counter file is used when it was measured on this rank's share: the row shard renders H / N rows of every
     # frame, the counter file of the 1-GPU share ("--spp S/N": the same number of samples per rank) is the closest committed
     # stand-in and is NOT used -- frac stays null unless a file for exactly [workload, W, H, spp, world] exists

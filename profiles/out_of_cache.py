@@ -1,0 +1,75 @@
+"""The traversal out of the caches (not a bench line).  Every BASELINE scene is a few MB and is served from L2 / the
+Infinity Cache, so north_star's "fraction of the HBM roofline on BVH traversal" has no meaning on them.  This renders the seeded
+8.4 M-triangle terrain of scenes.terrain_scene (pairs + primitive records 1 GiB = four Infinity Caches; one scene BVH, binned SAH,
+built by the host mirror) at 1920x1080 in path mode and reports the kernels' times; profiles/out_of_cache.sh runs it under
+rocprofv3 --pmc for HBM bytes, L2 hit rate and texture-addresser busy.  With --check the hits of a 64 x 64 crop of the frame are
+compared with the oracle's, bit for bit (the oracle builds the same tree on the CPU).
+Usage (GPU box): python profiles/out_of_cache.py [--n 2048] [--spp 4] [--steps 3] [--check] [--json out.json]"""
+import argparse, importlib, json, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=2048); ap.add_argument("--spp", type=int, default=4); ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--check", action="store_true"); ap.add_argument("--json", default="")
+args = ap.parse_args()
+ha = importlib.import_module("ray-and-pathtracer_amd.host_api"); scenes = importlib.import_module("ray-and-pathtracer_amd.scenes")
+W, H = 1920, 1080
+t0 = time.time()
+r = ha.HostRenderer(W, H)
+d = scenes.terrain_scene(r.scene, n=args.n)
+t_build = time.time() - t0
+r.commit()
+c = d["camera"]
+r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+import ctypes as C
+raw = (C.c_int * 7)()
+r.scene.L.rth_bvh_info(r.scene.h, -1, raw)
+info = {"nodes_used": raw[0], "N": raw[1]}
+out = {"scene": "terrain n=%d" % args.n, "triangles": d["triangles"], "bvh_nodes": int(info["nodes_used"]),
+       "pair_bytes": int(info["nodes_used"]) // 2 * 64, "prim_bytes": int(info["N"]) * 64, "host_build_s": round(t_build, 1),
+       "frame": "%dx%d x %d spp, path integrator (five hit levels)" % (W, H, args.spp)}
+out["scene_bytes"] = out["pair_bytes"] + out["prim_bytes"]
+print("built: %d triangles, %d nodes, pairs + prims %.2f GB, %.1f s" % (out["triangles"], out["bvh_nodes"], out["scene_bytes"] / 1e9, t_build), flush=True)
+if args.check:
+    from oracle import oracle_api as oa
+    t0 = time.time()
+    o = oa.OracleScene(); scenes.terrain_scene(o, n=args.n)
+    tl, tr, bl = (np.array(c[k], np.float64) for k in ("top_left", "top_right", "bottom_left"))
+    x0, y0, n = 928, 560, 64  # a crop below the horizon
+    P = lambda x, y: tl + (x / W) * (tr - tl) + (y / H) * (bl - tl)
+    orr = oa.OracleRenderer(o, n, n)
+    orr.set_camera(c["cam_pos"], tuple(P(x0, y0)), tuple(P(x0 + n, y0)), tuple(P(x0, y0 + n)))
+    O, D = orr.primary_rays()
+    ref, got = o.find_nearest(O, D, t_min=1e-6), r.find_nearest(O, D, t_min=1e-6)
+    ok = (np.array_equal(got["obj"], ref["obj"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+          and np.array_equal(got["normal"][ref["obj"] != -1].view(np.uint32), ref["normal"][ref["obj"] != -1].view(np.uint32)))
+    occ_ref, occ_got = o.is_occluded(O, D)["occluded"], r.is_occluded(O, D)
+    ok = ok and np.array_equal(occ_ref, occ_got)
+    out["oracle_check"] = {"crop": [x0, y0, n, n], "rays": int(len(O)), "hits": int((ref["obj"] != -1).sum()), "bit_exact": bool(ok), "oracle_s": round(time.time() - t0, 1)}
+    print("oracle check:", out["oracle_check"], flush=True)
+    o.close()
+    assert ok, "the crop's hits differ from the oracle's"
+# counting pass (the walk the timed kernels make), warm-up, timed steps
+r.set_counting(ha.RT_COUNT_EXECUTED); r.counters()
+r.clear(); r.render(ha.RT_MODE_PATH, 0, args.spp)
+near, occl = r.counters_split(); r.set_counting(False)
+r.clear(); r.render(ha.RT_MODE_PATH, 0, args.spp); r.synchronize()
+r.set_profiling(True); r.profile()
+t0 = time.perf_counter()
+for s in range(args.steps):
+    r.clear(); r.render(ha.RT_MODE_PATH, 0, args.spp)
+r.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+pr = r.profile(); r.set_profiling(False)
+out["ms_per_step"] = round(dt * 1e3, 3)
+out["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in pr.items() if v["launches"]}
+out["extend_launches_per_step"] = pr["extend"]["launches"] / args.steps
+out["work_per_step"] = {k: int(near[k]) for k in ("inner_visits", "prim_tests", "rays_nearest")}
+out["work_per_step"].update({"occluded_" + k: int(occl[k]) for k in ("inner_visits", "prim_tests", "rays_occluded")})
+out["extend_algorithmic_bytes_per_step"] = int(ha.algorithmic_bytes(near))
+out["mrays_per_s_primary"] = round(W * H * args.spp / dt / 1e6, 1)
+out["build"] = r.build_info()
+print(json.dumps(out))
+if args.json:
+    json.dump(out, open(args.json, "w"), indent=1)
+r.close()

@@ -166,3 +166,35 @@ def synthetic_sky_hdr(width=256, height=128, seed=7):
     lin += sun[..., None] * 40.0
     lin[height - 4:, :8] = 0.0  # exact zeros (e = 0 texels)
     return lin
+
+
+def terrain(n=2048, seed=11, size=64.0, height=6.0):
+    """A seeded procedural heightfield of n x n cells = 2 n^2 triangles (n = 2048: 8,388,608), (T, 9) float32: five octaves of
+    value noise (bilinear, seeded) over a size x size square centred on the origin, heights in [0, height].  The out-of-cache
+    stand-in for the reference's big meshes (eifel.obj, christ.obj: .MISSING_LARGE_BLOBS): at n = 2048 its pair and
+    primitive records are 1 GiB, four times the MI355X's Infinity Cache (profiles/out_of_cache.py)."""
+    rng = np.random.default_rng(seed)
+    v = n + 1
+    u = np.linspace(0.0, 1.0, v, dtype=np.float64)
+    h = np.zeros((v, v), np.float64)
+    amp, freq = 1.0, 4
+    for _ in range(5):
+        g = rng.random((freq + 2, freq + 2))
+        x = u * freq
+        i0 = np.minimum(x.astype(np.int64), freq)
+        f = x - i0
+        f = f * f * (3 - 2 * f)
+        row = g[i0][:, None, :] * (1 - f)[:, None, None] + g[i0 + 1][:, None, :] * f[:, None, None]  # [v, 1, freq + 2]
+        a = row[:, 0, :][:, i0] * (1 - f)[None, :] + row[:, 0, :][:, i0 + 1] * f[None, :]
+        h += amp * a
+        amp *= 0.5
+        freq *= 2
+    h = (h - h.min()) / (h.max() - h.min()) * height
+    xs = ((u - 0.5) * size).astype(np.float32)
+    X, Z = np.meshgrid(xs, xs, indexing="ij")
+    P = np.stack([X, h.astype(np.float32), Z], -1)  # [v, v, 3]
+    p00, p10, p01, p11 = P[:-1, :-1], P[1:, :-1], P[:-1, 1:], P[1:, 1:]
+    tris = np.empty((n, n, 2, 9), np.float32)
+    tris[:, :, 0, 0:3], tris[:, :, 0, 3:6], tris[:, :, 0, 6:9] = p00, p01, p10  # counter-clockwise seen from above
+    tris[:, :, 1, 0:3], tris[:, :, 1, 3:6], tris[:, :, 1, 6:9] = p10, p01, p11
+    return tris.reshape(-1, 9)

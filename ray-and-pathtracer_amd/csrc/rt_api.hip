@@ -66,6 +66,7 @@ struct rt_ctx {
 	hipStream_t streamSide = nullptr;
 	uint* streamSideSpill = nullptr;
 	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
+	hipEvent_t gatherDone = nullptr; // rt_gather_rows with this context as the source: its rows have arrived at the destination
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
@@ -384,6 +385,7 @@ void rt_destroy(rt_ctx* c)
 	if (c->streamSideSpill) (void)hipFree(c->streamSideSpill);
 	if (c->streamFork) (void)hipEventDestroy(c->streamFork);
 	if (c->streamJoin) (void)hipEventDestroy(c->streamJoin);
+	if (c->gatherDone) (void)hipEventDestroy(c->gatherDone);
 	for (int k = 0; k < 2; k++) if (c->megaEv[k]) (void)hipEventDestroy(c->megaEv[k]);
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
@@ -465,8 +467,10 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		}
 	}
 
-	// pairs + prims of every BLAS, concatenated
-	std::vector<float> pairs, prims;
+	// pairs + prims of every BLAS, concatenated; rel: the 32-byte parent-relative form of every BLAS pair (rt_scene_dev.h rel[]),
+	// all or nothing: relOK falls when a parent's box plane is not bit for bit one of its children's, or a link needs bits 26-28
+	std::vector<float> pairs, prims, rel;
+	bool relOK = RT_PAIR32 && !(getenv("RT_PAIR32") && atoi(getenv("RT_PAIR32")) == 0);
 	std::vector<uint> rootLink(d->n_blas), pairOffOf(d->n_blas);
 	for (uint k = 0; k < d->n_blas; k++) {
 		const rt_blas& b = d->blas[k];
@@ -503,6 +507,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		}
 		rootLink[k] = b.n_prims == 0 ? RT_EMPTY : link_of(0);
 		pairs.resize(pairs.size() + (size_t)(b.nodes_used / 2) * 16, 0.0f);
+		rel.resize(rel.size() + (size_t)(b.nodes_used / 2) * 8, 0.0f);
 		for (uint i = 2; i + 1 < b.nodes_used + 0u && b.n_prims > 0; i += 2) {
 			float* rec = &pairs[(size_t)(pairOff + i / 2) * 16];
 			for (int s = 0; s < 2; s++) {
@@ -511,6 +516,26 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 				memcpy(rec + 8 * s, nd.aabb_min, 12), memcpy(rec + 8 * s + 3, &lk, 4);
 				memcpy(rec + 8 * s + 4, nd.aabb_max, 12);
 			}
+		}
+		// the same pairs relative to their parent (the inner node whose left_first names the pair)
+		for (uint pi = 0; pi < b.nodes_used && b.n_prims > 0 && relOK; pi++) {
+			if (pi == 1 || b.nodes[pi].prim_count > 0) continue;
+			const rt_bvh_node& par = b.nodes[pi];
+			const uint i = par.left_first;
+			const rt_bvh_node &A = b.nodes[i], &B = b.nodes[i + 1];
+			uint la = link_of(i), lb = link_of(i + 1);
+			if (((la | lb) & (7u << 26)) != 0) { relOK = false; break; } // (the leaf / instance flags sit above bit 28)
+			float* rr = &rel[(size_t)(pairOff + i / 2) * 8];
+			for (int k = 0; k < 6 && relOK; k++) {
+				const float pa = k < 3 ? par.aabb_min[k] : par.aabb_max[k - 3], a = k < 3 ? A.aabb_min[k] : A.aabb_max[k - 3], bb = k < 3 ? B.aabb_min[k] : B.aabb_max[k - 3];
+				uint pu, au, bu;
+				memcpy(&pu, &pa, 4), memcpy(&au, &a, 4), memcpy(&bu, &bb, 4);
+				uint& word = k < 3 ? la : lb;
+				if (au == pu) rr[k] = bb;                                  // A carries the parent's value, B's is explicit: bit clear
+				else if (bu == pu) rr[k] = a, word |= 1u << (26 + k % 3);  // B carries the parent's value, A's is explicit: bit set
+				else relOK = false;
+			}
+			memcpy(rr + 6, &la, 4), memcpy(rr + 7, &lb, 4);
 		}
 		prims.resize(prims.size() + (size_t)b.n_prims * 16);
 		for (uint j = 0; j < b.n_prims; j++) {
@@ -728,6 +753,13 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	HIPCHK(c, dalloc(c->sceneAllocs, &dp, pairs.size() + 16));
 	HIPCHK(c, hipMemcpy(dp, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
 	S.pairs = (const float4*)dp;
+	S.rel = nullptr;
+	if (relOK && !rel.empty()) {
+		float* dr = nullptr;
+		HIPCHK(c, dalloc(c->sceneAllocs, &dr, rel.size() + 8));
+		HIPCHK(c, hipMemcpy(dr, rel.data(), rel.size() * 4, hipMemcpyHostToDevice));
+		S.rel = (const float4*)dr;
+	}
 	HIPCHK(c, dalloc(c->sceneAllocs, &dp, prims.size() + 16));
 	HIPCHK(c, hipMemcpy(dp, prims.data(), prims.size() * 4, hipMemcpyHostToDevice));
 	S.prims = (const float4*)dp;
@@ -1139,6 +1171,7 @@ int rt_set_time(rt_ctx* c, float t)
 	if (c->S.useTLAS) return fail(c, RT_E_UNSUPPORTED, "rt_set_time: the reference animates only without the TLAS (animOn, template/scene.h:1389)");
 	if (!c->primsOrig) return RT_OK; // nothing to animate
 	c->S.wide8 = nullptr; // the quantised boxes were rounded around the uploaded geometry: a refitted tree is walked through the exact nodes
+	c->S.rel = nullptr;   // the relative records describe the uploaded boxes: a refitted tree is walked through its 64-byte records
 	HIPCHK(c, hipSetDevice(c->device));
 	// float r = fmodf(t, 2 * PI); float a = sinf(r) * 0.5f;  (template/scene.h:1229-1230; sinf in f64, rounded once)
 	const float r = fmodf(t, 2 * RT_PI);
@@ -1872,27 +1905,33 @@ int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int 
 	if (row_first < 0 || row_stride < 1 || row_count < 1 || row_first + (row_count - 1) * row_stride >= dst->height)
 		return fail(dst, RT_E_ARG, "rt_gather_rows: rows %d + k*%d (k < %d) outside 0..%d", row_first, row_stride, row_count, dst->height);
 	if (dst == src) return RT_OK;
-	// the rows must be complete before they are copied
-	HIPCHK(dst, hipSetDevice(src->device));
-	HIPCHK(dst, hipStreamSynchronize(src->stream));
-	HIPCHK(dst, hipSetDevice(dst->device));
+	// (errors from here on are reported on SRC: the call may come from the source context's host thread while another thread
+	// drives dst)
+	// A PUSH on the source's stream: the copy follows the source's rendering in stream order (no host wait), every source
+	// context pushes over its own link to the destination at the same time (xGMI is point to point), and the destination's
+	// stream waits for the source's event -- what it does next (resolve, the next frame) sees the rows.
+	HIPCHK(src, hipSetDevice(src->device));
 	const size_t rowBytes = (size_t)dst->width * sizeof(float4), pitch = rowBytes * (size_t)row_stride;
 	const float4* from = src->accum + (size_t)row_first * src->width;
 	float4* to = dst->accum + (size_t)row_first * dst->width;
 	bool direct = dst->device == src->device;
 	if (!direct) {
-		// peer access dst <- src: one strided copy engine transfer over the link between the two GPUs
+		// peer access src -> dst: one strided copy engine transfer over the link between the two GPUs
 		int can = 0;
-		if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
-			const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+		if (hipDeviceCanAccessPeer(&can, src->device, dst->device) == hipSuccess && can) {
+			const hipError_t e = hipDeviceEnablePeerAccess(dst->device, 0);
 			direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
 			(void)hipGetLastError();
 		}
 	}
-	if (direct) HIPCHK(dst, hipMemcpy2DAsync(to, pitch, from, pitch, rowBytes, (size_t)row_count, hipMemcpyDeviceToDevice, dst->stream));
+	if (direct) HIPCHK(src, hipMemcpy2DAsync(to, pitch, from, pitch, rowBytes, (size_t)row_count, hipMemcpyDeviceToDevice, src->stream));
 	else
 		for (int k = 0; k < row_count; k++)
-			HIPCHK(dst, hipMemcpyPeerAsync((char*)to + (size_t)k * pitch, dst->device, (const char*)from + (size_t)k * pitch, src->device, rowBytes, dst->stream));
+			HIPCHK(src, hipMemcpyPeerAsync((char*)to + (size_t)k * pitch, dst->device, (const char*)from + (size_t)k * pitch, src->device, rowBytes, src->stream));
+	if (!src->gatherDone) HIPCHK(src, hipEventCreateWithFlags(&src->gatherDone, hipEventDisableTiming));
+	HIPCHK(src, hipEventRecord(src->gatherDone, src->stream));
+	HIPCHK(src, hipSetDevice(dst->device));
+	HIPCHK(src, hipStreamWaitEvent(dst->stream, src->gatherDone, 0));
 	return RT_OK;
 }
 
@@ -2206,9 +2245,9 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d pair32=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->fuseTraversal, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->drainLanes, c->drainLanesAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
+	         c->pairAgain, c->pairAgainAny, c->drainLanes, c->drainLanesAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->S.rel ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();

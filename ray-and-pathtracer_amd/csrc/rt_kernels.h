@@ -184,14 +184,27 @@ __device__ __forceinline__ f3 sky_color(const DScene& S, const f3& D)
 	if (!p) return f3(0.0f);
 	return f3((float)p[0], (float)p[1], (float)p[2]) / 255;
 }
-// The gamma itself is the device library's single-precision powf (round 4; the reference's expression is a double-precision
-// pow rounded to float, which is what this was until round 3: 200 M double-precision pow per bench step, 1.45 ms of k_accumulate).
-// It is an OUTPUT transform: its value goes into the accumulator and nowhere else -- no ray, no texel index, no random draw
-// depends on it, so no hit id can move.  Error against the rounded double-precision value: <= 2 ulp (2.4e-7 relative; measured
-// on the 256 sky values: tests/test_gpu_parity.py::test_gamma_of_finished_samples), 400 x inside the 1e-4 radiance bar.  ONE
-// function everywhere a finished sample is made (here, k_accumulate, k_gamma_lut), so the knobs that move the gamma between
-// kernels still give identical bits.
-__device__ __forceinline__ float gamma_powf(float x) { return powf(x, RT_GAMMA); }
+// The gamma itself is evaluated in single precision (round 4; the reference's expression is a double-precision pow rounded to
+// float, which is what this was until round 3: 200 M double-precision pow per bench step, 1.45 ms of k_accumulate; the device
+// library's powf: 1.0 ms).  It is an OUTPUT transform: its value goes into the accumulator and nowhere else -- no ray, no texel
+// index, no random draw depends on it, so no hit id can move.  x^g = 2^(g log2 x) on the hardware's log2 / exp2 (1 ulp each)
+// with the two roundings that would be amplified by the exponent's size repaired: the rounding of log2 x from x / 2^l0 = 1 + d
+// (log2(1 + d) = d log2 e to first order, d ~ 1e-6), the rounding of g * l0 by an fma; the result is 2^t_hi * (1 + ln 2 * t_lo).
+// Error against the rounded double-precision value: <= 4 ulp with every hardware result a full ulp off the worst way (4.8e-7 relative:
+// 200 x inside the 1e-4 radiance bar), 1.5 ulp with correctly rounded ones (profiles/r04_gamma_error.txt); measured
+// <= 2 on the 256 sky values: tests/test_gpu_parity.py::test_gamma_of_finished_samples).  Values outside [1e-30, 1e30] -- zero,
+// negatives, NaN, inf (a directly viewed light, Q7), denormals -- take the library's powf.  ONE function everywhere a finished
+// sample is made (here, k_accumulate, k_gamma_lut), so the knobs that move the gamma between kernels still give identical bits.
+__device__ __forceinline__ float gamma_powf(float x)
+{
+	if (!(x >= 1e-30f && x <= 1e30f)) return powf(x, RT_GAMMA);
+	const float l0 = __builtin_amdgcn_logf(x);                       // log2 x, rounded
+	const float d = __builtin_fmaf(x, __builtin_amdgcn_exp2f(-l0), -1.0f); // x / 2^l0 - 1
+	const float tHi = RT_GAMMA * l0;
+	const float tLo = __builtin_fmaf(RT_GAMMA, l0, -tHi) + RT_GAMMA * (d * 1.4426950408889634f);
+	const float p = __builtin_amdgcn_exp2f(tHi);
+	return __builtin_fmaf(p, tLo * 0.6931471805599453f, p);
+}
 // gammaLut[b] = the finished path-mode sample of radiance b / 255 (store_sample: pow(c, GAMMA) per channel, renderer.cpp:279-282)
 __global__ void k_gamma_lut(float* lut)
 {

@@ -8,6 +8,8 @@ is read-only, so every rank holds a full copy of the scene and renders rows rank
 the final framebuffer gather: W*H*16 B * (world-1)/world into rank 0, e.g. 29 MB at 1080p / 8 ranks.
 xGMI is point to point, so a gather to one rank uses all of that rank's links at once; no ring.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -66,21 +68,31 @@ def gather_rows(acc, rank, world, dst=0):
     return RowShard(acc.shape[0], acc.shape[1], rank, world, acc.device, dst, acc.dtype).gather(acc)
 
 
-def render_step(renderer, acc, mode, frame0, frames, shard, host_staging=None):
+def render_step(renderer, acc, mode, frame0, frames, shard, host_staging=None, timing=None):
     """One bench / Tick step of a rank: render the shard's rows into acc (the tensor bound as the renderer's accumulator),
     then gather them to the destination rank.  'renderer' is host_api.HostRenderer (render_rows -> rt_render_rows,
     synchronize -> rt_synchronize) or anything with those two methods.  host_staging: a pinned-size CPU tensor for the
-    gloo rehearsal mode (ranks share a GPU, the gather goes through host memory); its RowShard is host_staging[1]."""
+    gloo rehearsal mode (ranks share a GPU, the gather goes through host memory); its RowShard is host_staging[1].
+    timing: a dict that accumulates 'render_s' (until this rank's rows are complete) and 'gather_s' (from there until the
+    gather has completed on this rank: it includes the wait for the slowest rank) -- with several ranks the split is what
+    tells a slow share from a slow exchange."""
+    t0 = time.perf_counter()
     first, stride, count = shard.rows()
     if count > 0:
         renderer.render_rows(mode, frame0, frames, first, stride, count)
     renderer.synchronize()
+    t1 = time.perf_counter()
     if host_staging is None:
         shard.gather(acc)
+        if timing is not None and shard.world > 1 and acc.is_cuda:
+            torch.cuda.synchronize(acc.device)  # the collective is asynchronous on the device: its end is what is timed
     else:
         host, host_shard = host_staging
         host.copy_(acc)
         host_shard.gather(host)
         if shard.rank == shard.dst:
             acc.copy_(host)
+    if timing is not None:
+        timing["render_s"] = timing.get("render_s", 0.0) + (t1 - t0)
+        timing["gather_s"] = timing.get("gather_s", 0.0) + (time.perf_counter() - t1)
     return acc

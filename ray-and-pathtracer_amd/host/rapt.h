@@ -384,6 +384,9 @@ public:
 	uint32_t frame = 0;
 	bool downloadEachTick = true;
 	void SyncCamera();
+private:
+	struct Workers;                   // one parked host thread per context (several contexts only)
+	Workers* workers = nullptr;
 };
 
 } // namespace rapt

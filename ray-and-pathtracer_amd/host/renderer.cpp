@@ -2,12 +2,63 @@
 // reference's signatures.  The pixel loop of Tick (renderer.cpp:259-291) is one rt_render() +
 // rt_resolve() pair on the device; Trace and Sample evaluate a caller-supplied ray there too.
 #include "rapt.h"
+#include <condition_variable>
 #include <exception>
+#include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 #include <vector>
 
 namespace rapt {
+
+// One host thread per context, started once and parked on a condition variable between Ticks (a context is not thread safe,
+// and each thread binds its context's device once): the scanline loop of renderer.cpp:259 with one interleaved share of the rows
+// per GPU.  Round 3 spawned and joined N std::threads in every Tick.
+struct Renderer::Workers {
+	struct Slot { std::thread th; std::function<void()> job; bool busy = false; std::exception_ptr err; };
+	std::vector<Slot> slots;
+	std::mutex m;
+	std::condition_variable wake, done;
+	bool quit = false;
+	explicit Workers(int n) : slots((size_t)n)
+	{
+		for (int k = 0; k < n; k++)
+			slots[(size_t)k].th = std::thread([this, k]() {
+				Slot& s = slots[(size_t)k];
+				std::unique_lock<std::mutex> lk(m);
+				for (;;) {
+					wake.wait(lk, [&]() { return quit || s.busy; });
+					if (quit) return;
+					std::function<void()> job = s.job;
+					lk.unlock();
+					std::exception_ptr e;
+					try { job(); } catch (...) { e = std::current_exception(); }
+					lk.lock();
+					s.err = e, s.busy = false;
+					done.notify_all();
+				}
+			});
+	}
+	~Workers()
+	{
+		{ std::lock_guard<std::mutex> lk(m); quit = true; }
+		wake.notify_all();
+		for (Slot& s : slots) s.th.join();
+	}
+	// run job(k) on worker k for every k, wait for all, rethrow the first failure
+	void run(const std::function<void(int)>& job)
+	{
+		{
+			std::lock_guard<std::mutex> lk(m);
+			for (size_t k = 0; k < slots.size(); k++) slots[k].job = [&job, k]() { job((int)k); }, slots[k].busy = true, slots[k].err = nullptr;
+		}
+		wake.notify_all();
+		std::unique_lock<std::mutex> lk(m);
+		done.wait(lk, [&]() { for (const Slot& s : slots) if (s.busy) return false; return true; });
+		for (Slot& s : slots) if (s.err) std::rethrow_exception(s.err);
+	}
+};
 
 static void check(rt_ctx* ctx, int rc)
 {
@@ -41,6 +92,7 @@ void Renderer::Init() // renderer.cpp:5-11: allocate and zero the float4 accumul
 		ctxs.push_back(c);
 	}
 	ctx = ctxs[0];
+	if (ctxs.size() > 1) workers = new Workers((int)ctxs.size());
 	accumulator = new float4[(size_t)width * height]();
 	screenPixels = new uint32_t[(size_t)width * height];
 	memset(screenPixels, 0, 4 * (size_t)width * height);
@@ -49,6 +101,8 @@ void Renderer::Init() // renderer.cpp:5-11: allocate and zero the float4 accumul
 
 void Renderer::Shutdown()
 {
+	delete workers;
+	workers = nullptr;
 	for (rt_ctx* c : ctxs) rt_destroy(c);
 	ctxs.clear();
 	ctx = nullptr;
@@ -95,26 +149,15 @@ void Renderer::Tick(float /*deltaTime*/)
 	const int n = (int)ctxs.size();
 	if (n == 1) check(ctx, rt_render(ctx, mode, frame, 1, seedBase, 0, height, 4));
 	else {
-		// the scanline loop of renderer.cpp:259, one interleaved share of the rows per GPU: one host thread per context
-		// (a context is not thread safe, and each thread binds its context's device)
-		std::vector<std::exception_ptr> errs((size_t)n);
-		std::vector<std::thread> pool;
-		for (int k = 0; k < n; k++)
-			pool.emplace_back([&, k]() {
-				try {
-					const int count = (height - k + n - 1) / n;
-					if (count > 0) {
-						check(ctxs[k], rt_render_rows(ctxs[k], mode, frame, 1, seedBase, k, n, count, 4));
-						check(ctxs[k], rt_synchronize(ctxs[k]));
-					}
-				} catch (...) { errs[(size_t)k] = std::current_exception(); }
-			});
-		for (auto& t : pool) t.join();
-		for (auto& e : errs) if (e) std::rethrow_exception(e);
-		for (int k = 1; k < n; k++) {
+		// the scanline loop of renderer.cpp:259, one interleaved share of the rows per GPU, each on its context's own (parked)
+		// host thread; a share's rows are pushed to context 0 from that thread as soon as they are queued -- every gather is
+		// issued before anything waits (rt_gather_rows is asynchronous: context 0's stream waits for the rows, not the host)
+		workers->run([&](int k) {
 			const int count = (height - k + n - 1) / n;
-			if (count > 0) check(ctx, rt_gather_rows(ctx, ctxs[k], k, n, count));
-		}
+			if (count <= 0) return;
+			check(ctxs[k], rt_render_rows(ctxs[k], mode, frame, 1, seedBase, k, n, count, 4));
+			if (k > 0) check(ctxs[k], rt_gather_rows(ctx, ctxs[k], k, n, count)); // (its errors are reported on the source context)
+		});
 	}
 	if (!scene.raytracer && qlearning) {
 		// learning happens between frames: add the contexts' pending (integer) reward sums, give every context the total, apply

@@ -180,6 +180,19 @@ def config4(b):
     return d
 
 
+def terrain_scene(b, n=2048, rt=True):
+    """The out-of-cache profile scene (profiles/out_of_cache.py; not a BASELINE configuration): assets.terrain(n) -- 2 n^2 triangles,
+    8.4 M at the default -- as one diffuse mesh under the synthetic sky and one area light, one scene BVH (binned SAH), the camera
+    above a corner looking across the whole field."""
+    b.sky(assets.synthetic_sky(seed=3))
+    ground = b.diffuse(0.8, WHITE, 0.2, 0.8, 4, rt=rt)
+    b.area_light(11, (0.0, 40.0, 0.0), 600.0, WHITE, 4.0, (0, -1, 0))
+    b.mesh_raw(1, ground, assets.terrain(n))
+    b.build(BINNEDSAH)
+    cam = dict(cam_pos=(-30.0, 14.0, -30.0), top_left=(-29.7073, 14.4434, -27.1932), top_right=(-27.1932, 14.4434, -29.7073), bottom_left=(-30.0764, 12.5127, -27.5623))  # looks at (4, 1, 4), 16:9, screen at distance 2
+    return dict(name="terrain", tlas=False, camera=cam, triangles=2 * n * n)
+
+
 def bigb_instanced(b, n=16, rt=True, mesh="BigB"):
     """BASELINE config 5: BigB.obj (11,830 triangles) instanced n times on a grid through
     bvhInstance/TLAS, transforms Translate*Scale*RotateY as in TLASSceneTest2
@@ -248,6 +261,27 @@ def mixed_small(b, rt=True, split=BINNEDSAH):
     b.plane(0, fl, (0, 1, 0), 0)
     b.build(split)
     return dict(name="mixed_small", tlas=False)
+
+
+def qlearn_probe(b, rt=True):
+    """mixed_small lit by the sky and two DirectionalLights instead of its area lights.  No ray can hit a DirectionalLight
+    (AreaLight::Intersect is the only light test, template/scene.h:105-120), so no path value is ever +inf (Q7) and the
+    linear-radiance mean of Sample() is well defined: the scene of the Q-learning sampler's unbiasedness test."""
+    b.sky(assets.synthetic_sky(64, 32, seed=4))
+    b.dir_light(11, (5, 3, -1), 6.0, WHITE, (-1, -1, 1), 1)
+    b.dir_light(12, (-4, 5, 2), 3.0, WHITE, (1, -1, -0.5), 1)
+    gl = b.glass(1.5, BABYBLUE, (0.1, 0.2, 0.05), rt=rt)
+    me = b.metal(0.7, GOLD, rt=rt)
+    df = b.diffuse(0.8, GREEN, 0.6, 0.4, 10, rt=rt)
+    fl = b.diffuse(0.8, WHITE, 0.0, 1.0, 4, rt=rt)
+    b.mesh_obj(1, assets.obj_path("ico"), gl, (-0.9, 0.6, 0.6), 0.5)
+    b.mesh_obj(2, assets.obj_path("stellatedDode"), me, (0.9, 0.7, 0.8), 0.5)
+    b.mesh_obj(3, assets.obj_path("three"), df, (0.0, 0.5, 1.8), 1.2)
+    b.sphere(1, gl, (0.2, 0.35, 0.2), 0.35)
+    b.sphere(2, me, (-0.5, 0.25, -0.3), 0.25)
+    b.plane(0, fl, (0, 1, 0), 0)
+    b.build(BINNEDSAH)
+    return dict(name="qlearn_probe", tlas=False)
 
 
 # ---- the remaining factories of template/scene.h:791-1209, as data (SURVEY.md 8f N2) -----------------------------------
@@ -486,6 +520,8 @@ def scene7(b, rt=True, split=BINNEDSAH, nx=255, ny=255):
 
 
 REGISTRY = {
+    "terrain": terrain_scene,
+    "qlearn_probe": qlearn_probe,
     "config1": config1, "config2": config2, "config3": config3, "config4": config4, "config5": config5,
     "background": background_scene, "scene3": scene3, "pretty_tlas": pretty_tlas, "tower": tower_scene,
     "bigb_instanced": bigb_instanced, "tlas_test2": tlas_test2, "mixed_small": mixed_small,
