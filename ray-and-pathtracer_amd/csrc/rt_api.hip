@@ -467,10 +467,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		}
 	}
 
-	// pairs + prims of every BLAS, concatenated; rel: the 32-byte parent-relative form of every BLAS pair (rt_scene_dev.h rel[]),
-	// all or nothing: relOK falls when a parent's box plane is not bit for bit one of its children's, or a link needs bits 26-28
-	std::vector<float> pairs, prims, rel;
-	bool relOK = RT_PAIR32 && !(getenv("RT_PAIR32") && atoi(getenv("RT_PAIR32")) == 0);
+	// pairs + prims of every BLAS, concatenated
+	std::vector<float> pairs, prims;
 	std::vector<uint> rootLink(d->n_blas), pairOffOf(d->n_blas);
 	for (uint k = 0; k < d->n_blas; k++) {
 		const rt_blas& b = d->blas[k];
@@ -507,7 +505,6 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 		}
 		rootLink[k] = b.n_prims == 0 ? RT_EMPTY : link_of(0);
 		pairs.resize(pairs.size() + (size_t)(b.nodes_used / 2) * 16, 0.0f);
-		rel.resize(rel.size() + (size_t)(b.nodes_used / 2) * 8, 0.0f);
 		for (uint i = 2; i + 1 < b.nodes_used + 0u && b.n_prims > 0; i += 2) {
 			float* rec = &pairs[(size_t)(pairOff + i / 2) * 16];
 			for (int s = 0; s < 2; s++) {
@@ -516,26 +513,6 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 				memcpy(rec + 8 * s, nd.aabb_min, 12), memcpy(rec + 8 * s + 3, &lk, 4);
 				memcpy(rec + 8 * s + 4, nd.aabb_max, 12);
 			}
-		}
-		// the same pairs relative to their parent (the inner node whose left_first names the pair)
-		for (uint pi = 0; pi < b.nodes_used && b.n_prims > 0 && relOK; pi++) {
-			if (pi == 1 || b.nodes[pi].prim_count > 0) continue;
-			const rt_bvh_node& par = b.nodes[pi];
-			const uint i = par.left_first;
-			const rt_bvh_node &A = b.nodes[i], &B = b.nodes[i + 1];
-			uint la = link_of(i), lb = link_of(i + 1);
-			if (((la | lb) & (7u << 26)) != 0) { relOK = false; break; } // (the leaf / instance flags sit above bit 28)
-			float* rr = &rel[(size_t)(pairOff + i / 2) * 8];
-			for (int k = 0; k < 6 && relOK; k++) {
-				const float pa = k < 3 ? par.aabb_min[k] : par.aabb_max[k - 3], a = k < 3 ? A.aabb_min[k] : A.aabb_max[k - 3], bb = k < 3 ? B.aabb_min[k] : B.aabb_max[k - 3];
-				uint pu, au, bu;
-				memcpy(&pu, &pa, 4), memcpy(&au, &a, 4), memcpy(&bu, &bb, 4);
-				uint& word = k < 3 ? la : lb;
-				if (au == pu) rr[k] = bb;                                  // A carries the parent's value, B's is explicit: bit clear
-				else if (bu == pu) rr[k] = a, word |= 1u << (26 + k % 3);  // B carries the parent's value, A's is explicit: bit set
-				else relOK = false;
-			}
-			memcpy(rr + 6, &la, 4), memcpy(rr + 7, &lb, 4);
 		}
 		prims.resize(prims.size() + (size_t)b.n_prims * 16);
 		for (uint j = 0; j < b.n_prims; j++) {
@@ -753,13 +730,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene_desc* d)
 	HIPCHK(c, dalloc(c->sceneAllocs, &dp, pairs.size() + 16));
 	HIPCHK(c, hipMemcpy(dp, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
 	S.pairs = (const float4*)dp;
-	S.rel = nullptr;
-	if (relOK && !rel.empty()) {
-		float* dr = nullptr;
-		HIPCHK(c, dalloc(c->sceneAllocs, &dr, rel.size() + 8));
-		HIPCHK(c, hipMemcpy(dr, rel.data(), rel.size() * 4, hipMemcpyHostToDevice));
-		S.rel = (const float4*)dr;
-	}
+
 	HIPCHK(c, dalloc(c->sceneAllocs, &dp, prims.size() + 16));
 	HIPCHK(c, hipMemcpy(dp, prims.data(), prims.size() * 4, hipMemcpyHostToDevice));
 	S.prims = (const float4*)dp;
@@ -1171,7 +1142,6 @@ int rt_set_time(rt_ctx* c, float t)
 	if (c->S.useTLAS) return fail(c, RT_E_UNSUPPORTED, "rt_set_time: the reference animates only without the TLAS (animOn, template/scene.h:1389)");
 	if (!c->primsOrig) return RT_OK; // nothing to animate
 	c->S.wide8 = nullptr; // the quantised boxes were rounded around the uploaded geometry: a refitted tree is walked through the exact nodes
-	c->S.rel = nullptr;   // the relative records describe the uploaded boxes: a refitted tree is walked through its 64-byte records
 	HIPCHK(c, hipSetDevice(c->device));
 	// float r = fmodf(t, 2 * PI); float a = sinf(r) * 0.5f;  (template/scene.h:1229-1230; sinf in f64, rounded once)
 	const float r = fmodf(t, 2 * RT_PI);
@@ -2245,9 +2215,9 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d pair32=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->fuseTraversal, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->drainLanes, c->drainLanesAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->S.rel ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
+	         c->pairAgain, c->pairAgainAny, c->drainLanes, c->drainLanesAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();

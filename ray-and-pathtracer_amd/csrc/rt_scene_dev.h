@@ -33,16 +33,6 @@
 //            rule for equal t is untouched and results are identical.  Counting launches either walk like
 //            the reference (no culling: the counters are the reference's tallies) or like the timed
 //            kernels (RT_TUNE_CULL_COUNTED: the counters are the work actually done).
-//   rel[]    one 32-byte record per BLAS pair, beside pairs[] (same index): the same two child boxes and links, RELATIVE to the parent's
-//            box.  A parent's box is the union of its children's (bvh::UpdateNodeBounds takes min / max over the node's primitives,
-//            bvh.cpp:96-114, and so does Refit), so for each of the six box planes one child's coordinate IS the parent's, bit for
-//            bit (checked at upload; a tree where it is not keeps rel null): the record holds the OTHER child's coordinate per plane
-//            and one bit per plane saying which child that is -- {e_min.xyz, e_max.x}{e_max.yz, linkA | bits 26-28: planes min.xyz,
-//            linkB | bits 26-28: planes max.xyz}; a set bit = child A carries the explicit value, child B the parent's.  A lane
-//            that DESCENDS into an inner node has just computed that node's box and keeps it (six registers); the next pair step
-//            decodes the children's boxes from rel[] -- two lane accesses on the vector-memory path instead of four, the same
-//            floats.  A lane that POPS a node has no box: it reads the 64-byte pairs[] record as before.  (DESIGN.md finding 53:
-//            the traversal is short of bytes per visit on that path.)
 //   wide[]   4-wide nodes for occlusion queries (the reference's own 4-wide variant is bvh.cpp:335-512,
 //            :658-761).  One 128-byte record = one cache line: {min.x[4]}{min.y[4]}{min.z[4]}{max.x[4]}{max.y[4]}{max.z[4]}
 //            {link[4]}{source[4]}; built at upload by collapsing the reference's binary tree (a node's children are
@@ -137,7 +127,6 @@ struct DScene {
 	const DInstance* inst;
 	const float4* brute; // TLAS mode: spheres then planes, prim-record format
 	const float4* reach; // TLAS mode: per TLAS pair, the boxes its children's geometry can actually occupy (see below)
-	const float4* rel;   // 32-byte parent-relative pair records, beside pairs[] (see below); null: every visit reads the 64-byte record
 	const float4* wide;  // 4-wide nodes of every BLAS (any-hit queries of clean rays), 128-byte records; null when a tree is not nested
 	uint rootWide;       // scene BVH root through the wide nodes (unused in TLAS mode: instances carry theirs)
 	const uint4* wide8;  // 8-wide nodes with quantised child boxes (any-hit queries of clean rays), 128-byte records, see below; null: not built
@@ -297,10 +286,6 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // drain per round instead of two (a launch ends when its longest ray does, several hundred microseconds after the
 // queue ran dry, whatever the queue held).
 #define RT_INST_BIT 0x40000000u // link names an instance (TLAS leaf)
-#define RT_REL_BIT 0x10000000u  // a lane's link only, never stored: the node was reached by a descent, its box is in the lane's registers (rel[])
-#ifndef RT_PAIR32
-#define RT_PAIR32 0 // 1: the 32-byte parent-relative pair records for descents (rel[]) are compiled in (RT_PAIR32=0 in the environment still switches them off)
-#endif
 #define RT_BOX_BIT 0x20000000u  // 8-wide walk: link names a leafBox[] record (the leaf's exact box is tested before its primitives)
 #define RT_LINK_EXIT 0xFFFFFFFCu // leave the current instance (the sentinel was popped)
 #define RT_LINK_DONE 0xFFFFFFFBu // this ray is finished; its result is written at the next refill
@@ -456,7 +441,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	int inst = -1;
 	bool laneAny = ANY;  // MIXED: this lane's work item is an occlusion query
 	bool clean = false; // the current (world or object space) ray cannot produce a NaN slab product
-	f3 boxLo(0.0f), boxHi(0.0f); // RT_PAIR32: the box of the node 'link' names when RT_REL_BIT is set in it
 
 	// next node for this lane: pop the stack; an empty stack ends the ray, the sentinel leaves the instance
 	auto pop_next = [&]() __attribute__((always_inline)) {
