@@ -10,7 +10,7 @@ for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     pas = f.split(os.sep)[-3]
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "rtd::" not in k or "<true" in k:
+        if "rtd::" not in k or ("<true" in k and "k_shade_s" not in k):  # "<true": the counting variants -- except k_shade_s<QL>, the Q-learning sampler's kernel
             continue
         k = k.split("rtd::")[1].split("(")[0]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -94,7 +94,6 @@ struct rt_ctx {
 	std::vector<void*> qAllocs;
 	int shadeLds = 1;        // RT_SHADE_LDS: the shading kernels keep the material / brute-force primitive tables in LDS
 	int gridShadeS = 0, gridLightS = 0; // resident blocks of the grid-stride shading kernels (a second, partial round of blocks would run at low occupancy)
-	int orderQueue = 0;      // RT_ORDER: the traversal queue grouped by ray key inside 1024-entry tiles (k_compact_keyed_s)
 	int decideRays = 1;      // RT_DECIDE: producers answer rays whose first traversal step leaves nothing to visit (rt_stream.h ray_decided)
 	int gridTraverseS = 0;
 	int gridExtendS = 0, gridConnectS = 0, gridConnectWideS = 0, gridLeftoverS = 0, gridConnectWide8S = 0;
@@ -292,7 +291,6 @@ rt_ctx* rt_create(int device, int width, int height)
 	memset(&c->slot.P, 0, sizeof(PathState)), memset(&c->slot.Q, 0, sizeof(Queues));
 	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0 one kernel at a time, 1 one traversal launch per round, 2 connect + light on a second stream; negative: the default by batch size
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
-	if (getenv("RT_ORDER")) c->orderQueue = atoi(getenv("RT_ORDER")) != 0;
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
 	if (getenv("RT_MEGA_LPT")) c->megaLpt = atoi(getenv("RT_MEGA_LPT")) != 0;
@@ -1593,8 +1591,7 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	bool pendingJoin = false;
 	for (int round = 0; round < rounds; round++) {
 		const int last = round + 1 == rounds ? 1 : 0, lastNext = round + 2 == rounds ? 1 : 0;
-		if (c->orderQueue) hipLaunchKernelGGL(k_compact_keyed_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
-		else hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
+		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 #ifdef RT_TAIL_PROBE
 		tail_probe_reset(st);
 #endif

@@ -325,85 +325,6 @@ __device__ __forceinline__ void compact_body(const unsigned char* status, int nS
 		base += n;
 	}
 }
-// The same with the selected entries of every 1024-entry tile GROUPED by the key in bits 4-7 of their status byte (a counting sort
-// inside the wave: 16 LDS counters, two passes of LDS atomics): consecutive queue entries then hold rays of one key.  The order
-// inside a group is whatever the atomics make it -- a ray's result does not depend on its place in the queue.
-__device__ __forceinline__ void compact_body_keyed(const unsigned char* status, int nSlots, int bit, uint* queue, int* count)
-{
-	__shared__ int waveTotal[RT_COMPACT_BLOCK / 64];
-	__shared__ int blockBase;
-	__shared__ uint stage[RT_COMPACT_BLOCK / 64][1024];
-	__shared__ uint keyCount[RT_COMPACT_BLOCK / 64][16];
-	const uint lane = threadIdx.x & 63;
-	const uint bits = (uint)bit * 0x01010101u;
-	const int waves = (gridDim.x * blockDim.x) >> 6;
-	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	int per = (nSlots + waves - 1) / waves;
-	per = (per + 1023) & ~1023;
-	const long long firstL = (long long)wave * per;
-	const int first = firstL < nSlots ? (int)firstL : nSlots;
-	const int last = firstL + per < nSlots ? (int)(firstL + per) : nSlots;
-	int mine = 0;
-	for (int s0 = first; s0 < last; s0 += 1024) {
-		const uint4 v = status16(status, s0 + (int)lane * 16, last, bits);
-		mine += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-	}
-	int total = mine;
-	for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-	const int wib = threadIdx.x >> 6;
-	if (lane == 0) waveTotal[wib] = total;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		int sum = 0;
-		for (int w = 0; w < RT_COMPACT_BLOCK / 64; w++) sum += waveTotal[w];
-		blockBase = sum > 0 ? atomicAdd(count, sum) : 0;
-	}
-	__syncthreads();
-	int base = blockBase;
-	for (int w = 0; w < wib; w++) base += waveTotal[w];
-	if (total == 0) return;
-	uint* mystage = stage[wib];
-	uint* kc = keyCount[wib];
-	for (int s0 = first; s0 < last; s0 += 1024) {
-		const int slot0 = s0 + (int)lane * 16;
-		// the raw status bytes too: the key rides in their high nibbles
-		uint4 raw = make_uint4(0, 0, 0, 0);
-		if (slot0 < last) raw = *(const uint4*)(status + slot0);
-		const uint4 v = status16(status, slot0, last, bits);
-		const int c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-		int incl = c;
-		for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
-		if (lane < 16) kc[lane] = 0;
-		__builtin_amdgcn_wave_barrier();
-		int at = incl - c;
-		const uint w[4] = { v.x, v.y, v.z, v.w }, rw[4] = { raw.x, raw.y, raw.z, raw.w };
-		for (int k = 0; k < 4; k++) {
-			uint x = w[k];
-			while (x) {
-				const int b = __ffs(x) - 1;
-				const uint key = (rw[k] >> ((b & ~7) + 4)) & 15u;
-				mystage[at++] = (uint)(slot0 + 4 * k + (b >> 3)) | (key << 28); // entry indices stay below 2^28 (the slot budget)
-				atomicAdd(&kc[key], 1u);
-				x &= x - 1;
-			}
-		}
-		const int n = __shfl(incl, 63);
-		__builtin_amdgcn_wave_barrier();
-		// exclusive scan of the 16 counts -> first position of every group
-		uint cnt = lane < 16 ? kc[lane] : 0u, inc = cnt;
-		for (int o = 1; o < 16; o <<= 1) { const uint t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
-		__builtin_amdgcn_wave_barrier();
-		if (lane < 16) kc[lane] = inc - cnt;
-		__builtin_amdgcn_wave_barrier();
-		for (int i = (int)lane; i < n; i += 64) {
-			const uint e = mystage[i];
-			const uint pos = atomicAdd(&kc[e >> 28], 1u);
-			queue[base + (int)pos] = e & 0x0FFFFFFFu;
-		}
-		__builtin_amdgcn_wave_barrier();
-		base += n;
-	}
-}
 __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact(PathState P, int bit, uint* queue, int* count)
 {
 	compact_body(P.status, P.nSlots, bit, queue, count);

@@ -91,12 +91,9 @@ __device__ __forceinline__ int hit_class(const DScene& S, int objIdx, int mat, i
 // Does the first step of the traversal already end it?  (trace_persistent: link = S.rootLink, one pair step, stack empty.)
 // Same operands, same tests: the reference's boxes with the clean / exact slab test, and at the TLAS level the reach
 // boxes under the same guard.  All loads are wave-uniform.
-// *key (optional): a 4-bit ordering key of a ray that does need the walk -- the octant of its direction and which child of the
-// root pair it reaches first (RT_ORDER, k_compact_keyed_s)
-__device__ __forceinline__ bool ray_decided(const DScene& S, const f3& O, const f3& D, float rayT, uint* key = nullptr)
+__device__ __forceinline__ bool ray_decided(const DScene& S, const f3& O, const f3& D, float rayT)
 {
 	const uint root = S.rootLink;
-	if (key) *key = (D.x < 0 ? 1u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 4u : 0u);
 	if (root == RT_EMPTY) return true;
 	if (root & (RT_LEAF_BIT | RT_INST_BIT)) return false; // a single leaf / a single instance: extend's business
 	const f3 rD = rcp3(D);
@@ -112,7 +109,6 @@ __device__ __forceinline__ bool ray_decided(const DScene& S, const f3& O, const 
 		if (!box_reachable(O, rD, rayT, xyz(r0), f3(r0.w, r1.x, r1.y))) dist1 = 1e30f;
 		if (!box_reachable(O, rD, rayT, f3(r1.z, r1.w, r2.x), f3(r2.y, r2.z, r2.w))) dist2 = 1e30f;
 	}
-	if (key && dist2 < dist1) *key |= 8u;
 	return dist1 == 1e30f && dist2 == 1e30f;
 }
 
@@ -129,8 +125,7 @@ __device__ __forceinline__ NewRay emit_ray_s(const DScene& S, const StreamState&
 	LaneCounters unused;
 	find_nearest_head<false>(S, O, D, t_min, rayT, head, unused);
 	r.cls = CL_LIVE | CL_TRACE, r.decided = false, r.t = rayT, r.objIdx = -1, r.mat = -1, r.normal = f3(0.0f);
-	uint key = 0;
-	if (decide && ray_decided(S, O, D, rayT, &key)) {
+	if (decide && ray_decided(S, O, D, rayT)) {
 		r.decided = true;
 		head.t = rayT;
 		int matType;
@@ -142,7 +137,6 @@ __device__ __forceinline__ NewRay emit_ray_s(const DScene& S, const StreamState&
 		T.hitId[p][e] = make_int2(r.objIdx, r.mat);
 		r.cls = (unsigned char)(CL_LIVE | hc);
 	}
-	r.cls |= (unsigned char)(key << 4); // the ordering key rides in the class byte's free high nibble (extend's flush overwrites it)
 	T.O[p][e] = mk4(O, rayT);
 	T.D[p][e] = mk4(D, __uint_as_float(pack_head(head)));
 	return r;
@@ -196,11 +190,6 @@ __global__ void k_stream_begin(StreamState T)
 __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact_s(StreamState T, int round)
 {
 	compact_body(T.cls[round & 1], T.counts[SC_N + round % 3], CL_TRACE, T.traceQ, &T.counts[SC_TRACE]);
-}
-// RT_ORDER=1: the traversal queue grouped by the rays' key (direction octant, nearer child of the root pair) inside tiles of 1024 entries
-__global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_compact_keyed_s(StreamState T, int round)
-{
-	compact_body_keyed(T.cls[round & 1], T.counts[SC_N + round % 3], CL_TRACE, T.traceQ, &T.counts[SC_TRACE]);
 }
 
 // generate: camera sample e of the batch (renderer.cpp:263-278) -> entry e of round 0.  A sample whose camera ray

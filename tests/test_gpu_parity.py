@@ -1126,9 +1126,9 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
     caller-supplied rays at every depth, and the same number of FindNearest / IsOccluded queries."""
     out, rays = {}, {}
     pO = pD = None
-    for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_two_streams", {"RT_FUSE": "2"}), ("stream_ordered_queue", {"RT_ORDER": "1"}), ("stream_ordered_queue_one_launch_per_round", {"RT_ORDER": "1", "RT_FUSE": "1"}), ("stream_one_launch_per_round", {"RT_FUSE": "1"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
+    for key, env in (("slot", {"RT_STREAM": "0"}), ("stream", {}), ("stream_serial", {"RT_FUSE": "0"}), ("stream_two_streams", {"RT_FUSE": "2"}), ("stream_one_launch_per_round", {"RT_FUSE": "1"}), ("stream_nodecide", {"RT_DECIDE": "0"}),
                      ("stream_gamma_at_the_store", {"RT_DEFER_GAMMA": "0"})):
-        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_DEFER_GAMMA", "RT_ORDER"):
+        for k in ("RT_STREAM", "RT_FUSE", "RT_DECIDE", "RT_DEFER_GAMMA"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1156,7 +1156,7 @@ def test_stream_pipeline_equals_slot_pipeline(name, kw, w, h, frames, scenes, or
                 pO, pD = pO[::7].copy(), pD[::7].copy()
             out[key + "_sample"] = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 99) for depth in (0, 1, 4)]
         r.close()
-    for key in ("stream", "stream_serial", "stream_two_streams", "stream_ordered_queue", "stream_ordered_queue_one_launch_per_round", "stream_one_launch_per_round", "stream_nodecide", "stream_gamma_at_the_store"):
+    for key in ("stream", "stream_serial", "stream_two_streams", "stream_one_launch_per_round", "stream_nodecide", "stream_gamma_at_the_store"):
         assert np.array_equal(out["slot"].view(np.uint32), out[key].view(np.uint32)), key
         assert rays[key] == rays["slot"], (key, rays[key], rays["slot"])
     for other in ("stream_sample",):
