@@ -25,7 +25,7 @@
 namespace rtd {
 
 #ifndef RT_EXTEND_WAVES
-#define RT_EXTEND_WAVES 7 // waves per SIMD the extend kernel is compiled for (launch bound)
+#define RT_EXTEND_WAVES 8 // waves per SIMD the extend kernel is compiled for (launch bound: 64 VGPRs; it needs exactly that since round 4, DESIGN.md finding 55)
 #endif
 #define RT_PEND_CAP 12 // pending Whitted branches per pixel (glass: <= 3 at depth 4; shiny diffuse: more)
 
@@ -686,7 +686,7 @@ struct ListedPolicy {
 	__device__ __forceinline__ void store(int i, bool occluded) const { base.store((int)list[i], occluded); }
 };
 #ifndef RT_CONNECT_WAVES
-#define RT_CONNECT_WAVES 7
+#define RT_CONNECT_WAVES 8
 #endif
 // WIDE: the 4-wide walk (needs S.wide); LISTED: the work items are Q.leftover[0 .. Q.counts[8])
 template <bool COUNT, bool WIDE = false, bool LISTED = false>
@@ -706,7 +706,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S
 }
 
 #ifndef RT_TRAVERSE_WAVES
-#define RT_TRAVERSE_WAVES 7 // k_traverse_s (rt_stream.h)
+#define RT_TRAVERSE_WAVES 8 // k_traverse_s (rt_stream.h)
 #endif
 // light: the direct-light terms of a diffuse hit, in light order.
 // Whitted (renderer.cpp:89-105): scatter first (energy changes even when occluded), then the

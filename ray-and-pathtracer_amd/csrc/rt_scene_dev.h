@@ -73,15 +73,16 @@ namespace rtd {
 #define RT_MAX_LIGHTS 32 // per-light planes of the path state are sized by the scene's own count; this bounds memory, nothing else
 
 #define RT_BLOCK 256
-// A traversal block's LDS (trace_persistent): 23,040 bytes, seven blocks = 28 waves per CU of the 160 KB.  Three parts,
+// A traversal block's LDS (trace_persistent): 20,480 bytes, eight blocks = 32 waves per CU of the 160 KB (seven blocks of 23,040
+// bytes until the kernels fitted 64 registers: round 4, profiles/r04_ab_eight_waves.txt).  Three parts,
 // split per scene (DScene::stackRows, set at upload):
 //   [0, rows)            the top 'rows' entries of every lane's traversal stack, [entry][lane]
 //   [rows, rows + 6)     the world-space ray of a lane that is inside an instance, [component][lane]
 //   the rest             the block's copy of the TLAS (pairs, reach records, instance transforms), when it fits
-// rows = 16 without a TLAS copy; a copy takes rows away down to RT_STACK_ROWS_MIN (the 16 instances of config 5: 13 rows;
+// rows = 14 without a TLAS copy; a copy takes rows away down to RT_STACK_ROWS_MIN (the bench scene's 8 instances: 12 rows; the 16 of config 5: 10;
 // measured there: 13 rows cost nothing, the copy takes 4 % off the frame set); a TLAS too large for that stays in global memory.
 #ifndef RT_LDS_WORDS
-#define RT_LDS_WORDS 5760 // 18 allocation granules of 320 words
+#define RT_LDS_WORDS 5120 // 20 KB: eight blocks = 32 waves per CU of the 160 KB
 #endif
 #define RT_STACK_ROWS_MAX 16
 #ifndef RT_STACK_ROWS_MIN
