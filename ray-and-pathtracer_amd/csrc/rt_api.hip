@@ -108,7 +108,7 @@ struct rt_ctx {
 	int stepMinAny = 8, pairAgainAny = 16; // the any-hit kernel's RT_STEPMIN / RT_PAIRAGAIN (RT_STEPMIN_ANY, RT_PAIRAGAIN_ANY)
 	int drainLanes = 64, drainLanesAny = 64; // RT_DRAIN_LANES / RT_DRAIN_LANES_ANY: once a wave's queue is dry, this many live lanes (1, 2, 4 .. 64; 0: never) leave the
 	                                       // scheduled state machine for the plain per-lane walk (trace_persistent "the drain")
-	int stepMinXform = 0; // RT_STEPMIN_XFORM: lanes that must want an instance entry / exit before it runs (0: the same as RT_STEPMIN)
+	int stepMinXform = 0; // lanes that must want an instance entry / exit before it runs (0: the same as RT_STEPMIN; swept in round 2: 4-6 neutral, less loses)
 	float* gammaLut = nullptr; // DScene::gammaLut
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
@@ -311,7 +311,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	{
 		// the persistent traversal kernels are launched with exactly the blocks a CU can hold (occupancy calculator, per
 		// kernel): a block that had to wait for a slot would find its share of the queue already taken
-		const int capBlocks = getenv("RT_TRAV_BLOCKS") ? atoi(getenv("RT_TRAV_BLOCKS")) : 8; // experiment: leave room on every CU for another stream's kernels
+		const int capBlocks = 8;
 		auto resident = [&](const void* fn) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, RT_BLOCK, 0) != hipSuccess || b < 1) b = 1; if (b > 8) b = 8; if (capBlocks >= 1 && b > capBlocks) b = capBlocks; return b * prop.multiProcessorCount; };
 		const int e0 = std::min(resident((const void*)k_extend<false, false>), resident((const void*)k_extend<false, true>)), e1 = std::min(resident((const void*)k_extend<true, false>), resident((const void*)k_extend<true, true>));
 		const int c0 = resident((const void*)k_connect<false>), c1 = resident((const void*)k_connect<true>);
@@ -326,8 +326,8 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridTraverseS = resident((const void*)k_traverse_s);
 		c->gridMega = resident((const void*)k_whitted_mega);
 		c->gridLevel = resident((const void*)k_whitted_level);
-		c->gridShadeS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : std::min(resident((const void*)k_shade_s<false>), resident((const void*)k_shade_s<true>));
-		c->gridLightS = getenv("RT_SHADE_GRID") ? atoi(getenv("RT_SHADE_GRID")) : resident((const void*)k_light_s);
+		c->gridShadeS = std::min(resident((const void*)k_shade_s<false>), resident((const void*)k_shade_s<true>));
+		c->gridLightS = resident((const void*)k_light_s);
 		int q = c->gridConnect < c->gridExtend ? c->gridConnect : c->gridExtend;
 		const void* qk[9] = { (const void*)k_query_nearest<false>, (const void*)k_query_nearest<true>, (const void*)k_query_occluded<false>, (const void*)k_query_occluded<true>, (const void*)k_primary_hits<false>, (const void*)k_primary_hits<true>,
 		                      (const void*)k_query_occluded<false, true>, (const void*)k_query_occluded<false, false, true>, (const void*)k_query_occluded<false, false, false, true> };
@@ -343,8 +343,6 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (c->pairAgain < 1 || c->pairAgain > 65) c->pairAgain = 16;
 	if (getenv("RT_DRAIN_LANES")) c->drainLanes = c->drainLanesAny = atoi(getenv("RT_DRAIN_LANES"));
 	if (getenv("RT_DRAIN_LANES_ANY")) c->drainLanesAny = atoi(getenv("RT_DRAIN_LANES_ANY"));
-	if (getenv("RT_STEPMIN_XFORM")) c->stepMinXform = atoi(getenv("RT_STEPMIN_XFORM"));
-	if (c->stepMinXform < 0 || c->stepMinXform > 15) c->stepMinXform = 0;
 	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 8; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8;
 	  c->stepMinAny = getenv("RT_STEPMIN_ANY") ? atoi(getenv("RT_STEPMIN_ANY")) : sm; if (c->stepMinAny < 0 || c->stepMinAny > 64) c->stepMinAny = sm;
 	  c->pairAgainAny = getenv("RT_PAIRAGAIN_ANY") ? atoi(getenv("RT_PAIRAGAIN_ANY")) : c->pairAgain; if (c->pairAgainAny < 1 || c->pairAgainAny > 65) c->pairAgainAny = c->pairAgain; }
@@ -1341,10 +1339,9 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 {
 	RenderParams R = R0;
 	// deal the frame out in tiles of 64 pixels from all over it (rt_mega.h sample_of): the multiplier nearest nTiles / 61 that is coprime to nTiles
-	if (R.nSamples >= 16384 && !(getenv("RT_MEGA_PERM") && atoi(getenv("RT_MEGA_PERM")) == 0)) {
+	if (R.nSamples >= 16384) {
 		auto gcd = [](unsigned a, unsigned b) { while (b) { const unsigned t = a % b; a = b; b = t; } return a; };
-		R.permShift = getenv("RT_MEGA_TILE") ? (unsigned)atoi(getenv("RT_MEGA_TILE")) : 3; // tiles of 8 pixels (profiles/r03_tick_mega.txt)
-		if (R.permShift > 8) R.permShift = 8;
+		R.permShift = 3; // tiles of 8 pixels (profiles/r03_tick_mega.txt: tile sizes 2^0 .. 2^6)
 		const unsigned nTiles = (R.nSamples + (1u << R.permShift) - 1) >> R.permShift;
 		unsigned p = nTiles / 61 | 1;
 		while (gcd(p, nTiles) != 1) p += 2;
@@ -1422,8 +1419,8 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 		M.cost = c->megaCost;
 		c->megaCostSamples = R.nSamples, c->megaCostFirst = R.sampleFirst;
 	}
-	// a flush runs the body of Trace for the lanes that finished a query: it waits for more of them than a plain store does (RT_REFILL_MEGA, 32: 5.0 -> 4.85 ms)
-	const int refillMega = getenv("RT_REFILL_MEGA") && atoi(getenv("RT_REFILL_MEGA")) > 0 && atoi(getenv("RT_REFILL_MEGA")) <= 64 ? atoi(getenv("RT_REFILL_MEGA")) : 32;
+	// a flush runs the body of Trace for the lanes that finished a query: it waits for more of them than a plain store does (32 instead of 16: 5.0 -> 4.85 ms)
+	const int refillMega = 32;
 	if (useLevels) {
 		bool redo = false;
 		const int rc = run_levels(c, R, M, grid, refillMega, &redo); // level 0 deals its tiles out like the single launch (M.order), and records what they cost

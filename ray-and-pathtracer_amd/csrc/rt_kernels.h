@@ -849,7 +849,7 @@ struct Suspended { // a DIFFUSE hit whose light loop is waiting for a shiny bran
 __global__ void __launch_bounds__(RT_BLOCK) k_sample_general(DScene S, DCamera C, RenderParams R, uint* spill, int* overflow)
 {
 	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
-	Stack st = make_stack(ldsStack, spill, overflow);
+	Stack st = make_stack(ldsStack, spill, overflow, RT_STACK_LDS);
 	for (uint sid = blockIdx.x * blockDim.x + threadIdx.x; sid < R.nSamples; sid += gridDim.x * blockDim.x) {
 		f3 O, D;
 		uint seed;

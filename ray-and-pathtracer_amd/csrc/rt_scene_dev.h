@@ -84,11 +84,13 @@ namespace rtd {
 #ifndef RT_LDS_WORDS
 #define RT_LDS_WORDS 5120 // 20 KB: eight blocks = 32 waves per CU of the 160 KB
 #endif
-#define RT_STACK_ROWS_MAX 16
+// stack rows without a TLAS copy: what the block's LDS holds beside the six world-ray rows (14 at 5120 words), at most 16
+#define RT_STACK_ROWS_MAX ((RT_LDS_WORDS / RT_BLOCK - 6) < 16 ? (RT_LDS_WORDS / RT_BLOCK - 6) : 16)
 #ifndef RT_STACK_ROWS_MIN
 #define RT_STACK_ROWS_MIN 8
 #endif
-#define RT_STACK_LDS RT_STACK_ROWS_MAX // kernels with a plain LDS stack (k_sample_general)
+#define RT_STACK_LDS 16 // kernels with a plain LDS stack of their own (k_sample_general)
+static_assert((RT_STACK_ROWS_MAX + 6) * RT_BLOCK <= RT_LDS_WORDS && RT_STACK_ROWS_MAX >= RT_STACK_ROWS_MIN, "a traversal block's LDS holds the stack rows and the six world-ray rows");
 // words of a TLAS copy: per pair 16 (boxes + links) + 12 (reach), per instance 12 (invT rows) + 1 (root link)
 #define RT_TLAS_COPY_WORDS(pairs, instances) ((pairs) * 28 + (instances) * 13)
 #define RT_STACK_MAX 130  // tlas::Intersect's stack[64] (tlas.cpp:67) + the instance sentinel + bvh::BIntersect's own stack[64]
