@@ -13,4 +13,5 @@ run _config2 --steps 10 --warmup 3 --workload config2 --no-cpu-baseline
 run _config4 --steps 5 --warmup 2 --workload config4 --no-cpu-baseline
 run _config5 --steps 2 --warmup 1 --workload config5 --no-cpu-baseline
 run _config5_qlearn --steps 2 --warmup 1 --workload config5 --qlearn 32 --no-cpu-baseline
+for r in 0 1 2 3 4 5 6 7; do run _emulate_world8_rank$r --steps 10 --warmup 3 --emulate-world 8 --emulate-rank $r --no-cpu-baseline; done
 run _config3_qlearn --steps 3 --warmup 1 --qlearn 8 --no-cpu-baseline

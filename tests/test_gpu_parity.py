@@ -196,6 +196,7 @@ RENDER_SCENES = [
     ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 128, 72),  # BASELINE config 5's layout with the small mesh
     ("bigb_instanced", {"n": 16, "mesh": "BigB"}, 192, 108),  # BASELINE config 5's scene itself (189,280 instanced triangles) at 1/20 size
     ("tower", {}, 192, 108),  # BASELINE config 4's scene (51,200-triangle stand-in for eifel.obj + synthetic sky) at 1/10 size
+    ("terrain", {"n": 160}, 160, 90),  # the out-of-cache profile's scene (profiles/out_of_cache.py runs n = 2048: 8.4 M triangles) at 51,200 triangles
 ]
 
 
