@@ -971,22 +971,9 @@ __global__ void k_accumulate(DCamera C, RenderParams R, int batchFrames)
 	const int pixel = y * C.width + x;
 	if (R.mode == 0) { R.accum[pixel] = R.samples[lp]; return; }
 	float4 a = R.accum[pixel];
-	// added in frame order; four frames' samples are fetched together (a thread's 64 loads one after the other left the kernel at
-	// 3.4 TB/s with its waves waiting 69 % of the time)
-	int f = 0;
-	for (; f + 4 <= batchFrames; f += 4) {
-		float4 s[4];
-#pragma unroll
-		for (int k = 0; k < 4; k++) s[k] = R.samples[(size_t)(f + k) * R.tilePixels + lp];
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			if (s[k].w != 0) s[k] = gamma_sample(xyz(s[k])); // stored raw (R.deferGamma)
-			a.x += s[k].x, a.y += s[k].y, a.z += s[k].z, a.w += 0;
-		}
-	}
-	for (; f < batchFrames; f++) {
+	for (int f = 0; f < batchFrames; f++) {
 		float4 s = R.samples[(size_t)f * R.tilePixels + lp];
-		if (s.w != 0) s = gamma_sample(xyz(s));
+		if (s.w != 0) s = gamma_sample(xyz(s)); // stored raw (R.deferGamma)
 		a.x += s.x, a.y += s.y, a.z += s.z, a.w += 0;
 	}
 	R.accum[pixel] = a;
