@@ -102,13 +102,6 @@ struct rt_ctx {
 	int gridBlocks = 0;
 	std::vector<int> matTypes; // material types of the uploaded scene (measurement builds)
 	int gridExtend = 0, gridConnect = 0, gridQuery = 0, gridConnectWide = 0, gridLeftover = 0; // resident blocks of the persistent traversal kernels (every wave owns a first chunk: none may wait for a slot)
-	int refillMin = 16; // free lanes a wave waits for before it flushes + refills them (RT_REFILL); bits 8-15: stepMin (RT_STEPMIN)
-	int refillAny = 24; // the same threshold for the any-hit kernel (RT_REFILL_ANY)
-	int pairAgain = 16; // lanes that must still want a pair step for an iteration to repeat it (RT_PAIRAGAIN); tuning bits 20-26
-	int stepMinAny = 8, pairAgainAny = 16; // the any-hit kernel's RT_STEPMIN / RT_PAIRAGAIN (RT_STEPMIN_ANY, RT_PAIRAGAIN_ANY)
-	int drainLanes = 64, drainLanesAny = 64; // RT_DRAIN_LANES / RT_DRAIN_LANES_ANY: once a wave's queue is dry, this many live lanes (1, 2, 4 .. 64; 0: never) leave the
-	                                       // scheduled state machine for the plain per-lane walk (trace_persistent "the drain")
-	int stepMinXform = 0; // lanes that must want an instance entry / exit before it runs (0: the same as RT_STEPMIN; swept in round 2: 4-6 neutral, less loses)
 	float* gammaLut = nullptr; // DScene::gammaLut
 	int* flags = nullptr; // [0] overflow for batch queries
 	DCounters* counters = nullptr;
@@ -149,7 +142,7 @@ static void free_pool(std::vector<void*>& pool)
 	pool.clear();
 }
 
-static int tuning(const rt_ctx* c, int base) { return base | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgain << 20) | (c->stepMinXform << 27) | RT_TUNE_DRAIN(c->drainLanes); }
+static int tuning(const rt_ctx* c) { return c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0; } // the traversal kernels' one launch-time flag (the thresholds are constants: rt_scene_dev.h)
 
 // ---- profiling helpers ---------------------------------------------------------------------
 enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_CONNECT, K_QUERY };
@@ -334,18 +327,6 @@ rt_ctx* rt_create(int device, int width, int height)
 		for (int i = 0; i < 9; i++) { const int r = resident(qk[i]); if (r < q) q = r; }
 		c->gridQuery = q;
 	}
-	if (getenv("RT_REFILL")) c->refillMin = atoi(getenv("RT_REFILL"));
-	if (c->refillMin < 1) c->refillMin = 1;
-	if (c->refillMin > 64) c->refillMin = 64;
-	if (getenv("RT_REFILL_ANY")) c->refillAny = atoi(getenv("RT_REFILL_ANY"));
-	if (c->refillAny < 1 || c->refillAny > 64) c->refillAny = 24;
-	if (getenv("RT_PAIRAGAIN")) c->pairAgain = atoi(getenv("RT_PAIRAGAIN"));
-	if (c->pairAgain < 1 || c->pairAgain > 65) c->pairAgain = 16;
-	if (getenv("RT_DRAIN_LANES")) c->drainLanes = c->drainLanesAny = atoi(getenv("RT_DRAIN_LANES"));
-	if (getenv("RT_DRAIN_LANES_ANY")) c->drainLanesAny = atoi(getenv("RT_DRAIN_LANES_ANY"));
-	{ int sm = getenv("RT_STEPMIN") ? atoi(getenv("RT_STEPMIN")) : 8; if (sm < 0) sm = 0; if (sm > 64) sm = 64; c->refillMin |= sm << 8;
-	  c->stepMinAny = getenv("RT_STEPMIN_ANY") ? atoi(getenv("RT_STEPMIN_ANY")) : sm; if (c->stepMinAny < 0 || c->stepMinAny > 64) c->stepMinAny = sm;
-	  c->pairAgainAny = getenv("RT_PAIRAGAIN_ANY") ? atoi(getenv("RT_PAIRAGAIN_ANY")) : c->pairAgain; if (c->pairAgainAny < 1 || c->pairAgainAny > 65) c->pairAgainAny = c->pairAgain; }
 	ok = ok && hipMalloc((void**)&c->spill, (size_t)(RT_STACK_MAX - RT_STACK_ROWS_MIN) * c->gridBlocks * RT_BLOCK * sizeof(uint)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->flags, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
 	ok = ok && hipMemset(c->flags, 0, (16 + RT_HEADS * RT_HEAD_STRIDE) * sizeof(int)) == hipSuccess;
@@ -1226,7 +1207,7 @@ static int slot_budget(const rt_ctx* c);
 static void launch_connect(rt_ctx* c, hipStream_t st, const PathState& P, const Queues& Q, int parity, uint* spill)
 {
 	// the any-hit walk has its own thresholds (RT_REFILL_ANY, RT_STEPMIN_ANY, RT_PAIRAGAIN_ANY)
-	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27) | RT_TUNE_DRAIN(c->drainLanesAny);
+	const int tun = tuning(c);
 	if (c->counting) hipLaunchKernelGGL((k_connect<true>), dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
 	else if (!c->S.wide) hipLaunchKernelGGL((k_connect<false>), dim3(c->gridConnect), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, tun, spill, c->counters + 1);
 	else {
@@ -1274,7 +1255,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds, int known
 		prof_begin(c, K_EXTEND, st);
 		{
 			auto extendKernel = c->counting ? (allActive ? k_extend<true, true> : k_extend<true, false>) : (allActive ? k_extend<false, true> : k_extend<false, false>);
-			hipLaunchKernelGGL(extendKernel, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+			hipLaunchKernelGGL(extendKernel, dim3(c->gridExtend), dim3(RT_BLOCK), 0, st, c->S, P, Q, parity, t_min, tuning(c), c->spill, c->counters);
 		}
 		prof_end(c, st);
 #ifdef RT_TAIL_PROBE
@@ -1334,7 +1315,7 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds, int known
 
 // ---- Whitted frames as one persistent launch (rt_mega.h) -----------------------------------------------
 #define RT_LEVEL_SAMPLES_MAX (16u << 20) // larger batches keep the single launch: their drain is a small part of them, and the queues would take GBs
-static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int grid0, int refill, bool* redo);
+static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int grid0, bool* redo);
 static int run_mega(rt_ctx* c, const RenderParams& R0)
 {
 	RenderParams R = R0;
@@ -1420,10 +1401,9 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 		c->megaCostSamples = R.nSamples, c->megaCostFirst = R.sampleFirst;
 	}
 	// a flush runs the body of Trace for the lanes that finished a query: it waits for more of them than a plain store does (32 instead of 16: 5.0 -> 4.85 ms)
-	const int refillMega = 32;
 	if (useLevels) {
 		bool redo = false;
-		const int rc = run_levels(c, R, M, grid, refillMega, &redo); // level 0 deals its tiles out like the single launch (M.order), and records what they cost
+		const int rc = run_levels(c, R, M, grid, &redo); // level 0 deals its tiles out like the single launch (M.order), and records what they cost
 		if (rc != RT_OK || !redo) { probe_end(); return rc; }
 		probe = -1, c->megaAuto.choice = 0; // this scene overflows the level queues: the single launch from now on
 		// a queue overflowed (more than two live branches per sample on average): the frame again, as one launch
@@ -1433,7 +1413,7 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 	tail_probe_reset(c->stream);
 #endif
 	prof_begin(c, K_EXTEND);
-	hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c, (c->refillMin & ~0xFF) | refillMega), c->spill, c->flags);
+	hipLaunchKernelGGL(k_whitted_mega, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M, tuning(c), c->spill, c->flags);
 	prof_end(c);
 #ifdef RT_TAIL_PROBE
 	tail_probe_print(c->stream, "mega", 0);
@@ -1453,7 +1433,7 @@ static int run_mega(rt_ctx* c, const RenderParams& R0)
 }
 
 // Whitted frames by tree levels (rt_mega.h): depth launches of k_whitted_level + k_whitted_reduce.  *redo: a queue overflowed.
-static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int grid0, int refill, bool* redo)
+static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int grid0, bool* redo)
 {
 	const int levels = R.maxDepth;
 	const size_t cap = ((size_t)2 * R.nSamples + 65536 + 63) & ~(size_t)63;
@@ -1481,7 +1461,7 @@ static int run_levels(rt_ctx* c, const RenderParams& R, const MegaState& M0, int
 		if (level > 0) (void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		V.level = level;
 		const int grid = level == 0 ? std::min(grid0, c->gridLevel) : c->gridLevel;
-		hipLaunchKernelGGL(k_whitted_level, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M0, V, tuning(c, (c->refillMin & ~0xFF) | refill), c->spill, c->flags);
+		hipLaunchKernelGGL(k_whitted_level, dim3(grid), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, R, M0, V, tuning(c), c->spill, c->flags);
 	}
 	hipLaunchKernelGGL(k_whitted_reduce, dim3((R.nSamples + 255) / 256), dim3(256), 0, c->stream, R, V);
 	prof_end(c);
@@ -1541,7 +1521,7 @@ static int ensure_stream_state(rt_ctx* c, int n)
 }
 static void launch_connect_s(rt_ctx* c, hipStream_t st, const StreamState& T, int round, uint* spill)
 {
-	const int tun = (c->refillAny | (c->stepMinAny << 8)) | (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->pairAgainAny << 20) | (c->stepMinXform << 27) | RT_TUNE_DRAIN(c->drainLanesAny);
+	const int tun = tuning(c);
 	if (c->counting) hipLaunchKernelGGL((k_connect_s<true>), dim3(c->gridConnectS), dim3(RT_BLOCK), 0, st, c->S, T, round, tun, spill, c->counters + 1);
 	else if (c->S.wide8) {
 		// the 8-wide quantised walk, then the binary walk over the rays it handed back (not clean: normally none)
@@ -1593,9 +1573,9 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		tail_probe_reset(st);
 #endif
 		prof_begin(c, K_EXTEND, st);
-		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c, c->refillMin), c->spill);
-		else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
-		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c, c->refillMin), c->spill, c->counters);
+		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c), c->spill);
+		else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c), c->spill, c->counters);
+		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c), c->spill, c->counters);
 		prof_end(c, st);
 #ifdef RT_TAIL_PROBE
 		tail_probe_print(st, "extend_s", round);
@@ -1964,11 +1944,11 @@ int rt_intersect_scope(rt_ctx* c, int scope, int index, int n, const float* O, c
 		prof_begin(c, K_QUERY);
 		const bool head = scope == RT_SCOPE_SCENE;
 		if (c->counting) {
-			if (head) hipLaunchKernelGGL((k_query_nearest<true, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
-			else hipLaunchKernelGGL((k_query_nearest<true, false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
+			if (head) hipLaunchKernelGGL((k_query_nearest<true, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c), dH, c->spill, c->flags, c->counters);
+			else hipLaunchKernelGGL((k_query_nearest<true, false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c), dH, c->spill, c->flags, c->counters);
 		} else {
-			if (head) hipLaunchKernelGGL((k_query_nearest<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
-			else hipLaunchKernelGGL((k_query_nearest<false, false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c, c->refillMin), dH, c->spill, c->flags, c->counters);
+			if (head) hipLaunchKernelGGL((k_query_nearest<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c), dH, c->spill, c->flags, c->counters);
+			else hipLaunchKernelGGL((k_query_nearest<false, false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, t_min, tuning(c), dH, c->spill, c->flags, c->counters);
 		}
 		prof_end(c);
 #ifdef RT_SECTION_PROBE
@@ -2034,15 +2014,15 @@ int rt_occluded_scope(rt_ctx* c, int scope, int index, int n, const float* O, co
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL((k_query_occluded<true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
-		else if (!wideWalk) hipLaunchKernelGGL((k_query_occluded<false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+		if (c->counting) hipLaunchKernelGGL((k_query_occluded<true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c), dR, c->spill, c->flags, c->counters + 1, dL);
+		else if (!wideWalk) hipLaunchKernelGGL((k_query_occluded<false>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c), dR, c->spill, c->flags, c->counters + 1, dL);
 		else {
 			// the 4-wide walk, then the binary walk over the rays it handed back (not clean: normally none)
 			(void)hipMemsetAsync(c->flags + 2, 0, sizeof(int), c->stream);
-			if (wide8Walk) hipLaunchKernelGGL((k_query_occluded<false, false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
-			else hipLaunchKernelGGL((k_query_occluded<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+			if (wide8Walk) hipLaunchKernelGGL((k_query_occluded<false, false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c), dR, c->spill, c->flags, c->counters + 1, dL);
+			else hipLaunchKernelGGL((k_query_occluded<false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c), dR, c->spill, c->flags, c->counters + 1, dL);
 			(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream);
-			hipLaunchKernelGGL((k_query_occluded<false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c, c->refillMin), dR, c->spill, c->flags, c->counters + 1, dL);
+			hipLaunchKernelGGL((k_query_occluded<false, false, true>), dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, S, n, dO, dD, dT, tuning(c), dR, c->spill, c->flags, c->counters + 1, dL);
 		}
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
@@ -2069,8 +2049,8 @@ int rt_primary_hits(rt_ctx* c, float t_min, int32_t* obj_out, float* t_out)
 	if (e == hipSuccess) {
 		(void)hipMemsetAsync(c->flags + 16, 0, RT_HEADS * RT_HEAD_STRIDE * sizeof(int), c->stream); // work heads
 		prof_begin(c, K_QUERY);
-		if (c->counting) hipLaunchKernelGGL(k_primary_hits<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, tuning(c, c->refillMin), dO, dT, c->spill, c->flags, c->counters);
-		else hipLaunchKernelGGL(k_primary_hits<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, tuning(c, c->refillMin), dO, dT, c->spill, c->flags, c->counters);
+		if (c->counting) hipLaunchKernelGGL(k_primary_hits<true>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, tuning(c), dO, dT, c->spill, c->flags, c->counters);
+		else hipLaunchKernelGGL(k_primary_hits<false>, dim3(query_grid(c, n)), dim3(RT_BLOCK), 0, c->stream, c->S, c->C, t_min, tuning(c), dO, dT, c->spill, c->flags, c->counters);
 		prof_end(c);
 		e = hipStreamSynchronize(c->stream);
 	}
@@ -2213,8 +2193,8 @@ const char* rt_tuning_info(rt_ctx* c)
 	if (!c) return "";
 	char buf[640];
 	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
-	         c->useStream, c->decideRays, c->fuseTraversal, c->refillMin & 0xFF, c->refillAny, (c->refillMin >> 8) & 0xFF, c->stepMinAny, c->stepMinXform,
-	         c->pairAgain, c->pairAgainAny, c->drainLanes, c->drainLanesAny, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
+	         c->useStream, c->decideRays, c->fuseTraversal, RT_REFILL, RT_REFILL_ANY, RT_STEPMIN, RT_STEPMIN_ANY, RT_STEPMIN_XFORM,
+	         RT_PAIRAGAIN, RT_PAIRAGAIN_ANY, RT_DRAIN_LANES, RT_DRAIN_LANES_ANY, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();

@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(RT_MEGA_ORDER_BLOCK) k_mega_order(const uint* 
 
 struct WhittedMegaPolicy {
 	static constexpr bool kAdvance = true;
+	static constexpr int kRefill = 32;
 	const DScene& S;
 	const DCamera& C;
 	const RenderParams& R;
@@ -322,6 +323,7 @@ typedef __attribute__((address_space(3))) int lds_int;
 
 struct WhittedLevelPolicy {
 	static constexpr bool kAdvance = true;
+	static constexpr int kRefill = 32;
 	const DScene& S;
 	const DCamera& C;
 	const RenderParams& R;

@@ -303,8 +303,38 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 // each (4 KB apart: separate L2 channels); a wave reserves from its home sub-queue, sizes the
 // reservation by what is left there (256 entries early on, 64 near the end), and moves on to the other
 // sub-queues when its own is empty.
-#define RT_TUNE_CULL_COUNTED 0x10000 // 'tuning' bit: a counting launch drops unreachable TLAS children like a timed one
-#define RT_TUNE_DRAIN(lanes) ((lanes) <= 0 ? 0 : ((lanes) >= 64 ? 7 : (32 - __builtin_clz((unsigned)(lanes)))) << 17) // 'tuning' bits 17-19: the drain loop takes over at 1, 2, 4 .. 64 live lanes
+#define RT_TUNE_CULL_COUNTED 0x10000 // the one bit of a traversal kernel's 'tuning' argument: a counting launch drops unreachable TLAS children like a timed one
+// The scheduling thresholds of trace_persistent are compile-time constants (they were launch arguments, and environment variables on
+// the host, through round 4's sweeps: every sweep since round 2 came out flat around these values, and as constants they leave the
+// kernels five scalar registers and their selects -- k_extend_s -2.7 %, profiles/r04_ab_fixed_tuning.txt).  A sweep is a rebuild:
+// make EXTRA="-DRT_STEPMIN=12" in a copy of the tree (profiles/r04_bisect.sh).  _ANY: launches of any-hit queries only.
+#ifndef RT_REFILL
+#define RT_REFILL 16        // free lanes a wave waits for before it flushes them and refills (a policy's kRefill overrides it)
+#endif
+#ifndef RT_REFILL_ANY
+#define RT_REFILL_ANY 24
+#endif
+#ifndef RT_STEPMIN
+#define RT_STEPMIN 8        // lanes that must want a leaf step before it runs (or it is the most wanted kind)
+#endif
+#ifndef RT_STEPMIN_ANY
+#define RT_STEPMIN_ANY 8
+#endif
+#ifndef RT_STEPMIN_XFORM
+#define RT_STEPMIN_XFORM 0  // the same for an instance entry / exit (0: as RT_STEPMIN; 4-6 neutral, less loses: round 2)
+#endif
+#ifndef RT_PAIRAGAIN
+#define RT_PAIRAGAIN 16     // lanes that must still want a pair step for an iteration to repeat it
+#endif
+#ifndef RT_PAIRAGAIN_ANY
+#define RT_PAIRAGAIN_ANY 16
+#endif
+#ifndef RT_DRAIN_LANES
+#define RT_DRAIN_LANES 64   // live lanes of a wave whose queue is dry at which they leave the scheduled machine for the per-lane loop (0: never)
+#endif
+#ifndef RT_DRAIN_LANES_ANY
+#define RT_DRAIN_LANES_ANY 64
+#endif
 #define RT_HEADS 16
 #ifndef RT_NO_DRAIN_LOOP
 #define RT_NO_DRAIN_LOOP 0 // measurement builds: 1 keeps the drain in the scheduled machine
@@ -366,6 +396,9 @@ template <class P, class = void> struct pol_starts_done { static constexpr bool 
 template <class P> struct pol_starts_done<P, decltype((void)&P::starts_done)> { static constexpr bool value = true; };
 template <class P, class = void> struct pol_advances { static constexpr bool value = false; };
 template <class P> struct pol_advances<P, decltype((void)P::kAdvance)> { static constexpr bool value = P::kAdvance; };
+// 'static constexpr int kRefill': the policy's own refill threshold (the Whitted launches hand out tiles, not rays)
+template <class P, class = void> struct pol_refill { static constexpr int value = 0; };
+template <class P> struct pol_refill<P, decltype((void)P::kRefill)> { static constexpr int value = P::kRefill; };
 
 template <bool ANY, bool COUNT, bool HEAD, class Policy, bool MIXED = false, int WIDTH = 2>
 __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, int n, int* heads, float t_min, int tuning,
@@ -380,9 +413,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	constexpr int REPEAT = ANY && !MIXED ? RT_CONNECT_REPEAT : RT_PAIR_REPEAT; // pair steps per iteration at most
 	constexpr bool DRAINS = !ANYWIDE && !pol_advances<Policy>::value && !RT_NO_DRAIN_LOOP; // the last rays of a wave leave the machine for a plain per-lane loop
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
-	const int refillMin = tuning & 0xFF, stepMinBusy = (tuning >> 8) & 0xFF, pairAgainBusy = (tuning >> 20) & 0x7F;
-	const int stepMinXformBusy = ((tuning >> 27) & 0xF) ? ((tuning >> 27) & 0xF) : stepMinBusy; // entry / exit: arithmetic and LDS only when the TLAS is in LDS
-	const int drainLanes = ((tuning >> 17) & 7) ? 1 << (((tuning >> 17) & 7) - 1) : 0; // RT_TUNE_DRAIN: live lanes of a wave whose queue is dry at which they leave the scheduled machine (0: never)
+	constexpr bool ANYQ = ANY && !MIXED; // a launch of any-hit queries only
+	constexpr int refillMin = pol_refill<Policy>::value ? pol_refill<Policy>::value : (ANYQ ? RT_REFILL_ANY : RT_REFILL);
+	constexpr int stepMinBusy = ANYQ ? RT_STEPMIN_ANY : RT_STEPMIN, pairAgainBusy = ANYQ ? RT_PAIRAGAIN_ANY : RT_PAIRAGAIN;
+	constexpr int stepMinXformBusy = RT_STEPMIN_XFORM ? RT_STEPMIN_XFORM : stepMinBusy; // entry / exit: arithmetic and LDS only when the TLAS is in LDS
+	constexpr int drainLanes = ANYQ ? RT_DRAIN_LANES_ANY : RT_DRAIN_LANES;
 	// (lane and the bits below it are recomputed where they are used: two instructions there instead of three registers kept live
 	// across the hottest loop of the library, which has none to spare at seven waves per SIMD)
 #define lane (threadIdx.x & 63)
