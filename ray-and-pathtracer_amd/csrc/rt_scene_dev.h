@@ -324,7 +324,7 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #define RT_STEPMIN_XFORM 0  // the same for an instance entry / exit (0: as RT_STEPMIN; 4-6 neutral, less loses: round 2)
 #endif
 #ifndef RT_PAIRAGAIN
-#define RT_PAIRAGAIN 16     // lanes that must still want a pair step for an iteration to repeat it
+#define RT_PAIRAGAIN 24     // lanes that must still want a pair step for an iteration to repeat it (16 with four repeats)
 #endif
 #ifndef RT_PAIRAGAIN_ANY
 #define RT_PAIRAGAIN_ANY 16
@@ -343,7 +343,7 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #define RT_SHORT_QUEUE_RAYS 32 // queue entries per wave below which further waves of the grid do not take part
 #endif
 #ifndef RT_PAIR_REPEAT
-#define RT_PAIR_REPEAT 4 // pair steps per iteration at most (unrolled)
+#define RT_PAIR_REPEAT 5 // pair steps per iteration at most (unrolled; 4 through round 4: five fit since the kernel has registers to spare, profiles/r04_sweep_repeat.txt)
 #endif
 #ifndef RT_CONNECT_REPEAT
 #define RT_CONNECT_REPEAT 6 // the same for a launch of any-hit queries only (six spill in the nearest-hit kernel at its 72 registers)
