@@ -292,6 +292,13 @@ __device__ __forceinline__ void unpack_head(uint v, HitRef& h)
 #define RT_BOX_BIT 0x20000000u  // 8-wide walk: link names a leafBox[] record (the leaf's exact box is tested before its primitives)
 #define RT_LINK_EXIT 0xFFFFFFFCu // leave the current instance (the sentinel was popped)
 #define RT_LINK_DONE 0xFFFFFFFBu // this ray is finished; its result is written at the next refill
+// What a lane's link asks for, as ONE unsigned compare each (the scheduler of trace_persistent takes a dozen ballots of these per
+// iteration; a ballot of a compare is the compare, a ballot of an AND of conditions is the conditions, a 0 / 1 value in a vector
+// register, and a compare of that).  An idle lane (work < 0) holds RT_LINK_DONE, so "live" is link != RT_LINK_DONE.
+#define RT_WANTS_PAIR(lk) ((lk) < RT_INST_BIT)                            // neither RT_LEAF_BIT nor RT_INST_BIT (the special links have both)
+#define RT_WANTS_ENTER(lk) ((lk) - RT_INST_BIT < RT_INST_BIT)             // RT_INST_BIT without RT_LEAF_BIT
+#define RT_WANTS_LEAF(lk) ((lk) - RT_LEAF_BIT < RT_LINK_DONE - RT_LEAF_BIT) // RT_LEAF_BIT, below the special links
+static_assert(RT_LEAF_BIT == 0x80000000u && RT_INST_BIT == 0x40000000u && RT_LINK_DONE + 1 == RT_LINK_EXIT, "the link tests above read the encoding this way");
 #define RT_CHUNK 256 // queue entries a wave reserves per atomic on a work head (upper bound)
 #ifndef RT_CHUNK_MIN
 #define RT_CHUNK_MIN 64 // ... and the lower bound, near the end of a sub-queue (a power of two)
@@ -513,16 +520,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	// (k_extend_s: 0 -> 20 bytes of scratch at its 72 registers, which costs 10 % of the kernel; profiles/r04_ab_drain_loop.txt).
 	while (true) {
 		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
-		bool idle = work < 0;
 		bool doneLane = work >= 0 && link == RT_LINK_DONE;
-		unsigned long long freeMask = __ballot(idle || doneLane); // lanes that can take a new work item
+		unsigned long long freeMask = __ballot(link == RT_LINK_DONE); // lanes that can take a new work item: idle ones (they hold RT_LINK_DONE too) and finished ones
 		RT_SEC_COUNT(8);
 		if (freeMask != 0) {
 			const int cnt = __popcll(freeMask);
 			const bool nothingLeft = freeMask == ~0ull;
 			// (once the queue is dry there is nothing to hand out: the block is for finished lanes only -- a wave's last rays then
 			// skip it on all the iterations in which none of them finished)
-			if ((cnt >= refillMin || nothingLeft) && (!exhausted || __ballot(doneLane) != 0)) {
+			if ((cnt >= refillMin || nothingLeft) && (!exhausted || (__ballot(work >= 0) & freeMask) != 0)) {
 				const unsigned long long secT = RT_SEC_NOW();
 				RT_SEC_COUNT(13);
 				if (doneLane) {
@@ -603,7 +609,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 							if (link == RT_EMPTY) link = RT_LINK_DONE;
 							if constexpr (pol_starts_done<Policy>::value) { if (pol.starts_done()) link = RT_LINK_DONE; } // the policy answered the query itself
 							rays++;
-							if constexpr (ANYWIDE) { if (!clean) { pol.leftover(mine); work = -1; } } // the binary walk answers this one
+							if constexpr (ANYWIDE) { if (!clean) { pol.leftover(mine); work = -1, link = RT_LINK_DONE; } } // the binary walk answers this one
 						}
 						chunkNext += cntFree < avail ? cntFree : avail;
 					}
@@ -615,8 +621,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #ifdef RT_TAIL_PROBE
 		if (exhausted && !probed) { probed = true; if (lane == 0) atomicMin(&g_tailProbe[1], __builtin_amdgcn_s_memrealtime()); }
 #endif
-		const bool stepping = work >= 0 && link != RT_LINK_DONE;
-		const unsigned long long stepMask = __ballot(stepping);
+		const unsigned long long stepMask = __ballot(link != RT_LINK_DONE);
 		if (stepMask == 0) {
 			if (exhausted && __ballot(work >= 0) == 0) break;
 			continue; // only finished lanes left (they flush above), or nothing was handed out this time
@@ -639,17 +644,15 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #pragma unroll
 		for (int rep = 0; rep < REPEAT; rep++) {
 			const uint lk = link;
-			const bool live = work >= 0 && lk != RT_LINK_DONE;
-			const bool wantPair = live && !(lk & (RT_LEAF_BIT | RT_INST_BIT));
-			const bool isLeaf = live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
+			const bool wantPair = RT_WANTS_PAIR(lk);
 			const int nP = __popcll(__ballot(wantPair));
 			if (nP == 0) break;
 			if (rep == 0) {
 				if (nP < stepMin) {
 					// fewer than stepMin: only if nothing else is wanted more
-					const int nL = __popcll(__ballot(isLeaf));
-					const int nN = __popcll(__ballot(live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT)));
-					const int nE = __popcll(__ballot(live && lk == RT_LINK_EXIT));
+					const int nL = __popcll(__ballot(RT_WANTS_LEAF(lk)));
+					const int nN = __popcll(__ballot(RT_WANTS_ENTER(lk)));
+					const int nE = __popcll(__ballot(lk == RT_LINK_EXIT));
 					if (nP < nL || nP < nN || nP < nE) break;
 				}
 			} else if (nP < pairAgain) break;
@@ -662,11 +665,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		}
 		// the other kinds, on the links as they are now
 		uint lk = link;
-		bool live = work >= 0 && lk != RT_LINK_DONE;
-		bool wantLeaf = live && lk < RT_LINK_EXIT && (lk & RT_LEAF_BIT);
-		bool wantExit = live && lk == RT_LINK_EXIT;
-		bool wantEnter = live && !(lk & RT_LEAF_BIT) && (lk & RT_INST_BIT);
-		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(live && !(lk & (RT_LEAF_BIT | RT_INST_BIT))));
+		bool live = lk != RT_LINK_DONE;
+		bool wantLeaf = RT_WANTS_LEAF(lk);
+		bool wantExit = lk == RT_LINK_EXIT;
+		bool wantEnter = RT_WANTS_ENTER(lk);
+		const int nL = __popcll(__ballot(wantLeaf)), nP = __popcll(__ballot(RT_WANTS_PAIR(lk)));
 		const int nN = __popcll(__ballot(wantEnter)), nE = __popcll(__ballot(wantExit));
 		int most = nL > nP ? nL : nP;
 		most = nN > most ? nN : most;
