@@ -183,7 +183,7 @@ struct Stack {
 	__device__ __forceinline__ void push(uint v)
 	{
 		RT_CHECK(sp <= RT_STACK_MAX, 1, overflow);
-		if (sp < rows) lds[sp * RT_BLOCK] = v;
+		if (__builtin_expect(sp < rows, 1)) lds[sp * RT_BLOCK] = v; // (the hint: the LDS rows are where nearly every entry goes)
 		else if (sp < RT_STACK_MAX) spill[spill_at(sp - rows)] = v;
 		else { *overflow = 1; sp = 0; return; } // reported as RT_E_OVERFLOW by the host; the ray ends at its next pop instead of walking a wrong stack
 		sp++;
@@ -192,7 +192,7 @@ struct Stack {
 	{
 		RT_CHECK(sp >= 1 && sp <= RT_STACK_MAX, 2, overflow);
 		sp--;
-		if (sp < rows) return lds[sp * RT_BLOCK];
+		if (__builtin_expect(sp < rows, 1)) return lds[sp * RT_BLOCK];
 		return spill[spill_at(sp - rows)];
 	}
 };
