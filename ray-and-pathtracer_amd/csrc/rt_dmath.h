@@ -176,19 +176,18 @@ __device__ __forceinline__ float intersect_aabb(bool clean, const f3& O, const f
 __device__ __forceinline__ bool tri_hit(const f3& O, const f3& D, float rayT, float t_min,
                                         const f3& v0, const f3& v1, const f3& v2, const f3& N, float d, float& tOut)
 {
-	float NdotRayDir = dot(N, D);
-	if (fabsf(NdotRayDir) < t_min) return false;
-	float t = -(dot(N, O) + d) / NdotRayDir;
-	if (t < 0) return false;
-	f3 p = O + t * D;
-	f3 c = cross(v1 - v0, p - v0);
-	if (dot(N, c) < 0) return false;
-	c = cross(v2 - v1, p - v1);
-	if (dot(N, c) < 0) return false;
-	c = cross(v0 - v2, p - v2);
-	if (dot(N, c) < 0) return false;
-	if (t < rayT && t > t_min) { tOut = t; return true; }
-	return false;
+	// The reference returns false at five places on the way (:195, :201, :210, :216, :222); here everything is computed and the
+	// verdict is ONE conjunction of the same comparisons, negated where the reference leaves -- a NaN falls the same way through
+	// either form, and nothing computed has a side effect.  Lanes of a wave do not leave together, so the early returns saved no
+	// instruction and cost a mask save, a branch and a restore each.
+	const float NdotRayDir = dot(N, D);
+	const float t = -(dot(N, O) + d) / NdotRayDir;
+	const f3 p = O + t * D;
+	const float e0 = dot(N, cross(v1 - v0, p - v0));
+	const float e1 = dot(N, cross(v2 - v1, p - v1));
+	const float e2 = dot(N, cross(v0 - v2, p - v2));
+	tOut = t;
+	return !(fabsf(NdotRayDir) < t_min) & !(t < 0) & !(e0 < 0) & !(e1 < 0) & !(e2 < 0) & (t < rayT) & (t > t_min);
 }
 // Sphere::Intersect (template/scene.h:351-371): nearest accepted root
 __device__ __forceinline__ bool sphere_hit(const f3& O, const f3& D, float rayT, float t_min, const f3& pos, float r2, float& tOut)
