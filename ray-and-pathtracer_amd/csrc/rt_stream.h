@@ -357,15 +357,18 @@ __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_assign(StreamState T, int 
 // that does not depend on another load is issued before the first use.
 #define RT_LDS_MATS 48   // materials / brute-force primitives a block keeps in LDS (scenes with more read them from memory)
 #define RT_LDS_BRUTE 24
-struct ShadeTables { uint mats[RT_LDS_MATS * 16]; float4 brute[RT_LDS_BRUTE * 4]; };
+struct ShadeTables { uint mats[RT_LDS_MATS * 16]; float4 brute[RT_LDS_BRUTE * 4]; uint lights[RT_MAX_LIGHTS * (sizeof(DLight) / 4)]; };
 __device__ __forceinline__ void load_tables(DScene& S, ShadeTables& L, int enable)
 {
 	const bool m = enable && S.nMats <= RT_LDS_MATS, b = enable && S.useTLAS && S.nBruteSph + S.nBrutePla <= RT_LDS_BRUTE && S.nBruteSph + S.nBrutePla > 0;
+	const bool l = enable && S.nLights > 0 && S.nLights <= RT_MAX_LIGHTS; // the light loop of a diffuse hit reads every light's record: a round trip each otherwise
 	if (m) for (int i = (int)threadIdx.x; i < S.nMats * 16; i += (int)blockDim.x) L.mats[i] = ((const uint*)S.mats)[i];
 	if (b) for (int i = (int)threadIdx.x; i < (S.nBruteSph + S.nBrutePla) * 4; i += (int)blockDim.x) L.brute[i] = S.brute[i];
-	if (m || b) __syncthreads();
+	if (l) for (int i = (int)threadIdx.x; i < S.nLights * (int)(sizeof(DLight) / 4); i += (int)blockDim.x) L.lights[i] = ((const uint*)S.lights)[i];
+	if (m || b || l) __syncthreads();
 	if (m) S.mats = (const DMaterial*)L.mats;
 	if (b) S.brute = L.brute;
+	if (l) S.lights = (const DLight*)L.lights;
 }
 
 // shade: everything Sample does at the hit of entry e except the occlusion-dependent direct terms (renderer.cpp:133-233).
