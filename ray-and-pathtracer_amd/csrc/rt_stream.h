@@ -13,7 +13,7 @@
 // class bytes into positions.  Per round:
 //   compact   cls -> queue of the entries that still need a traversal                        (1 B per entry)
 //   extend    Scene::FindNearest for those; hit record + class byte per entry                (persistent, the dominant kernel)
-//   assign    exclusive scans of the CONT and SHADOW class bits -> pos[e] = (position in round r + 1, shadow position)
+//   assign    exclusive scans of the CONT and SHADOW class bits -> pos[e / 64] = (position in round r + 1, shadow position) of the group's first entry
 //   shade     the body of Sample at the hit: reads entry e, writes the continuation (next ray, W, E, L) at its
 //             position in the other buffer of a ping-pong pair and the shadow record at its shadow position; a path
 //             that ends stores its finished sample.  Nothing else is written.
@@ -61,7 +61,7 @@ struct StreamState {
 	float4* E[2];     // energy xyz, w = RNG state
 	float4* L[2];     // radiance so far xyz, w = sample id
 	unsigned char* cls[2]; // CL_* bits
-	int2* pos;        // current round: x = entry in the next round (CL_CONT), y = shadow record (CL_SHADOW)
+	int2* pos;        // current round, per GROUP of 64 entries: x = entry in the next round of the group's first CL_CONT entry, y = shadow record of its first CL_SHADOW entry (k_assign; k_shade_s counts inside the group)
 	float4* shI;      // shadow record: ray.IntersectionPoint() xyz, w = material
 	float4* shN;      //                hit normal xyz, w = continuation entry (holds this path's E and L)
 	float4* shD;      //                direction of the ray that hit xyz
@@ -276,10 +276,10 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S
 	}
 }
 
-// assign: pos[e] = (number of CL_CONT entries before e, number of CL_SHADOW entries before e) + the block's bases; the
+// assign: pos[e / 64] = (number of CL_CONT entries before group e / 64, number of CL_SHADOW entries before it) + the block's bases; the
 // totals become the next round's entry count and this round's shadow count.  Same shape as compact_body: a wave owns a
-// contiguous range, counts it, the block reserves with one atomic per counter, then every lane writes the positions of
-// its 16 entries (128 contiguous bytes).  Blocks reserve in arrival order, so entry order is by block, in order within.
+// contiguous range, counts it, the block reserves with one atomic per counter, then every fourth lane writes the bases of
+// its group of 64 entries.  Blocks reserve in arrival order, so entry order is by block, in order within.
 __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_assign(StreamState T, int round)
 {
 	const int parity = round & 1;
@@ -328,24 +328,10 @@ __global__ void __launch_bounds__(RT_COMPACT_BLOCK) k_assign(StreamState T, int 
 			const int tc = __shfl_up(inC, o), ts = __shfl_up(inS, o);
 			if ((int)lane >= o) inC += tc, inS += ts;
 		}
-		int pc = bc + inC - cC, ps = bs + inS - cS;
-		if (e0 < last) {
-			const uint w[4] = { v.x, v.y, v.z, v.w };
-			int4* out = (int4*)(T.pos + e0); // pos has room for the whole last vector
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-#pragma unroll
-				for (int j = 0; j < 4; j += 2) {
-					const uint b0 = (w[k] >> (8 * j)) & 0xFF, b1 = (w[k] >> (8 * j + 8)) & 0xFF;
-					int4 o4;
-					o4.x = pc, o4.y = ps;
-					pc += (b0 & CL_CONT) ? 1 : 0, ps += (b0 & CL_SHADOW) ? 1 : 0;
-					o4.z = pc, o4.w = ps;
-					pc += (b1 & CL_CONT) ? 1 : 0, ps += (b1 & CL_SHADOW) ? 1 : 0;
-					out[2 * k + j / 2] = o4;
-				}
-			}
-		}
+		// one pair of bases per GROUP of 64 entries (four lanes of this scan): a wave of the shading kernel holds exactly one group and
+		// counts inside it with two ballots -- eight bytes per entry written here and read there otherwise (4.5 GB per bench step)
+		const int pc = bc + inC - cC, ps = bs + inS - cS;
+		if (e0 < last && (lane & 3) == 0) T.pos[e0 >> 6] = make_int2(pc, ps);
 		bc += __shfl(inC, 63), bs += __shfl(inS, 63);
 	}
 }
@@ -400,19 +386,26 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 		// looks at the class first: the entries of samples finished by generate hold nothing, and they come in long runs)
 		const bool spec = !fresh && e < n;
 		float4 o4, d4, hn, e4, w4, l4;
-		int2 id, p = make_int2(0, 0);
+		int2 id;
+		const int2 grp = e < n ? T.pos[e >> 6] : make_int2(0, 0); // the bases of this wave's group of 64 entries (k_assign); the same for every lane that has an entry (the grid's last iteration reaches past n, and past pos[])
 		if (spec) {
 			o4 = T.O[parity][e], d4 = T.D[parity][e], hn = T.hitN[parity][e], id = T.hitId[parity][e];
-			e4 = T.E[parity][e], w4 = T.W[parity][e], l4 = T.L[parity][e], p = T.pos[e];
+			e4 = T.E[parity][e], w4 = T.W[parity][e], l4 = T.L[parity][e];
 		}
 		const unsigned char c = e < n ? T.cls[parity][e] : 0;
+		// the entry's place in the next round and its shadow record: the group's bases + the entries before it in the wave that want one
+		int2 p;
+		{
+			const unsigned long long mC = __ballot((c & CL_CONT) != 0), mS = __ballot((c & CL_SHADOW) != 0);
+			p.x = grp.x + (int)__builtin_amdgcn_mbcnt_hi((uint)(mC >> 32), __builtin_amdgcn_mbcnt_lo((uint)mC, 0u));
+			p.y = grp.y + (int)__builtin_amdgcn_mbcnt_hi((uint)(mS >> 32), __builtin_amdgcn_mbcnt_lo((uint)mS, 0u));
+		}
 		if (c & CL_LIVE) {
 			if (!spec) {
 				o4 = T.O[parity][e], d4 = T.D[parity][e], hn = T.hitN[parity][e], id = T.hitId[parity][e];
 				e4 = fresh_energy(C, R, R.sampleFirst + (uint)e);
 				w4 = make_float4(1, 1, 1, 0);
 				l4 = make_float4(0, 0, 0, __uint_as_float(R.sampleFirst + (uint)e));
-				if (c & CL_CONT) p = T.pos[e];
 			}
 			RT_CHECK(!(c & CL_CONT) || (p.x >= 0 && p.x < T.cap && p.y >= 0 && p.y < T.cap), 21, &T.counts[SC_FLAG]);
 			const f3 O = xyz(o4), D = xyz(d4), normal = xyz(hn);
