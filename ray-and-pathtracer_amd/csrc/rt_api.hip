@@ -1505,7 +1505,7 @@ static int ensure_stream_state(rt_ctx* c, int n)
 		HIPCHK(c, dalloc(A, &T.W[b], cap)); HIPCHK(c, dalloc(A, &T.E[b], cap)); HIPCHK(c, dalloc(A, &T.L[b], cap));
 		HIPCHK(c, dalloc(A, &T.cls[b], cap));
 	}
-	HIPCHK(c, dalloc(A, &T.pos, cap));
+	HIPCHK(c, dalloc(A, &T.pos, cap / 64 + 64)); // a pair of bases per group of 64 entries
 	HIPCHK(c, dalloc(A, &T.shI, cap)); HIPCHK(c, dalloc(A, &T.shN, cap)); HIPCHK(c, dalloc(A, &T.shD, cap)); HIPCHK(c, dalloc(A, &T.shW, cap));
 	HIPCHK(c, dalloc(A, &T.shP, cap * nl));
 	HIPCHK(c, dalloc(A, &T.vis, cap * nl));
