@@ -219,6 +219,18 @@ def test_path_frames(name, kw, w, h, frames, pipeline, scenes, oracle_api, host_
     r.close()
 
 
+@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("pretty_tlas", {"n_instances": 4})])
+@pytest.mark.parametrize("w,h,frames", [(37, 23, 1), (37, 23, 3), (7, 5, 1), (65, 1, 1), (63, 1, 2), (129, 3, 5)])
+def test_path_frames_ragged_batches(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
+    """Batches whose sample count is not a multiple of 64 (and batches of less than one wave): the dense pipeline hands out
+    positions per GROUP of 64 entries and its shading kernel counts inside the group with ballots (csrc/rt_stream.h k_assign /
+    k_shade_s); the last group of such a batch is ragged, and the grid's last iteration reaches past the batch."""
+    monkeypatch.setenv("RT_STREAM", "1")
+    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
+    check_frames(orr, r, "path", frames, host_api)
+    r.close()
+
+
 @pytest.mark.parametrize("name,kw", [("pretty_scene1", {}), ("pretty_animation", {}), ("bigb_scene", {}), ("christ_scene", {}), ("tlas_test", {}),
                                      ("scene1", {}), ("scene2", {}), ("scene4", {}), ("scene5", {}), ("scene6", {}), ("scene7", {"nx": 64, "ny": 64}),
                                      ("scene7", {})])
