@@ -504,14 +504,14 @@ struct ExtendPolicy {
 	}
 };
 template <bool COUNT, bool DENSE>
-__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend(DScene S, PathState P, Queues Q, int parity, float t_min, int tuning, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
 	ExtendPolicy<DENSE> pol{ S, P, Q.active, parity, &Q.counts[3] };
-	trace_persistent<false, COUNT, false>(S, pol, Q.counts[0], Q.heads, t_min, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+	trace_persistent<false, COUNT, false>(S, pol, Q.counts[0], Q.heads, t_min, tuning, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) {
 		// the head tests ran where the rays were created: per ray, every light and every brute-force primitive
 		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
@@ -690,7 +690,7 @@ struct ListedPolicy {
 #endif
 // WIDE: the 4-wide walk (needs S.wide); LISTED: the work items are Q.leftover[0 .. Q.counts[8])
 template <bool COUNT, bool WIDE = false, bool LISTED = false>
-__global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S, PathState P, Queues Q, int parity, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S, PathState P, Queues Q, int parity, int tuning, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
@@ -699,9 +699,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect(DScene S
 	ConnectPolicy pol{ P, Q.shadow, parity, S.nLights, &Q.counts[3], Q.leftover, &Q.counts[8] };
 	if constexpr (LISTED) {
 		ListedPolicy<ConnectPolicy> lp{ pol, Q.leftover };
-		trace_persistent<true, COUNT, false, ListedPolicy<ConnectPolicy>>(S, lp, Q.counts[8], Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+		trace_persistent<true, COUNT, false, ListedPolicy<ConnectPolicy>>(S, lp, Q.counts[8], Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, tuning, ldsStack, spill, &Q.counts[3], lc, rays);
 	} else
-		trace_persistent<true, COUNT, false, ConnectPolicy, false, WIDE ? 4 : 2>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, refillMin, ldsStack, spill, &Q.counts[3], lc, rays);
+		trace_persistent<true, COUNT, false, ConnectPolicy, false, WIDE ? 4 : 2>(S, pol, Q.counts[2] * S.nLights, Q.heads + RT_HEADS * RT_HEAD_STRIDE, 0.0f, tuning, ldsStack, spill, &Q.counts[3], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -1038,7 +1038,7 @@ struct PrimaryPolicy {
 // HEAD: Scene::FindNearest (lights and brute-force primitives first); !HEAD: the accelerator alone (bvh::Intersect,
 // tlas::Intersect, bvhInstance::BIntersect -- the host passes a DScene rooted at what is asked for)
 template <bool COUNT, bool HEAD = true>
-__global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, const float* O3, const float* D3, const float* tmax, float t_min, int refillMin,
+__global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, const float* O3, const float* D3, const float* tmax, float t_min, int tuning,
                                                             QueryHit* out, uint* spill, int* work, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
@@ -1046,13 +1046,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_nearest(DScene S, int n, con
 	lc.clear();
 	uint rays = 0;
 	NearestQueryPolicy pol(S, O3, D3, tmax, out);
-	trace_persistent<false, COUNT, HEAD>(S, pol, n, work + 16, t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, COUNT, HEAD>(S, pol, n, work + 16, t_min, tuning, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 
 // work[0] unused, work[1] overflow flag, work[2] rays handed back by the wide walk; LISTED: the items are leftover[0 .. work[2])
 template <bool COUNT, bool WIDE = false, bool LISTED = false, bool WIDE8 = false>
-__global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax, int refillMin,
+__global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, const float* O3, const float* D3, const float* tmax, int tuning,
                                                              unsigned char* out, uint* spill, int* work, DCounters* counters, uint* leftover)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
@@ -1062,21 +1062,21 @@ __global__ void __launch_bounds__(RT_BLOCK) k_query_occluded(DScene S, int n, co
 	OccludedQueryPolicy pol(O3, D3, tmax, out, leftover, &work[2]);
 	if constexpr (LISTED) {
 		ListedPolicy<OccludedQueryPolicy> lp{ pol, leftover };
-		trace_persistent<true, COUNT, false>(S, lp, work[2], work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+		trace_persistent<true, COUNT, false>(S, lp, work[2], work + 16, 0.0f, tuning, ldsStack, spill, &work[1], lc, rays);
 	} else
-		trace_persistent<true, COUNT, false, OccludedQueryPolicy, false, WIDE8 ? 8 : (WIDE ? 4 : 2)>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+		trace_persistent<true, COUNT, false, OccludedQueryPolicy, false, WIDE8 ? 8 : (WIDE ? 4 : 2)>(S, pol, n, work + 16, 0.0f, tuning, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, float t_min, int refillMin, int* objOut, float* tOut, uint* spill, int* work, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK) k_primary_hits(DScene S, DCamera C, float t_min, int tuning, int* objOut, float* tOut, uint* spill, int* work, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
 	PrimaryPolicy pol{ S, C, objOut, tOut };
-	trace_persistent<false, COUNT, true>(S, pol, C.width * C.height, work + 16, t_min, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, COUNT, true>(S, pol, C.width * C.height, work + 16, t_min, tuning, ldsStack, spill, &work[1], lc, rays);
 	if (COUNT) flush_counters(counters, lc, rays, 0);
 }
 

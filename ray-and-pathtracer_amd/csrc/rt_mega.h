@@ -534,17 +534,17 @@ struct WhittedLevelPolicy {
 #ifndef RT_MEGA_WAVES
 #define RT_MEGA_WAVES 4 // measured: 3 waves (no spill) and 5 are slower, profiles/r03_tick_mega.txt
 #endif
-__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene S, DCamera C, RenderParams R, MegaState M, int refillMin, uint* spill, int* work)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_mega(DScene S, DCamera C, RenderParams R, MegaState M, int tuning, uint* spill, int* work)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
 	WhittedMegaPolicy pol{ S, C, R, M, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1] };
-	trace_persistent<false, false, false, WhittedMegaPolicy, true>(S, pol, M.nWork, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, false, false, WhittedMegaPolicy, true>(S, pol, M.nWork, work + 16, 0.0f, tuning, ldsStack, spill, &work[1], lc, rays);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScene S, DCamera C, RenderParams R, MegaState M, LevelState V, int refillMin, uint* spill, int* work)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScene S, DCamera C, RenderParams R, MegaState M, LevelState V, int tuning, uint* spill, int* work)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	__shared__ int reservation[RT_BLOCK / 64][2];
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MEGA_WAVES) k_whitted_level(DScen
 	if ((threadIdx.x & 63) == 0) res[0] = 0, res[1] = 0;
 	WhittedLevelPolicy pol{ S, C, R, M, V, (int)(blockIdx.x * blockDim.x + threadIdx.x), &work[1], res };
 	const int n = V.level == 0 ? M.nWork : (V.count[V.level] < V.qcap ? V.count[V.level] : V.qcap);
-	trace_persistent<false, false, false, WhittedLevelPolicy, true>(S, pol, n, work + 16, 0.0f, refillMin, ldsStack, spill, &work[1], lc, rays);
+	trace_persistent<false, false, false, WhittedLevelPolicy, true>(S, pol, n, work + 16, 0.0f, tuning, ldsStack, spill, &work[1], lc, rays);
 	// the slots this wave reserved and did not fill are nothing to trace
 	const int lo = res[0] + (int)(threadIdx.x & 63), hi = res[1];
 	if (lo < hi && lo < V.qcap) V.seg[(V.level + 1) & 1][4 * (size_t)lo] = make_float4(0, 0, 0, __int_as_float(-1));

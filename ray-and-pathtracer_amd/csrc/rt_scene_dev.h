@@ -353,7 +353,7 @@ static_assert(RT_LEAF_BIT == 0x80000000u && RT_INST_BIT == 0x40000000u && RT_LIN
 #define RT_PAIR_REPEAT 5 // pair steps per iteration at most (unrolled; 4 through round 4: five fit since the kernel has registers to spare, profiles/r04_sweep_repeat.txt)
 #endif
 #ifndef RT_CONNECT_REPEAT
-#define RT_CONNECT_REPEAT 6 // the same for a launch of any-hit queries only (six spill in the nearest-hit kernel at its 72 registers)
+#define RT_CONNECT_REPEAT 6 // the same for a launch of any-hit queries only (5-8 repeats are within the noise: profiles/r04_sweep_repeat.txt)
 #endif
 #define RT_HEAD_STRIDE 1024 // ints between two heads
 #ifndef RT_HEADS_PROBE
@@ -426,7 +426,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	constexpr int stepMinXformBusy = RT_STEPMIN_XFORM ? RT_STEPMIN_XFORM : stepMinBusy; // entry / exit: arithmetic and LDS only when the TLAS is in LDS
 	constexpr int drainLanes = ANYQ ? RT_DRAIN_LANES_ANY : RT_DRAIN_LANES;
 	// (lane and the bits below it are recomputed where they are used: two instructions there instead of three registers kept live
-	// across the hottest loop of the library, which has none to spare at seven waves per SIMD)
+	// across the hottest loop of the library, which runs at eight waves per SIMD: 64 registers)
 #define lane (threadIdx.x & 63)
 	auto bits_below = [](unsigned long long m) __attribute__((always_inline)) { return (int)__builtin_amdgcn_mbcnt_hi((uint)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint)m, 0u)); }; // set bits of m below this lane
 	// sub-queue h = [h * subLen, (h + 1) * subLen) cut at n; all of this is wave-uniform (SGPRs)

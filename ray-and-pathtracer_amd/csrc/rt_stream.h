@@ -262,14 +262,14 @@ struct StreamExtendPolicy {
 	}
 };
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S, StreamState T, int parity, int last, float t_min, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S, StreamState T, int parity, int last, float t_min, int tuning, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
 	StreamExtendPolicy pol{ S, T, parity, last, &T.counts[SC_FLAG] };
-	trace_persistent<false, COUNT, false>(S, pol, T.counts[SC_TRACE], T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+	trace_persistent<false, COUNT, false>(S, pol, T.counts[SC_TRACE], T.heads, t_min, tuning, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) {
 		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
 		flush_counters(counters, lc, rays, 0);
@@ -559,7 +559,7 @@ struct StreamConnectPolicy {
 	__device__ __forceinline__ void leftover(int work) const { T.leftover[atomicAdd(&T.counts[SC_LEFTOVER], 1)] = (uint)work; }
 };
 template <bool COUNT, bool WIDE = false, bool LISTED = false, bool WIDE8 = false>
-__global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene S, StreamState T, int round, int refillMin, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene S, StreamState T, int round, int tuning, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
@@ -570,9 +570,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene
 	int* heads = T.heads + RT_HEADS * RT_HEAD_STRIDE;
 	if constexpr (LISTED) {
 		ListedPolicy<StreamConnectPolicy> lp{ pol, T.leftover };
-		trace_persistent<true, COUNT, false, ListedPolicy<StreamConnectPolicy>>(S, lp, T.counts[SC_LEFTOVER], heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+		trace_persistent<true, COUNT, false, ListedPolicy<StreamConnectPolicy>>(S, lp, T.counts[SC_LEFTOVER], heads, 0.0f, tuning, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	} else
-		trace_persistent<true, COUNT, false, StreamConnectPolicy, false, WIDE8 ? 8 : (WIDE ? 4 : 2)>(S, pol, nShadow * S.nLights, heads, 0.0f, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+		trace_persistent<true, COUNT, false, StreamConnectPolicy, false, WIDE8 ? 8 : (WIDE ? 4 : 2)>(S, pol, nShadow * S.nLights, heads, 0.0f, tuning, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) flush_counters(counters, lc, 0, rays);
 }
 
@@ -595,7 +595,7 @@ struct StreamTraversePolicy {
 	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& O, const f3& D) const { ext.store(work, hit, O, D); }
 	__device__ __forceinline__ void store(int work, bool occluded) const { con.store(work - nTrace, occluded); }
 };
-__global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DScene S, StreamState T, int round, int last, float t_min, int refillMin, uint* spill)
+__global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DScene S, StreamState T, int round, int last, float t_min, int tuning, uint* spill)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DSce
 	uint rays = 0;
 	const int nTrace = T.counts[SC_TRACE], nShadow = T.counts[SC_SHADOW + (round + 2) % 3]; // the shadow records of round - 1
 	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG] }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] }, nTrace };
-	trace_persistent<false, false, false, StreamTraversePolicy, true>(S, pol, nTrace + nShadow * S.nLights, T.heads, t_min, refillMin, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+	trace_persistent<false, false, false, StreamTraversePolicy, true>(S, pol, nTrace + nShadow * S.nLights, T.heads, t_min, tuning, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 }
 
 // light: the direct-light terms of a diffuse hit, in light order (renderer.cpp:158-176: occlusion test first, scatter
