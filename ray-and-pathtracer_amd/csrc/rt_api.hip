@@ -70,6 +70,7 @@ struct rt_ctx {
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
 	int carryLag = 2;        // RT_CARRY: times a path's ray may be parked at the end of an extend launch and resumed by the next (rt_stream.h "Carry"); 0: every launch walks its longest ray home
 	int carryK = 16;         // RT_CARRY_K: steps a ray still makes after its wave's queue ran dry before it is parked
+	int carryFirst = 1;      // RT_CARRY_FIRST: a wave walks the rays it resumed to their end before it takes anything from the queue
 	unsigned long long carryParked = 0, carryBatches = 0; // rt_carry_stats
 	int gridCarry = 0;       // blocks of the launches that park and resume (k_extend_s<false>, k_traverse_s): the same grid, a park list entry per lane
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
@@ -146,7 +147,7 @@ static void free_pool(std::vector<void*>& pool)
 	pool.clear();
 }
 
-static int tuning(const rt_ctx* c) { return c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0; } // the traversal kernels' one launch-time flag (the thresholds are constants: rt_scene_dev.h)
+static int tuning(const rt_ctx* c) { return (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->carryFirst ? RT_TUNE_RESUME_FIRST : 0); } // the traversal kernels' one launch-time flag (the thresholds are constants: rt_scene_dev.h)
 
 // ---- profiling helpers ---------------------------------------------------------------------
 enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_CONNECT, K_QUERY };
@@ -289,6 +290,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0 one kernel at a time, 1 one traversal launch per round, 2 connect + light on a second stream; negative: the default by batch size
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
 	if (getenv("RT_CARRY")) { const int v = atoi(getenv("RT_CARRY")); c->carryLag = v < 0 ? 0 : (v > 3 ? 3 : v); } // two bits of the class byte
+	if (getenv("RT_CARRY_FIRST")) c->carryFirst = atoi(getenv("RT_CARRY_FIRST")) != 0;
 	if (getenv("RT_CARRY_K")) { const int v = atoi(getenv("RT_CARRY_K")); c->carryK = v < 0 ? 0 : v; }
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;

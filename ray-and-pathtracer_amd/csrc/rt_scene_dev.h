@@ -312,7 +312,8 @@ static_assert(RT_LEAF_BIT == 0x80000000u && RT_INST_BIT == 0x40000000u && RT_LIN
 // each (4 KB apart: separate L2 channels); a wave reserves from its home sub-queue, sizes the
 // reservation by what is left there (256 entries early on, 64 near the end), and moves on to the other
 // sub-queues when its own is empty.
-#define RT_TUNE_CULL_COUNTED 0x10000 // the one bit of a traversal kernel's 'tuning' argument: a counting launch drops unreachable TLAS children like a timed one
+#define RT_TUNE_CULL_COUNTED 0x10000 // bit of a traversal kernel's 'tuning' argument: a counting launch drops unreachable TLAS children like a timed one
+#define RT_TUNE_RESUME_FIRST 0x20000 // carry: a wave walks the rays it resumed to their end, alone and at raised priority, before it takes anything from the queue
 // The scheduling thresholds of trace_persistent are compile-time constants (they were launch arguments, and environment variables on
 // the host, through round 4's sweeps: every sweep since round 2 came out flat around these values, and as constants they leave the
 // kernels five scalar registers and their selects -- k_extend_s -2.7 %, profiles/r04_ab_fixed_tuning.txt).  A sweep is a rebuild:
@@ -532,6 +533,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		}
 	};
 	// ---- the rays the launch before parked go on first (pol_carries) ----
+	bool resumedFirst = false; // wave-uniform
 	if constexpr (CARRIES) {
 		const int nRes = pol.resume_count(); // wave-uniform
 		const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
@@ -569,12 +571,19 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			rD = rcp3(D);
 			clean = ray_is_clean(O, D, rD);
 		}
+		// A resumed ray is one of the launch's longest.  Inside the scheduled machine, beside 63 fresh rays and seven other waves per
+		// SIMD, its steps take three times what a lane alone needs; so the wave walks it home FIRST, in the per-lane loop and at raised
+		// priority, and only then turns to the queue (the other waves hand out its share meanwhile).
+		resumedFirst = (tuning & RT_TUNE_RESUME_FIRST) != 0 && __ballot(work >= 0) != 0;
+		if (resumedFirst) __builtin_amdgcn_s_setprio(3);
 	}
 	// ---- the four kinds of step live in rt_step_*.inc: the code of one step for the lanes enabled where the file is included, on the
 	// lane's state as it is named here (lk: the link the step is for).  Text inclusion, not lambdas: the scheduled machine below and
 	// the drain loop behind it make the same steps, and with closures the compiler's register allocation of the hot loop moved
 	// (k_extend_s: 0 -> 20 bytes of scratch at its 72 registers, which costs 10 % of the kernel; profiles/r04_ab_drain_loop.txt).
+	// (carry: two passes over machine + drain loop when the wave resumed rays -- the first skips the machine)
 	while (true) {
+	if (!(CARRIES && resumedFirst)) while (true) {
 		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
 		bool doneLane = work >= 0 && link == RT_LINK_DONE;
 		unsigned long long freeMask = __ballot(link == RT_LINK_DONE); // lanes that can take a new work item: idle ones (they hold RT_LINK_DONE too) and finished ones
@@ -768,7 +777,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 		// (carry: a lane whose ray may be parked walks park_budget() more steps; if the ray has not ended by then, it is parked)
 		int budget = 0x7FFFFFFF;
 		if constexpr (CARRIES) {
-			if (work >= 0 && link != RT_LINK_DONE && !(MIXED && laneAny) && pol.may_park(work)) budget = pol.park_budget();
+			if (!resumedFirst && work >= 0 && link != RT_LINK_DONE && !(MIXED && laneAny) && pol.may_park(work)) budget = pol.park_budget();
 		}
 		while (work >= 0 && link != RT_LINK_DONE && (!CARRIES || budget != 0)) {
 			if constexpr (CARRIES) budget--;
@@ -820,6 +829,16 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			} else if constexpr (ANY) pol.store(work, hit.kind == 1);
 			else { hit.t = rayT; pol.store(work, hit, O, D); }
 		}
+	}
+	if constexpr (CARRIES) {
+		if (resumedFirst) { // the resumed rays are home: now the queue
+			resumedFirst = false;
+			__builtin_amdgcn_s_setprio(0);
+			work = -1, link = RT_LINK_DONE;
+			continue;
+		}
+	}
+	break;
 	}
 #ifdef RT_TAIL_PROBE
 	if (lane == 0) atomicMax(&g_tailProbe[2], __builtin_amdgcn_s_memrealtime());
