@@ -276,12 +276,6 @@ int rt_get_counters_split(rt_ctx* ctx, rt_counters* nearest, rt_counters* occlud
 int rt_set_profiling(rt_ctx* ctx, int profiling);
 int rt_get_profile(rt_ctx* ctx, rt_profile* out, int reset);
 int rt_synchronize(rt_ctx* ctx);
-/* Carry (csrc/rt_stream.h): a traversal launch of the path pipeline parks the rays that are still walking a few steps after its
- * queue ran dry, and the next round's launch resumes them -- the device-side form of renderer.cpp:259's dynamic schedule, in
- * which nothing waits for a straggler before the end of the frame.  parked_out: rays parked since the last reset;
- * batches_out: path batches rendered.  Environment: RT_CARRY = times a path may be parked (0 off, default 2, at most 3),
- * RT_CARRY_K = steps a ray still makes before it is parked (default 16).  Frames do not depend on either. */
-int rt_carry_stats(rt_ctx* ctx, uint64_t* parked_out, uint64_t* batches_out, int reset);
 /* What the library was built with (the -D flags given to the build and the compile-time tuning macros), and the tuning a
  * context resolved from its environment at rt_create (RT_* variables): measurement files are stamped with both, so that
  * counters taken on one build / tuning are not priced against timings of another.  Static / context-owned strings. */

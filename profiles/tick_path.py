@@ -1,5 +1,5 @@
 """One line per scene: a path-mode Renderer::Tick at 1920x1080 without the host mirror (the part the kernels decide), and the
-rays parked per Tick (rt_carry_stats).  Usage (GPU box): [RT_CARRY=.. RT_CARRY_K=.. RT_FUSE=..] python profiles/tick_path.py"""
+rays parked per Tick (rt_carry_stats, when the library has profiles/patches/carry.diff applied).  Usage (GPU box): [RT_CARRY=.. RT_CARRY_K=.. RT_FUSE=..] python profiles/tick_path.py"""
 import sys, time, importlib, os
 sys.path.insert(0, ".")
 ha = importlib.import_module("ray-and-pathtracer_amd.host_api"); scenes = importlib.import_module("ray-and-pathtracer_amd.scenes")
@@ -12,13 +12,14 @@ for name, kw in (("mixed_small", {}), ("pretty_tlas", {"n_instances": 8})):
     r.L.rth_renderer_set_download(r.h, 0)
     for _ in range(8):
         r.tick()
-    r.carry_stats()
+    stats = getattr(r, 'carry_stats', lambda: (0, 1))
+    stats()
     n = 40
     t = time.perf_counter()
     for _ in range(n):
         r.tick()
     dt = (time.perf_counter() - t) / n
-    parked, batches = r.carry_stats()
+    parked, batches = stats()
     r.set_profiling(True); r.profile()
     for _ in range(5):
         r.tick()

@@ -68,11 +68,6 @@ struct rt_ctx {
 	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
 	hipEvent_t gatherDone = nullptr; // rt_gather_rows with this context as the source: its rows have arrived at the destination
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
-	int carryLag = 2;        // RT_CARRY: times a path's ray may be parked at the end of an extend launch and resumed by the next (rt_stream.h "Carry"); 0: every launch walks its longest ray home
-	int carryK = 16;         // RT_CARRY_K: steps a ray still makes after its wave's queue ran dry before it is parked
-	int carryFirst = 1;      // RT_CARRY_FIRST: a wave walks the rays it resumed to their end before it takes anything from the queue
-	unsigned long long carryParked = 0, carryBatches = 0; // rt_carry_stats
-	int gridCarry = 0;       // blocks of the launches that park and resume (k_extend_s<false>, k_traverse_s): the same grid, a park list entry per lane
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
 	std::vector<void*> megaAllocs;
@@ -147,7 +142,7 @@ static void free_pool(std::vector<void*>& pool)
 	pool.clear();
 }
 
-static int tuning(const rt_ctx* c) { return (c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0) | (c->carryFirst ? RT_TUNE_RESUME_FIRST : 0); } // the traversal kernels' one launch-time flag (the thresholds are constants: rt_scene_dev.h)
+static int tuning(const rt_ctx* c) { return c->counting == RT_COUNT_EXECUTED ? RT_TUNE_CULL_COUNTED : 0; } // the traversal kernels' one launch-time flag (the thresholds are constants: rt_scene_dev.h)
 
 // ---- profiling helpers ---------------------------------------------------------------------
 enum { K_GENERATE = 0, K_EXTEND, K_SHADE, K_CONNECT, K_QUERY };
@@ -289,9 +284,6 @@ rt_ctx* rt_create(int device, int width, int height)
 	memset(&c->slot.P, 0, sizeof(PathState)), memset(&c->slot.Q, 0, sizeof(Queues));
 	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0 one kernel at a time, 1 one traversal launch per round, 2 connect + light on a second stream; negative: the default by batch size
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
-	if (getenv("RT_CARRY")) { const int v = atoi(getenv("RT_CARRY")); c->carryLag = v < 0 ? 0 : (v > 3 ? 3 : v); } // two bits of the class byte
-	if (getenv("RT_CARRY_FIRST")) c->carryFirst = atoi(getenv("RT_CARRY_FIRST")) != 0;
-	if (getenv("RT_CARRY_K")) { const int v = atoi(getenv("RT_CARRY_K")); c->carryK = v < 0 ? 0 : v; }
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
 	if (getenv("RT_MEGA_LPT")) c->megaLpt = atoi(getenv("RT_MEGA_LPT")) != 0;
@@ -325,7 +317,6 @@ rt_ctx* rt_create(int device, int width, int height)
 		c->gridLeftoverS = std::min(resident((const void*)k_connect_s<false, false, true>), prop.multiProcessorCount);
 		c->gridConnectWide8S = resident((const void*)k_connect_s<false, false, false, true>);
 		c->gridTraverseS = resident((const void*)k_traverse_s);
-		c->gridCarry = std::min(resident((const void*)k_extend_s<false>), c->gridTraverseS);
 		c->gridMega = resident((const void*)k_whitted_mega);
 		c->gridLevel = resident((const void*)k_whitted_level);
 		c->gridShadeS = std::min(resident((const void*)k_shade_s<false>), resident((const void*)k_shade_s<true>));
@@ -1311,7 +1302,6 @@ static int run_rounds(rt_ctx* c, const RenderParams& R, int maxRounds, int known
 			if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 			else if (hc[3] == 2) rc = fail(c, RT_E_OVERFLOW, "more than %d pending Whitted branches in one pixel", RT_PEND_CAP);
 			else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
-	else if (hc[3] == 198) rc = fail(c, RT_E_STATE, "a traversal launch parked more rays than its grid has lanes");
 			else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
 			if (hc[3] != 0) (void)hipMemsetAsync(Q.counts + 3, 0, sizeof(int), st);
 			if (rc != RT_OK || hc[0] == 0 || knownRounds > 0) break;
@@ -1525,13 +1515,6 @@ static int ensure_stream_state(rt_ctx* c, int n)
 	HIPCHK(c, dalloc(A, &T.heads, (size_t)2 * RT_HEADS * RT_HEAD_STRIDE));
 	HIPCHK(c, hipMemset(T.counts, 0, 16 * sizeof(int)));
 	T.cap = (int)cap;
-	// carry: a lane parks at most one ray per launch, and the next launch of the same grid resumes record i in lane i / waves of wave i % waves
-	T.parkCap = c->gridCarry * RT_BLOCK;
-	for (int b = 0; b < 2; b++) {
-		HIPCHK(c, dalloc(A, &T.parkHdr[b], (size_t)T.parkCap));
-		HIPCHK(c, dalloc(A, &T.parkEntry[b], (size_t)T.parkCap));
-		HIPCHK(c, dalloc(A, &T.parkStack[b], (size_t)T.parkCap * RT_STACK_MAX));
-	}
 	c->T = T;
 	c->streamCap = (int)cap, c->streamLights = c->S.nLights, c->streamWide = wide;
 	return RT_OK;
@@ -1579,40 +1562,34 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	hipStream_t st = c->stream, sb = twoStreams ? c->streamSide : c->stream;
 	const int cnt = c->counting ? 1 : 0;
 	const int n = (int)R.nSamples;
-	// carry (rt_stream.h): extend parks the rays that are still walking carryK steps after their wave's queue ran dry, the next round's
-	// launch resumes them beside its own rays; a path is parked at most maxLag times, so maxLag more (nearly empty) rounds see every
-	// path home.  Counting launches walk every ray to its end in its own launch (the tallies are per launch).
-	const int maxLag = c->counting ? 0 : c->carryLag, carryK = maxLag > 0 ? c->carryK : -1;
-	const int roundsRun = rounds + maxLag;
 	prof_begin(c, K_GENERATE, st);
 	hipLaunchKernelGGL(k_generate_s, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, rounds == 1 ? 1 : 0, c->decideRays, cnt);
 	prof_end(c, st);
 	bool pendingJoin = false;
-	for (int round = 0; round < roundsRun; round++) {
-		const int roundsLeft = rounds - 1 - round; // 0: the hits of a path that is not behind are at depth 0 (negative: only paths that are behind are left)
-		const bool last = round + 1 == roundsRun;
+	for (int round = 0; round < rounds; round++) {
+		const int last = round + 1 == rounds ? 1 : 0, lastNext = round + 2 == rounds ? 1 : 0;
 		hipLaunchKernelGGL(k_compact_s, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 #ifdef RT_TAIL_PROBE
 		tail_probe_reset(st);
 #endif
 		prof_begin(c, K_EXTEND, st);
-		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridCarry), dim3(RT_BLOCK), 0, st, c->S, T, round, roundsLeft, t_min, tuning(c), carryK, maxLag, c->spill);
-		else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round, roundsLeft, t_min, tuning(c), -1, 0, c->spill, c->counters);
-		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridCarry), dim3(RT_BLOCK), 0, st, c->S, T, round, roundsLeft, t_min, tuning(c), carryK, maxLag, c->spill, c->counters);
+		if (mixed && round > 0) hipLaunchKernelGGL(k_traverse_s, dim3(c->gridTraverseS), dim3(RT_BLOCK), 0, st, c->S, T, round, last, t_min, tuning(c), c->spill);
+		else if (c->counting) hipLaunchKernelGGL((k_extend_s<true>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c), c->spill, c->counters);
+		else hipLaunchKernelGGL((k_extend_s<false>), dim3(c->gridExtendS), dim3(RT_BLOCK), 0, st, c->S, T, round & 1, last, t_min, tuning(c), c->spill, c->counters);
 		prof_end(c, st);
 #ifdef RT_TAIL_PROBE
 		tail_probe_print(st, "extend_s", round);
 #endif
 		if (mixed && round > 0) { // the shadow answers of the round before came with this round's hits
 			prof_begin(c, K_SHADE, st);
-			hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, st, c->S, R, T, round - 1, c->shadeLds);
+			hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, st, c->S, R, T, round - 1, 0, c->shadeLds);
 			prof_end(c, st);
 		}
 		hipLaunchKernelGGL(k_assign, dim3(grid / 2), dim3(RT_COMPACT_BLOCK), 0, st, T, round);
 		if (pendingJoin) { HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0)); pendingJoin = false; }
 		prof_begin(c, K_SHADE, st);
-		if (c->Qt.on) hipLaunchKernelGGL(k_shade_s<true>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, roundsLeft, c->decideRays, c->shadeLds, cnt, c->Qt);
-		else hipLaunchKernelGGL(k_shade_s<false>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, roundsLeft, c->decideRays, c->shadeLds, cnt, c->Qt);
+		if (c->Qt.on) hipLaunchKernelGGL(k_shade_s<true>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt, c->Qt);
+		else hipLaunchKernelGGL(k_shade_s<false>, dim3(c->gridShadeS), dim3(RT_BLOCK), 0, st, c->S, c->C, R, T, round, round == 0 ? 1 : 0, last, lastNext, c->decideRays, c->shadeLds, cnt, c->Qt);
 		prof_end(c, st);
 		if (mixed && !last) continue; // this round's shadow rays ride in the next round's traversal launch
 		if (twoStreams) {
@@ -1623,21 +1600,18 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 		launch_connect_s(c, sb, T, round, twoStreams ? c->streamSideSpill : c->spill);
 		prof_end(c, sb);
 		prof_begin(c, K_SHADE, sb);
-		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, round, c->shadeLds);
+		hipLaunchKernelGGL(k_light_s, dim3(c->gridLightS), dim3(RT_BLOCK), 0, sb, c->S, R, T, round, last, c->shadeLds);
 		prof_end(c, sb);
 		if (twoStreams) { HIPCHK(c, hipEventRecord(c->streamJoin, sb)); pendingJoin = true; }
 	}
 	if (pendingJoin) HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0));
 	if (cnt) hipLaunchKernelGGL(k_fold_decided, dim3(1), dim3(1), 0, st, c->S, T.counts, c->counters);
-	HIPCHK(c, hipMemcpyAsync(c->hostCounts, T.counts, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
-	if (maxLag > 0) HIPCHK(c, hipMemsetAsync(T.counts + SC_PARKED, 0, sizeof(int), st));
+	HIPCHK(c, hipMemcpyAsync(c->hostCounts, T.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
 	HIPCHK(c, hipStreamSynchronize(st));
 	const int* hc = c->hostCounts;
-	c->carryParked += (unsigned)hc[SC_PARKED], c->carryBatches++;
 	int rc = RT_OK;
 	if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 	else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
-	else if (hc[3] == 198) rc = fail(c, RT_E_STATE, "a traversal launch parked more rays than its grid has lanes");
 	else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
 	if (hc[3] != 0) (void)hipMemsetAsync(T.counts + 3, 0, sizeof(int), st);
 	if (rc != RT_OK) return rc;
@@ -2218,21 +2192,12 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d carry=%d carry_k=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
-	         c->useStream, c->carryLag, c->carryK, c->decideRays, c->fuseTraversal, RT_REFILL, RT_REFILL_ANY, RT_STEPMIN, RT_STEPMIN_ANY, RT_STEPMIN_XFORM,
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	         c->useStream, c->decideRays, c->fuseTraversal, RT_REFILL, RT_REFILL_ANY, RT_STEPMIN, RT_STEPMIN_ANY, RT_STEPMIN_XFORM,
 	         RT_PAIRAGAIN, RT_PAIRAGAIN_ANY, RT_DRAIN_LANES, RT_DRAIN_LANES_ANY, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();
-}
-
-int rt_carry_stats(rt_ctx* c, uint64_t* parked_out, uint64_t* batches_out, int reset)
-{
-	if (!c) return RT_E_ARG;
-	if (parked_out) *parked_out = c->carryParked;
-	if (batches_out) *batches_out = c->carryBatches;
-	if (reset) c->carryParked = c->carryBatches = 0;
-	return RT_OK;
 }
 
 int rt_synchronize(rt_ctx* c)

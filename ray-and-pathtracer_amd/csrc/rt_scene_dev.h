@@ -195,8 +195,6 @@ struct Stack {
 		if (__builtin_expect(sp < rows, 1)) return lds[sp * RT_BLOCK];
 		return spill[spill_at(sp - rows)];
 	}
-	// entry j of the stack, 0 = the bottom (a ray that is parked takes its stack along: trace_persistent "carry")
-	__device__ __forceinline__ uint peek(uint j) const { return j < rows ? (uint)lds[j * RT_BLOCK] : (uint)spill[spill_at(j - rows)]; }
 };
 
 __device__ __forceinline__ Stack make_stack(uint* ldsBase, uint* spill, int* overflow, uint rows = RT_STACK_ROWS_MAX)
@@ -312,8 +310,7 @@ static_assert(RT_LEAF_BIT == 0x80000000u && RT_INST_BIT == 0x40000000u && RT_LIN
 // each (4 KB apart: separate L2 channels); a wave reserves from its home sub-queue, sizes the
 // reservation by what is left there (256 entries early on, 64 near the end), and moves on to the other
 // sub-queues when its own is empty.
-#define RT_TUNE_CULL_COUNTED 0x10000 // bit of a traversal kernel's 'tuning' argument: a counting launch drops unreachable TLAS children like a timed one
-#define RT_TUNE_RESUME_FIRST 0x20000 // carry: a wave walks the rays it resumed to their end, alone and at raised priority, before it takes anything from the queue
+#define RT_TUNE_CULL_COUNTED 0x10000 // the one bit of a traversal kernel's 'tuning' argument: a counting launch drops unreachable TLAS children like a timed one
 // The scheduling thresholds of trace_persistent are compile-time constants (they were launch arguments, and environment variables on
 // the host, through round 4's sweeps: every sweep since round 2 came out flat around these values, and as constants they leave the
 // kernels five scalar registers and their selects -- k_extend_s -2.7 %, profiles/r04_ab_fixed_tuning.txt).  A sweep is a rebuild:
@@ -406,19 +403,6 @@ template <class P, class = void> struct pol_starts_done { static constexpr bool 
 template <class P> struct pol_starts_done<P, decltype((void)&P::starts_done)> { static constexpr bool value = true; };
 template <class P, class = void> struct pol_advances { static constexpr bool value = false; };
 template <class P> struct pol_advances<P, decltype((void)P::kAdvance)> { static constexpr bool value = P::kAdvance; };
-// A policy with 'static constexpr bool kCarries = true' lets a launch END before its longest rays do (rt_stream.h "carry"): once a
-// wave's queue is dry, a lane whose nearest-hit ray has made park_budget() more steps PARKS it -- link, ray.t, the candidate hit, the
-// instance it is in and its stack go to a park record, the policy marks the ray's entry -- and the next launch of the same grid
-// RESUMES it before it takes anything from its queue: item i of the list goes to lane i / waves of wave i % waves (the long rays
-// spread over the machine), the same registers and stack words, the object-space ray recomputed from the world ray by the
-// expressions of the instance-entry step.  A resumed ray makes exactly the steps it would have made: same bits.  The policy offers
-//   int  resume_count()                                   park records of the launch before
-//   int  resume(int i, f3& O, f3& D, uint4& hdr)          world ray + record header of item i (stack words: park_word(i, j))
-//   bool may_park(int work), int park_budget(), int* park_counter(), int park_cap(), void park_note(int parked)
-//   void park(int work, int k, const uint4& hdr), void park_word(int k, uint j, uint v) / uint park_word(int i, uint j)
-// and work numbers >= n name resumed rays (n + i).
-template <class P, class = void> struct pol_carries { static constexpr bool value = false; };
-template <class P> struct pol_carries<P, decltype((void)P::kCarries)> { static constexpr bool value = P::kCarries; };
 // 'static constexpr int kRefill': the policy's own refill threshold (the Whitted launches hand out tiles, not rays)
 template <class P, class = void> struct pol_refill { static constexpr int value = 0; };
 template <class P> struct pol_refill<P, decltype((void)P::kRefill)> { static constexpr int value = P::kRefill; };
@@ -435,8 +419,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	constexpr bool ANYWIDE = WIDE || WIDE8; // a wide walk: rays that are not clean go back to the binary walk
 	constexpr int REPEAT = ANY && !MIXED ? RT_CONNECT_REPEAT : RT_PAIR_REPEAT; // pair steps per iteration at most
 	constexpr bool DRAINS = !ANYWIDE && !pol_advances<Policy>::value && !RT_NO_DRAIN_LOOP; // the last rays of a wave leave the machine for a plain per-lane loop
-	constexpr bool CARRIES = pol_carries<Policy>::value; // ... and may be parked there for the next launch to resume (see pol_carries)
-	static_assert(!CARRIES || (DRAINS && !COUNT), "rays are parked in the drain loop; a counting launch walks every ray to its end");
 	const float bvh_t_min = 0.0001f; // bvh.cpp:607, :764
 	constexpr bool ANYQ = ANY && !MIXED; // a launch of any-hit queries only
 	constexpr int refillMin = pol_refill<Policy>::value ? pol_refill<Policy>::value : (ANYQ ? RT_REFILL_ANY : RT_REFILL);
@@ -532,58 +514,11 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			else link = lk + 1;
 		}
 	};
-	// ---- the rays the launch before parked go on first (pol_carries) ----
-	bool resumedFirst = false; // wave-uniform
-	if constexpr (CARRIES) {
-		const int nRes = pol.resume_count(); // wave-uniform
-		const int nWaves = (int)((gridDim.x * blockDim.x) >> 6);
-		const int item = (int)lane * nWaves + waveId;
-		if (item < nRes) {
-			uint4 hdr;
-			pol.resume(item, O, D, hdr);
-			work = n + item;
-			link = hdr.x, rayT = __uint_as_float(hdr.y);
-			hit.prim = hdr.z, hit.kind = (int)(hdr.w & 3u) - 1, hit.inst = (int)((hdr.w >> 2) & 0x1FFu) - 1;
-			inst = (int)((hdr.w >> 11) & 0x1FFu) - 1;
-			const uint depth = hdr.w >> 20;
-			RT_CHECK(depth <= RT_STACK_MAX && inst < 256, 6, overflow);
-			for (uint j = 0; j < depth; j++) st.push(pol.park_word(item, j));
-			if constexpr (MIXED) laneAny = false;
-			if (inst >= 0) {
-				// inside an instance: the object-space ray by the expressions of the entry step (rt_step_enter.inc), on the same operands
-				float invT[12];
-				if (S.tlasLds) {
-					const lds_v4f* I = tlasL + 7 * S.tlasPairs + 3 * inst;
-					const v4f m0 = I[0], m1 = I[1], m2 = I[2];
-					invT[0] = m0.x, invT[1] = m0.y, invT[2] = m0.z, invT[3] = m0.w, invT[4] = m1.x, invT[5] = m1.y, invT[6] = m1.z, invT[7] = m1.w;
-					invT[8] = m2.x, invT[9] = m2.y, invT[10] = m2.z, invT[11] = m2.w;
-				} else {
-					const DInstance* I = S.inst + inst;
-#pragma unroll
-					for (int k = 0; k < 12; k++) invT[k] = I->invT[k];
-				}
-				worldRay[0 * RT_BLOCK] = __float_as_uint(O.x), worldRay[1 * RT_BLOCK] = __float_as_uint(O.y), worldRay[2 * RT_BLOCK] = __float_as_uint(O.z);
-				worldRay[3 * RT_BLOCK] = __float_as_uint(D.x), worldRay[4 * RT_BLOCK] = __float_as_uint(D.y), worldRay[5 * RT_BLOCK] = __float_as_uint(D.z);
-				const f3 Oo = xform_pos(invT, O);
-				const f3 Do = xform_vec(invT, D);
-				O = Oo, D = Do;
-			}
-			rD = rcp3(D);
-			clean = ray_is_clean(O, D, rD);
-		}
-		// A resumed ray is one of the launch's longest.  Inside the scheduled machine, beside 63 fresh rays and seven other waves per
-		// SIMD, its steps take three times what a lane alone needs; so the wave walks it home FIRST, in the per-lane loop and at raised
-		// priority, and only then turns to the queue (the other waves hand out its share meanwhile).
-		resumedFirst = (tuning & RT_TUNE_RESUME_FIRST) != 0 && __ballot(work >= 0) != 0;
-		if (resumedFirst) __builtin_amdgcn_s_setprio(3);
-	}
 	// ---- the four kinds of step live in rt_step_*.inc: the code of one step for the lanes enabled where the file is included, on the
 	// lane's state as it is named here (lk: the link the step is for).  Text inclusion, not lambdas: the scheduled machine below and
 	// the drain loop behind it make the same steps, and with closures the compiler's register allocation of the hot loop moved
 	// (k_extend_s: 0 -> 20 bytes of scratch at its 72 registers, which costs 10 % of the kernel; profiles/r04_ab_drain_loop.txt).
-	// (carry: two passes over machine + drain loop when the wave resumed rays -- the first skips the machine)
 	while (true) {
-	if (!(CARRIES && resumedFirst)) while (true) {
 		// ---- flush finished lanes and refill, once enough lanes have nothing to do ----
 		bool doneLane = work >= 0 && link == RT_LINK_DONE;
 		unsigned long long freeMask = __ballot(link == RT_LINK_DONE); // lanes that can take a new work item: idle ones (they hold RT_LINK_DONE too) and finished ones
@@ -597,7 +532,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 				const unsigned long long secT = RT_SEC_NOW();
 				RT_SEC_COUNT(13);
 				if (doneLane) {
-					RT_CHECK(work >= 0 && (work < n || CARRIES) && st.sp <= RT_STACK_MAX, 4, overflow);
+					RT_CHECK(work >= 0 && work < n && st.sp <= RT_STACK_MAX, 4, overflow);
 #ifdef RT_STEP_COUNT
 					if constexpr (!ANY && !MIXED) { if (g_stepOut) g_stepOut[pol.slot_of(work)] = (nsteps & 0xFFFFu) | (nenter << 16); }
 					nsteps = 0, nenter = 0;
@@ -774,13 +709,7 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 	// BEHIND the loop on purpose: inside it (tried first) the hot loop of k_extend_s went from 0 to 92 bytes of scratch at its 72
 	// registers.  The wide walks and the policies that keep a lane for the next query (advance) stay in the machine.
 	if constexpr (DRAINS) {
-		// (carry: a lane whose ray may be parked walks park_budget() more steps; if the ray has not ended by then, it is parked)
-		int budget = 0x7FFFFFFF;
-		if constexpr (CARRIES) {
-			if (!resumedFirst && work >= 0 && link != RT_LINK_DONE && !(MIXED && laneAny) && pol.may_park(work)) budget = pol.park_budget();
-		}
-		while (work >= 0 && link != RT_LINK_DONE && (!CARRIES || budget != 0)) {
-			if constexpr (CARRIES) budget--;
+		while (work >= 0 && link != RT_LINK_DONE) {
 			const uint lk = link;
 #ifdef RT_STEP_COUNT
 			nsteps++;
@@ -799,26 +728,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 #include "rt_step_enter.inc"
 			} else { *overflow = 199; link = RT_LINK_DONE; } // a link no step understands (a corrupt tree): reported as RT_E_STATE
 		}
-		if constexpr (CARRIES) {
-			const bool parkMe = work >= 0 && link != RT_LINK_DONE; // out of budget
-			const unsigned long long pm = __ballot(parkMe);
-			if (pm != 0) {
-				// one reservation per wave; record k: header, then the stack from the bottom
-				const int leader = __ffsll((long long)pm) - 1;
-				int base = 0;
-				if ((int)lane == leader) { base = atomicAdd(pol.park_counter(), __popcll(pm)); pol.park_note(__popcll(pm)); }
-				base = __shfl(base, leader);
-				const int k = base + bits_below(pm);
-				if (parkMe) {
-					if (k < pol.park_cap()) {
-						const uint4 hdr = make_uint4(link, __float_as_uint(rayT), hit.prim, (uint)(hit.kind + 1) | ((uint)(hit.inst + 1) << 2) | ((uint)(inst + 1) << 11) | (st.sp << 20));
-						pol.park(work, k, hdr);
-						for (uint j = 0; j < st.sp; j++) pol.park_word(k, j, st.peek(j));
-					} else *overflow = 198; // cannot happen: a lane parks at most one ray per launch and the list holds one per lane (the host sizes it)
-					work = -1;
-				}
-			}
-		}
 		if (work >= 0) {
 #ifdef RT_STEP_COUNT
 			if constexpr (!ANY && !MIXED) { if (g_stepOut) g_stepOut[pol.slot_of(work)] = (nsteps & 0xFFFFu) | (nenter << 16); }
@@ -829,16 +738,6 @@ __device__ __forceinline__ void trace_persistent(const DScene& S, Policy& pol, i
 			} else if constexpr (ANY) pol.store(work, hit.kind == 1);
 			else { hit.t = rayT; pol.store(work, hit, O, D); }
 		}
-	}
-	if constexpr (CARRIES) {
-		if (resumedFirst) { // the resumed rays are home: now the queue
-			resumedFirst = false;
-			__builtin_amdgcn_s_setprio(0);
-			work = -1, link = RT_LINK_DONE;
-			continue;
-		}
-	}
-	break;
 	}
 #ifdef RT_TAIL_PROBE
 	if (lane == 0) atomicMax(&g_tailProbe[2], __builtin_amdgcn_s_memrealtime());

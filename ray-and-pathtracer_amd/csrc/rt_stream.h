@@ -20,10 +20,9 @@
 //   connect   Scene::IsOccluded per (shadow record, light)                                    } on a second stream,
 //   light     the direct terms of the shadow records, in light order; updates E and L of the   } beside the next
 //             continuation entry (or stores the sample in the last round)                       } round's extend
-// Path depth is the round's (start depth - round) plus the rounds the path is behind (two bits of the class byte, see
-// "Carry" below; 0 without it), so "depth 0" is a launch argument and a compare, and W.w is free.  The order of entries is
-// the order of samples (frame-major, then pixels) with holes closed: neighbours stay neighbours, which is all the
-// coherence the later rounds have.
+// Path depth is the same for every entry of a round (depth = start depth - round), so "last round" is a launch
+// argument and W.w is free.  The order of entries is the order of samples (frame-major, then pixels) with holes
+// closed: neighbours stay neighbours, which is all the coherence the later rounds have.
 //
 // Producer-side decisions (ray_decided): a kernel that creates a ray (generate, shade) already runs the head tests of
 // Scene::FindNearest on it (lights, brute-force primitives).  It now also makes the FIRST step extend would make -- the
@@ -34,19 +33,6 @@
 // 59 % of the first-bounce rays are of this kind (profiles/r02_step_histogram_spp8.txt: "0 instance entries"); each used
 // to cost a queue slot, a refill in the 42 %-lane traversal kernel, and a ray load + hit store at random addresses.
 // The step is the one trace_persistent makes, on the same operands, so results are identical by construction.
-//
-// Carry: a launch of extend need not end on its longest ray.  The reference's pixel loop is an OpenMP dynamic schedule
-// (renderer.cpp:259): nothing waits for a straggler before the end of the frame.  Here every traversal launch used to: its
-// queue runs dry, most of the machine idles, and the few rays with 200-400 steps walk home at ~0.5 us per step while assign
-// and shade wait (0.3 ms per launch whatever it held: 17 % of the full step's extend, a third of a 1/8 share's, 70 % of a
-// Tick's).  Now a lane of a wave whose queue is dry walks carryK more steps and then PARKS its ray (trace_persistent,
-// pol_carries): the traversal state goes to a park record, the entry gets CL_PARKED | CL_CONT and the record's number in
-// hitId.x.  k_assign gives it a place in round r + 1 like any continuation, shade(r) moves the entry there unshaded (ray, W, E,
-// L; CL_RESUME, lag + 1) and tells the record where it went, and extend(r + 1) resumes the record before it takes anything from
-// its queue -- so the long ray goes on BESIDE the next round's rays.  The path is one round behind from then on: depth is per
-// entry (the round's + lag, two bits of the class byte), a path is parked at most maxLag times, and the round loop runs maxLag
-// rounds longer (nearly empty ones).  Every ray makes the steps it would have made and every path the same draws in the same
-// order; samples are accumulated by (pixel, frame), so frames are bit-identical.  Shadow rays are never parked: light(r) needs them.
 #pragma once
 #include "rt_kernels.h"
 #include "rt_qlearn.h"
@@ -57,9 +43,6 @@ namespace rtd {
 #define CL_LIVE 2   // the entry holds a path (round 0 only: entries of samples finished inside generate are not live)
 #define CL_CONT 4   // the path continues: shade writes a continuation entry at pos.x
 #define CL_SHADOW 8 // diffuse hit with lights: shade writes a shadow record at pos.y
-#define CL_PARKED 16 // extend parked this entry's ray (hitId.x = its park record): shade moves the entry to the next round as it is
-#define CL_RESUME 32 // the entry's ray goes on from a park record in this round's extend; it is not in the traversal queue
-#define CL_LAG_SHIFT 6 // bits 6-7: rounds this path is behind (it was parked that often); its depth is the round's + lag
 
 // counts[] of a StreamState
 #define SC_N 0       // [3] entries of round r at [r % 3]
@@ -68,8 +51,6 @@ namespace rtd {
 #define SC_TRACE 7   // length of the traversal queue
 #define SC_LEFTOVER 8 // shadow rays the 4-wide walk handed back
 #define SC_DECIDED 9 // rays answered by their producer (counting launches)
-#define SC_PARK 10   // [2] park records written by extend(r) at [r & 1]
-#define SC_PARKED 12 // rays parked since the host last looked (rt_carry_stats)
 
 struct StreamState {
 	float4* O[2];     // ray origin xyz, w = ray.t after the head tests        } entry e of round parity p
@@ -92,11 +73,6 @@ struct StreamState {
 	int* heads;       // work heads: extend [0, RT_HEADS), connect [RT_HEADS, 2 RT_HEADS)
 	int* counts;
 	int cap;          // entries the arrays hold
-	// carry (see "Carry" below): the rays extend(r) parked, list r & 1
-	uint4* parkHdr[2];  // [k] link, ray.t, hit.prim, kind + 1 | (hit.inst + 1) << 2 | (inst + 1) << 11 | sp << 20
-	uint* parkStack[2]; // [word][k], the traversal stack from the bottom
-	uint* parkEntry[2]; // [k] the entry of round r + 1 the ray belongs to (shade(r))
-	int parkCap;        // records a list holds: one per lane of the traversal grid
 };
 
 // what the hit decides about the path (path mode; 'last': the round whose hits are at depth 0, renderer.cpp:129)
@@ -200,9 +176,6 @@ __device__ __forceinline__ void prepare_round(const StreamState& T, int next /* 
 	if (blockIdx.x != 0 || threadIdx.x != 0) return;
 	if (n0 >= 0) T.counts[SC_N + next % 3] = n0; // generate: the batch's samples are round 0's entries
 	T.counts[SC_TRACE] = 0, T.counts[SC_N + (next + 1) % 3] = 0, T.counts[SC_SHADOW + next % 3] = 0;
-	// the park list extend(next) writes: extend(next - 1) has resumed what it held (generate: nothing is parked yet)
-	T.counts[SC_PARK + (next & 1)] = 0;
-	if (n0 >= 0) T.counts[SC_PARK + 1] = 0;
 	for (int h = 0; h < RT_HEADS; h++) T.heads[h * RT_HEAD_STRIDE] = 0;
 	// connect of the round before 'next' (it starts after the kernel this runs in)
 	T.counts[SC_LEFTOVER] = 0;
@@ -260,37 +233,24 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_s(DScene S, DCamera C, Re
 }
 
 // extend: Scene::FindNearest for the entries of the traversal queue
-// CARRY: the launch resumes the rays the round before parked and may park its own (see "Carry" above)
-template <bool CARRY>
 struct StreamExtendPolicy {
-	static constexpr bool kCarries = CARRY;
 	const DScene& S;
 	const StreamState& T;
-	int round, roundsLeft; // roundsLeft: rounds after this one in which a path that is not behind still traces (0: its hits are at depth 0, renderer.cpp:129)
-	int nQueue;            // work numbers below name queue entries, from nQueue on resumed rays
-	int carryK, maxLag;
+	int parity, last;
 	int* flag;
-	__device__ __forceinline__ int entry_of(int work) const
-	{
-		if (CARRY && work >= nQueue) return (int)T.parkEntry[(round + 1) & 1][work - nQueue];
-		return (int)ld_stream(T.traceQ + work);
-	}
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
 	{
 		const int e = (int)ld_stream(T.traceQ + work);
 		RT_CHECK(e >= 0 && e < T.cap, 20, flag);
-		const float4 o4 = ld_stream(T.O[round & 1] + e), d4 = ld_stream(T.D[round & 1] + e);
+		const float4 o4 = ld_stream(T.O[parity] + e), d4 = ld_stream(T.D[parity] + e);
 		O = xyz(o4), D = xyz(d4), tmax = o4.w;
 		unpack_head(__float_as_uint(d4.w), head);
 		return true;
 	}
-	__device__ __forceinline__ int slot_of(int work) const { return entry_of(work); }
+	__device__ __forceinline__ int slot_of(int work) const { return (int)T.traceQ[work]; }
 	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& /*O*/, const f3& /*D*/) const
 	{
-		const int parity = round & 1;
-		const int e = entry_of(work);
-		const uint lagBits = T.cls[parity][e] & (3u << CL_LAG_SHIFT);
-		const int last = roundsLeft + (int)(lagBits >> CL_LAG_SHIFT) == 0 ? 1 : 0;
+		const int e = (int)ld_stream(T.traceQ + work);
 		int objIdx, mat, matType;
 		f3 normal;
 		const StreamState& Tc = T;
@@ -298,44 +258,18 @@ struct StreamExtendPolicy {
 		resolve_hit_lazy(S, hit, [&](f3& o, f3& d) { o = xyz(ld_stream(Tc.O[par] + e)), d = xyz(ld_stream(Tc.D[par] + e)); }, objIdx, mat, normal, &matType);
 		st_stream(T.hitN[parity] + e, mk4(normal, hit.t));
 		st_stream(T.hitId[parity] + e, make_int2(objIdx, mat));
-		T.cls[parity][e] = (unsigned char)(lagBits | CL_LIVE | CL_TRACE | hit_class(S, objIdx, mat, last, matType)); // the record said what its material is: no second fetch
+		T.cls[parity][e] = (unsigned char)(CL_LIVE | CL_TRACE | hit_class(S, objIdx, mat, last, matType)); // the record said what its material is: no second fetch
 	}
-	// ---- carry (trace_persistent, pol_carries) ----
-	__device__ __forceinline__ int resume_count() const { return T.counts[SC_PARK + ((round + 1) & 1)]; } // what extend(round - 1) parked
-	__device__ __forceinline__ void resume(int i, f3& O, f3& D, uint4& hdr) const
-	{
-		const int lst = (round + 1) & 1;
-		const int e = (int)T.parkEntry[lst][i];
-		RT_CHECK(e >= 0 && e < T.cap, 25, flag);
-		O = xyz(T.O[round & 1][e]), D = xyz(T.D[round & 1][e]); // the world-space ray: shade(round - 1) moved the entry here
-		hdr = T.parkHdr[lst][i];
-	}
-	__device__ __forceinline__ uint park_word(int i, uint j) const { return T.parkStack[(round + 1) & 1][(size_t)j * (size_t)T.parkCap + (size_t)i]; }
-	__device__ __forceinline__ bool may_park(int work) const { return carryK >= 0 && (int)(T.cls[round & 1][entry_of(work)] >> CL_LAG_SHIFT) < maxLag; }
-	__device__ __forceinline__ int park_budget() const { return carryK; }
-	__device__ __forceinline__ int* park_counter() const { return &T.counts[SC_PARK + (round & 1)]; }
-	__device__ __forceinline__ int park_cap() const { return T.parkCap; }
-	__device__ __forceinline__ void park_note(int parked) const { atomicAdd(&T.counts[SC_PARKED], parked); }
-	__device__ __forceinline__ void park(int work, int k, const uint4& hdr) const
-	{
-		const int parity = round & 1;
-		const int e = entry_of(work);
-		T.parkHdr[parity][k] = hdr;
-		T.hitId[parity][e] = make_int2(k, -1);
-		T.cls[parity][e] = (unsigned char)((T.cls[parity][e] & (3u << CL_LAG_SHIFT)) | CL_LIVE | CL_PARKED | CL_CONT);
-	}
-	__device__ __forceinline__ void park_word(int k, uint j, uint v) const { T.parkStack[round & 1][(size_t)j * (size_t)T.parkCap + (size_t)k] = v; }
 };
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S, StreamState T, int round, int roundsLeft, float t_min, int tuning, int carryK, int maxLag, uint* spill, DCounters* counters)
+__global__ void __launch_bounds__(RT_BLOCK, RT_EXTEND_WAVES) k_extend_s(DScene S, StreamState T, int parity, int last, float t_min, int tuning, uint* spill, DCounters* counters)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
-	const int nTrace = T.counts[SC_TRACE];
-	StreamExtendPolicy<!COUNT> pol{ S, T, round, roundsLeft, nTrace, carryK, maxLag, &T.counts[SC_FLAG] };
-	trace_persistent<false, COUNT, false>(S, pol, nTrace, T.heads, t_min, tuning, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+	StreamExtendPolicy pol{ S, T, parity, last, &T.counts[SC_FLAG] };
+	trace_persistent<false, COUNT, false>(S, pol, T.counts[SC_TRACE], T.heads, t_min, tuning, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 	if (COUNT) {
 		lc.light = rays * (uint)S.nLights, lc.brute = S.useTLAS ? rays * (uint)(S.nBruteSph + S.nBrutePla) : 0;
 		flush_counters(counters, lc, rays, 0);
@@ -434,7 +368,7 @@ __device__ __forceinline__ void load_tables(DScene& S, ShadeTables& L, int enabl
 // QL: the indirect bounce of a diffuse hit is drawn from the Q table (rt_qlearn.h) and every hit pays its reward to the
 // (cell, patch) that sent the ray; W.w of an entry carries that key (0: none).
 template <bool QL>
-__global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_WAVES) k_shade_s(DScene S0, DCamera C, RenderParams R, StreamState T, int round, int fresh, int roundsLeft, int decide, int ldsTables, int counting, QTable Qt)
+__global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_WAVES) k_shade_s(DScene S0, DCamera C, RenderParams R, StreamState T, int round, int fresh, int last, int lastNext, int decide, int ldsTables, int counting, QTable Qt)
 {
 	__shared__ ShadeTables tables;
 	uint nDecided = 0;
@@ -479,11 +413,6 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 			f3 W = xyz(w4), E = xyz(e4), Lsum = xyz(l4);
 			uint seed = __float_as_uint(e4.w);
 			const f3 I = O + t * D; // ray.IntersectionPoint()
-			// depth is per entry: a path whose ray was parked (carry) is 'lag' rounds behind the round's own depth
-			const int lag = c >> CL_LAG_SHIFT;
-			const bool last = roundsLeft + lag == 0;   // this hit is at depth 0
-			const int lastNext = roundsLeft + lag == 1; // the ray this hit scatters is traced at depth 0
-			const bool parked = (c & CL_PARKED) != 0;
 			const bool childTraces = !last; // Sample(depth - 1 < 0) = 0.05 (renderer.cpp:129)
 			bool segmentEnds = true, wantShadow = false;
 			f3 nO(0.0f), nD(0.0f), nW(0.0f);
@@ -494,16 +423,7 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 			const bool learner = (keyWord & RT_Q_LEARNER) != 0;
 			const uint prevKey = learner ? (keyWord & ~RT_Q_LEARNER) : 0u;
 
-			if (parked) {
-				// extend parked this entry's ray (carry): nothing to shade yet.  The entry moves to the next round as it is -- W.w as the
-				// first shade would have found it -- and the park record (hitId.x) learns where its ray's hit is to go
-				T.O[pout][p.x] = o4, T.D[pout][p.x] = d4;
-				T.W[pout][p.x] = make_float4(w4.x, w4.y, w4.z, QL ? __uint_as_float(keyWord) : w4.w);
-				T.E[pout][p.x] = e4, T.L[pout][p.x] = l4;
-				T.cls[pout][p.x] = (unsigned char)(CL_LIVE | CL_RESUME | ((lag + 1) << CL_LAG_SHIFT));
-				RT_CHECK(id.x >= 0 && id.x < T.parkCap && lag < 3, 26, &T.counts[SC_FLAG]);
-				T.parkEntry[round & 1][id.x] = (uint)p.x;
-			} else if (id.x == -1) {
+			if (id.x == -1) {
 				const f3 sky = sky_color(S, D);
 				Lsum = Lsum + W * sky; // renderer.cpp:134
 				if (QL && prevKey) q_reward(Qt, prevKey, q_lum(sky));
@@ -585,11 +505,11 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 				}
 			}
 			// the class byte promised exactly these outputs
-			RT_CHECK(parked || (((c & CL_SHADOW) != 0) == wantShadow && ((c & CL_CONT) != 0) == (!segmentEnds || wantShadow)), 22, &T.counts[SC_FLAG]);
+			RT_CHECK(((c & CL_SHADOW) != 0) == wantShadow && ((c & CL_CONT) != 0) == (!segmentEnds || wantShadow), 22, &T.counts[SC_FLAG]);
 			if (wantShadow) {
 				T.shI[p.y] = mk4(I, __int_as_float(id.y));
 				T.shN[p.y] = mk4(normal, __int_as_float(p.x));
-				T.shD[p.y] = mk4(D, last ? 1.0f : 0.0f); // w: the path ends with this hit's direct light (light() stores the sample)
+				T.shD[p.y] = mk4(D, 0.0f);
 				T.shW[p.y] = mk4(W, 0.0f);
 			}
 			if (!segmentEnds || wantShadow) {
@@ -600,14 +520,14 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 					T.O[pout][p.x] = mk4(nO, 1e34f), T.D[pout][p.x] = mk4(nD, 0.0f);
 					T.hitN[pout][p.x] = make_float4(0, 0, 0, 1e34f), T.hitId[pout][p.x] = make_int2(-1, -1);
 					T.W[pout][p.x] = make_float4(0, 0, 0, 0);
-					T.cls[pout][p.x] = (unsigned char)(CL_LIVE | (lag << CL_LAG_SHIFT));
+					T.cls[pout][p.x] = CL_LIVE;
 				} else if (!segmentEnds) {
 					const NewRay nr = emit_ray_s(S, T, pout, p.x, nO, nD, mode_t_min(1), lastNext, false, decide != 0);
 					T.W[pout][p.x] = mk4(nW, __uint_as_float(nextKey | (keyWord & RT_Q_LEARNER)));
-					T.cls[pout][p.x] = (unsigned char)(nr.cls | (lag << CL_LAG_SHIFT));
+					T.cls[pout][p.x] = nr.cls;
 					nDecided += nr.decided ? 1u : 0u;
-				} else T.cls[pout][p.x] = 0; // the path ends here; the entry only holds E and L for light().  (Paths that are behind make the round loop go on: nobody may take this entry for a path)
-			} else if (!parked) store_sample(R, __float_as_uint(l4.w), Lsum);
+				}
+			} else store_sample(R, __float_as_uint(l4.w), Lsum);
 		}
 	}
 	if (counting) flush_decided(T.counts, nDecided);
@@ -663,20 +583,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_CONNECT_WAVES) k_connect_s(DScene
 // extend launch is busy 0.2-0.8 ms and drains for 0.5-0.7); at large batches waves that mix the two kinds cost more than the
 // drains return (DESIGN.md finding 19), so this is the small batches' round loop.
 struct StreamTraversePolicy {
-	static constexpr bool kCarries = true; // nearest-hit rays only: light(r - 1) waits for the shadow rays' answers
-	StreamExtendPolicy<true> ext;
+	StreamExtendPolicy ext;
 	StreamConnectPolicy con;
 	int nTrace;
-	__device__ __forceinline__ int resume_count() const { return ext.resume_count(); }
-	__device__ __forceinline__ void resume(int i, f3& O, f3& D, uint4& hdr) const { ext.resume(i, O, D, hdr); }
-	__device__ __forceinline__ uint park_word(int i, uint j) const { return ext.park_word(i, j); }
-	__device__ __forceinline__ bool may_park(int work) const { return ext.may_park(work); }
-	__device__ __forceinline__ int park_budget() const { return ext.park_budget(); }
-	__device__ __forceinline__ int* park_counter() const { return ext.park_counter(); }
-	__device__ __forceinline__ int park_cap() const { return ext.park_cap(); }
-	__device__ __forceinline__ void park_note(int parked) const { ext.park_note(parked); }
-	__device__ __forceinline__ void park(int work, int k, const uint4& hdr) const { ext.park(work, k, hdr); }
-	__device__ __forceinline__ void park_word(int k, uint j, uint v) const { ext.park_word(k, j, v); }
 	__device__ __forceinline__ bool any_of(int work) const { return work >= nTrace; }
 	__device__ __forceinline__ bool load(int work, f3& O, f3& D, float& tmax, HitRef& head) const
 	{
@@ -686,21 +595,20 @@ struct StreamTraversePolicy {
 	__device__ __forceinline__ void store(int work, const HitRef& hit, const f3& O, const f3& D) const { ext.store(work, hit, O, D); }
 	__device__ __forceinline__ void store(int work, bool occluded) const { con.store(work - nTrace, occluded); }
 };
-__global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DScene S, StreamState T, int round, int roundsLeft, float t_min, int tuning, int carryK, int maxLag, uint* spill)
+__global__ void __launch_bounds__(RT_BLOCK, RT_TRAVERSE_WAVES) k_traverse_s(DScene S, StreamState T, int round, int last, float t_min, int tuning, uint* spill)
 {
 	__shared__ __attribute__((aligned(16))) uint ldsStack[RT_LDS_WORDS];
 	LaneCounters lc;
 	lc.clear();
 	uint rays = 0;
 	const int nTrace = T.counts[SC_TRACE], nShadow = T.counts[SC_SHADOW + (round + 2) % 3]; // the shadow records of round - 1
-	const int n = nTrace + nShadow * S.nLights;
-	StreamTraversePolicy pol{ { S, T, round, roundsLeft, n, carryK, maxLag, &T.counts[SC_FLAG] }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] }, nTrace };
-	trace_persistent<false, false, false, StreamTraversePolicy, true>(S, pol, n, T.heads, t_min, tuning, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
+	StreamTraversePolicy pol{ { S, T, round & 1, last, &T.counts[SC_FLAG] }, { T, nShadow > 0 ? nShadow : 1, &T.counts[SC_FLAG] }, nTrace };
+	trace_persistent<false, false, false, StreamTraversePolicy, true>(S, pol, nTrace + nShadow * S.nLights, T.heads, t_min, tuning, ldsStack, spill, &T.counts[SC_FLAG], lc, rays);
 }
 
 // light: the direct-light terms of a diffuse hit, in light order (renderer.cpp:158-176: occlusion test first, scatter
 // only when visible), added to the radiance of the path's continuation entry; in the last round the sample is complete.
-__global__ void RT_LIGHT_BOUNDS k_light_s(DScene S0, RenderParams R, StreamState T, int round, int ldsTables)
+__global__ void RT_LIGHT_BOUNDS k_light_s(DScene S0, RenderParams R, StreamState T, int round, int last, int ldsTables)
 {
 	__shared__ ShadeTables tables;
 	DScene S = S0;
@@ -727,7 +635,7 @@ __global__ void RT_LIGHT_BOUNDS k_light_s(DScene S0, RenderParams R, StreamState
 		}
 		const f3 albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
 		Lsum = Lsum + W * ((direct * RT_INVPI) * albedo); // direct part of (direct*INVPI + 2*indirect) * albedo
-		if (d4.w != 0.0f) store_sample(R, __float_as_uint(l4.w), Lsum); // the hit was at depth 0 (shade said so): the sample is complete
+		if (last) store_sample(R, __float_as_uint(l4.w), Lsum);
 		else {
 			if (E.x != e4.x || E.y != e4.y || E.z != e4.z) T.E[pout][cp] = mk4(E, e4.w);
 			if (Lsum.x != l4.x || Lsum.y != l4.y || Lsum.z != l4.z) T.L[pout][cp] = mk4(Lsum, l4.w);

@@ -26,7 +26,7 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
               "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_device_of",
               "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy", "rt_build_info", "rt_tuning_info",
-              "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table", "rt_carry_stats"]
+              "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table"]
 
 
 class RtQlearnParams(C.Structure):
@@ -85,7 +85,6 @@ def rt_lib():
         L.rt_qlearn_get_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_qlearn_set_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_qlearn_get_table.argtypes = [C.c_void_p, C.c_void_p]
-        L.rt_carry_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.rt_build_info.restype = C.c_char_p
         L.rt_build_info.argtypes = []
         L.rt_tuning_info.restype = C.c_char_p
@@ -547,12 +546,6 @@ class HostRenderer:
     def build_info(self):
         """rt_build_info() + rt_tuning_info(): compile flags / compile-time tuning of the library and the tuning this context resolved"""
         return self.rt.rt_build_info().decode() + " | " + self.rt.rt_tuning_info(self.ctx).decode()
-
-    def carry_stats(self, reset=True):
-        """rt_carry_stats: (rays parked at the end of a traversal launch and resumed by the next, path batches) since the last reset"""
-        parked, batches = C.c_uint64(0), C.c_uint64(0)
-        self._rt(self.rt.rt_carry_stats(self.ctx, C.byref(parked), C.byref(batches), int(reset)))
-        return int(parked.value), int(batches.value)
 
     def set_profiling(self, on):
         self._rt(self.rt.rt_set_profiling(self.ctx, int(on)))

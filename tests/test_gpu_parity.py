@@ -231,53 +231,6 @@ def test_path_frames_ragged_batches(name, kw, w, h, frames, scenes, oracle_api, 
     r.close()
 
 
-@pytest.mark.parametrize("name,kw,w,h,frames", [("mixed_small", {}, 96, 64, 3), ("pretty_tlas", {"n_instances": 8}, 240, 135, 2), ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 128, 72, 2),
-                                               ("tower", {}, 120, 68, 2), ("scene3", {"force_diffuse": False}, 96, 54, 3), ("pretty_tlas", {"n_instances": 4}, 37, 23, 3)])
-def test_carry_parks_and_resumes(name, kw, w, h, frames, scenes, oracle_api, host_api, monkeypatch):
-    """Carry (csrc/rt_stream.h, trace_persistent's pol_carries): a traversal launch parks the rays that are still walking RT_CARRY_K
-    steps after its queue ran dry, the next round's launch resumes them, a path is parked at most RT_CARRY times.  Forced hard
-    here -- K = 0 parks EVERY ray that is alive when its wave's queue runs dry, up to three times per path, in all three round
-    loops (RT_FUSE) and inside instances (the object-space ray is recomputed at the resume) -- the frame must be the frame of
-    RT_CARRY=0 bit for bit, the oracle's within tolerance, and rays must really have been parked."""
-    monkeypatch.setenv("RT_CARRY", "0")
-    o, orr, r, d = make_pair(scenes.REGISTRY[name], oracle_api, host_api, w, h, **kw)
-    check_frames(orr, r, "path", frames, host_api)
-    plain = r.accumulator().copy()
-    assert r.carry_stats()[0] == 0
-    pO, pD = orr.primary_rays()
-    pO, pD = pO[::5].copy(), pD[::5].copy()
-    plain_samples = [r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 7) for depth in (0, 2, 6)]
-    r.close()
-    parked_any = 0
-    for lag, k, fuse in (("3", "0", "0"), ("3", "0", "1"), ("3", "0", "2"), ("1", "0", None), ("2", "3", None), ("2", "40", "0")):
-        monkeypatch.setenv("RT_CARRY", lag)
-        monkeypatch.setenv("RT_CARRY_K", k)
-        if fuse is None:
-            monkeypatch.delenv("RT_FUSE", raising=False)
-        else:
-            monkeypatch.setenv("RT_FUSE", fuse)
-        r = host_api.HostRenderer(w, h)
-        scenes.REGISTRY[name](r.scene, **kw)
-        r.commit()
-        if "camera" in d:
-            c = d["camera"]
-            r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
-        r.clear()
-        r.render(host_api.RT_MODE_PATH, 0, frames)
-        assert np.array_equal(r.accumulator().view(np.uint32), plain.view(np.uint32)), (lag, k, fuse)
-        parked, batches = r.carry_stats()
-        assert batches >= 1
-        if k == "0":
-            assert parked > 0, (lag, k, fuse)
-        parked_any += parked
-        # Sample() for caller-supplied rays at other depths than Tick's (depth + 1 rounds, the lag bits are relative to them)
-        for a, depth in zip(plain_samples, (0, 2, 6)):
-            b = r.trace_batch(host_api.RT_MODE_PATH, pO, pD, depth, 7)
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (lag, k, fuse, depth)
-        r.close()
-    assert parked_any > 0
-
-
 @pytest.mark.parametrize("name,kw", [("pretty_scene1", {}), ("pretty_animation", {}), ("bigb_scene", {}), ("christ_scene", {}), ("tlas_test", {}),
                                      ("scene1", {}), ("scene2", {}), ("scene4", {}), ("scene5", {}), ("scene6", {}), ("scene7", {"nx": 64, "ny": 64}),
                                      ("scene7", {})])
