@@ -17,7 +17,8 @@ the VALU lane throughput it reaches (it is bound by the CUs' vector pipelines, n
 SURVEY.md 8(d) algorithmic-bytes rate (work counters from an untimed counting pass of the identical,
 deterministic workload / device time measured with HIP events on the kernel's stream during the timed
 steps) and the counter-measured HBM rate beside it.  cpu_baseline: the oracle (oracle/, the CPU
-restatement; kind "port") on this box's physical host cores and on one thread, on bounded samples.
+restatement; kind "port") on the host cores this job may use and on one thread, on bounded samples; parity_check: the
+oracle's accumulator of those frames against the device's, the whole frame (rc != 0 above 1e-4).
 """
 import argparse
 import importlib
@@ -56,6 +57,18 @@ def main():
                     "long as its SLOWEST share: profiles/r04_shares_all_ranks.txt)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks as a CHILD process (torch.distributed.run, one rank per GPU) before
+        # torch is imported or HIP touched in this one, relay rank 0's JSON line (the ranks inherit stdout) and the exit code
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -64,7 +77,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; this benchmark has no CPU path")
     # RAPT_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share
@@ -187,6 +200,9 @@ def main():
         dist.all_reduce(split, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     rays_all = float(cnt.sum().item())  # per step, all ranks
+    seen = torch.ones(1, dtype=torch.int64, device=red_dev)  # the witness that the process group really had N ranks
+    if world > 1:
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
 
     if rank == 0:
         sec_per_step = dt / args.steps
@@ -198,7 +214,8 @@ def main():
         avg_ms = ext["ms"] / max(1, ext["launches"])  # HIP events on the kernel's own stream, inside the timed steps
         out = {
             "metric": ("Mrays/s at %d×%d×%dspp" % (W, H, spp)) + (" (rank %d's rows of a %d-rank shard only: a profiling line)" % (args.emulate_rank, args.emulate_world) if args.emulate_world > 1 else ""),
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "ranks_seen": int(seen.item()), "backend": backend if world > 1 else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s, %dx%d, %d spp, path integrator" % (args.workload, cfg["name"], W, H, spp),
@@ -218,9 +235,15 @@ def main():
                                        r.build_info(), sec_per_step, prof["connect"]),
         }
         out["frame_checksum"] = "%016x" % int(torch.sum(acc.view(torch.int32).to(torch.int64)).item() & 0xFFFFFFFFFFFFFFFF)
+        parity_ok = True
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, cfg, W, H)
+            can_check = not args.qlearn and args.emulate_world <= 1
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(args, cfg, W, H, spp, (r, acc, mode, out["frame_checksum"]) if can_check else None)
+            parity_ok = out["parity_check"] is None or out["parity_check"]["ok"]
         print(json.dumps(out), flush=True)
+        if not parity_ok:
+            r.close()
+            raise SystemExit("bench.py: the frame differs from the oracle's beyond the tolerance: %s" % json.dumps(out["parity_check"]))
     r.close()
     if world > 1:
         dist.barrier()
@@ -343,15 +366,50 @@ def physical_cores():
     return (len(cores) or len(allowed)), len(allowed)
 
 
-def cpu_baseline(args, cfg, W, H):
-    """The oracle (CPU restatement, kind 'port') on the host cores: frames of the same workload, OpenMP over
-    scanlines like renderer.cpp:259, per-pixel RNG streams.  value: OMP_NUM_THREADS = physical core count
-    (whole frames); value_1thread: one thread on every 2nd scanline of one frame (a bounded sample of the same
-    image)."""
+def cpu_allowance():
+    """CPUs' worth of time this process may use per second: the cgroup quota (cpu.max, v2; cfs_quota_us, v1), None when unlimited.
+    A GPU box gives one GPU's job 16 of its 256 logical CPUs this way while the affinity mask still shows all of them: threads
+    beyond the quota are throttled, not run (profiles/r05_cpu_scaling.txt: 128 threads reach 0.5-0.7x of what 16-32 do)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+def frame_error(got, ref, floor=1e-3):
+    """Relative error |got - ref| / max(|ref|, floor) over the finite entries (tests/conftest.py rel_err) and whether the
+    non-finite ones agree by class."""
+    import numpy as np
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    fa, fb = np.isfinite(got), np.isfinite(ref)
+    cls_ok = bool(np.array_equal(fa, fb) and np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isposinf(got), np.isposinf(ref)))
+    m = fa & fb
+    err = np.abs(got[m] - ref[m]) / np.maximum(np.abs(ref[m]), floor)
+    return (float(err.max()) if err.size else 0.0), cls_ok
+
+
+def cpu_baseline(args, cfg, W, H, spp, gpu=None):
+    """The oracle (CPU restatement, kind 'port') on the host cores: frames 0 .. F-1 of the same workload, OpenMP over
+    scanlines like renderer.cpp:259, per-pixel RNG streams; F = the step's spp when that fits --cpu-seconds.  Threads =
+    the physical cores this job may really use (the cgroup quota caps them: cpu_allowance).  value_1thread: one thread on
+    every 2nd scanline of one frame (a bounded sample of the same image).
+    gpu = (renderer, accumulator tensor, mode, checksum of the timed steps' frame): the SAME F frames are rendered once more
+    on the device, outside the timed region, and compared with the oracle's accumulator as a whole -> (baseline, parity_check):
+    the witness that the numbers above were measured on the reference's image (renderer.cpp:263-285), at full size."""
+    import numpy as np
     from oracle import oracle_api as oa
     scenes = pkg("scenes")
     oa.build()
     phys, logical = physical_cores()
+    allowed = cpu_allowance()
+    threads = phys if allowed is None else max(1, min(phys, int(allowed + 0.5)))
     s = oa.OracleScene()
     scenes.REGISTRY[args.workload](s)
     s.set_raytracer(False)
@@ -359,13 +417,15 @@ def cpu_baseline(args, cfg, W, H):
     if "camera" in cfg:
         c = cfg["camera"]
         orr.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+    orr.clear()
     t0 = time.perf_counter()
-    orr.render(0, 1, nthreads=phys)
+    orr.render(0, 1, nthreads=threads)
     t1 = time.perf_counter() - t0
-    frames = int(max(1, min(64, args.cpu_seconds / max(t1, 1e-3))))
-    t0 = time.perf_counter()
-    orr.render(1, frames, nthreads=phys)
+    frames = int(max(1, min(spp, args.cpu_seconds / max(t1, 1e-3))))
+    if frames > 1:
+        orr.render(1, frames - 1, nthreads=threads)
     dt = time.perf_counter() - t0
+    ref = orr.accumulator()
     rows = list(range(1, H, 2))
     t0 = time.perf_counter()
     for y in rows:
@@ -373,11 +433,30 @@ def cpu_baseline(args, cfg, W, H):
     dt1 = time.perf_counter() - t0
     orr.close()
     s.close()
-    return {"value": round(W * H * frames / dt / 1e6, 4), "unit": "Mrays/s", "cores": phys, "kind": "port",
-            "sample": "%d frame(s) of %dx%d of the same workload on %d threads (%.1f s)" % (frames, W, H, phys, dt),
-            "physical_cores": phys, "logical_cpus": logical,
+    base = {"value": round(W * H * frames / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "frames 0..%d of %dx%d of the same workload on %d threads (%.1f s)" % (frames - 1, W, H, threads, dt),
+            "physical_cores": phys, "logical_cpus": logical, "cpu_allowance": allowed,
+            "threads_note": "threads = min(physical cores, cgroup CPU quota): the box shows %d logical CPUs but this job may use %s of them" % (logical, "all" if allowed is None else "%.0f CPUs' worth of time" % allowed),
             "value_1thread": round(W * len(rows) / dt1 / 1e6, 4),
             "sample_1thread": "%d scanlines (every 2nd) of one %dx%d frame on 1 thread (%.1f s)" % (len(rows), W, H, dt1)}
+    if gpu is None:
+        return base, None
+    import torch
+    r, acc, mode, timed_checksum = gpu
+    acc.zero_()
+    torch.cuda.synchronize()
+    r.render(mode, 0, frames)
+    r.synchronize()
+    checksum = "%016x" % int(torch.sum(acc.view(torch.int32).to(torch.int64)).item() & 0xFFFFFFFFFFFFFFFF)
+    got = acc.cpu().numpy()
+    err, cls_ok = frame_error(got[..., :3], ref[..., :3])
+    tol = 1e-4  # BASELINE.json north_star: accumulated radiance within 1e-4 relative
+    parity = {"frames": frames, "pixels": W * H, "max_rel_err": err, "tolerance": tol, "nonfinite_class_equal": cls_ok,
+              "frac_bit_identical": round(float((got[..., :3] == ref[..., :3]).mean()), 6),
+              "same_frames_as_timed_step": frames == spp, "same_checksum_as_timed_step": (checksum == timed_checksum) if frames == spp else None,
+              "oracle": "oracle/ (CPU restatement of renderer.cpp:128-236; parity unpinned: the reference holds no fixtures)",
+              "ok": bool(cls_ok and err <= tol and (frames != spp or checksum == timed_checksum))}
+    return base, parity
 
 
 if __name__ == "__main__":

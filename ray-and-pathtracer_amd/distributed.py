@@ -74,8 +74,10 @@ def render_step(renderer, acc, mode, frame0, frames, shard, host_staging=None, t
     synchronize -> rt_synchronize) or anything with those two methods.  host_staging: a pinned-size CPU tensor for the
     gloo rehearsal mode (ranks share a GPU, the gather goes through host memory); its RowShard is host_staging[1].
     timing: a dict that accumulates 'render_s' (until this rank's rows are complete) and 'gather_s' (from there until the
-    gather has completed on this rank: it includes the wait for the slowest rank) -- with several ranks the split is what
-    tells a slow share from a slow exchange."""
+    exchange has completed on this rank: the wait for the slowest rank, the collective, and on the destination the strided
+    copy of the staging tensor into the frame) -- with several ranks the split is what tells a slow share from a slow
+    exchange.  Every step runs the same host sequence whether it is timed or not (the device is synchronised after the
+    gather in warm-up steps too)."""
     t0 = time.perf_counter()
     first, stride, count = shard.rows()
     if count > 0:
@@ -84,8 +86,8 @@ def render_step(renderer, acc, mode, frame0, frames, shard, host_staging=None, t
     t1 = time.perf_counter()
     if host_staging is None:
         shard.gather(acc)
-        if timing is not None and shard.world > 1 and acc.is_cuda:
-            torch.cuda.synchronize(acc.device)  # the collective is asynchronous on the device: its end is what is timed
+        if shard.world > 1 and acc.is_cuda:
+            torch.cuda.synchronize(acc.device)  # the collective is asynchronous on the device: its end is the step's end
     else:
         host, host_shard = host_staging
         host.copy_(acc)

@@ -457,6 +457,11 @@ def test_bench_two_ranks_equal_one(host_api):
     two = last_json(subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                              "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, cwd=ROOT, timeout=600))
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["ranks_seen"] == 1 and two["ranks_seen"] == 2  # an all-reduce of 1 over the process group
+    # the driver's own command shape: `python bench.py --gpus 2` with no WORLD_SIZE starts its ranks itself (a child process)
+    env_plain = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    self_started = last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env_plain, cwd=ROOT, timeout=600))
+    assert self_started["n_gpus"] == 2 and self_started["ranks_seen"] == 2 and self_started["frame_checksum"] == one["frame_checksum"]
     assert one["metric"] == two["metric"] == "Mrays/s at 320×181×4spp"
     assert one["frame_checksum"] == two["frame_checksum"]
     assert two["rays_per_step"] == one["rays_per_step"]  # the two shards trace exactly the rays of the whole frame
@@ -468,6 +473,19 @@ def test_bench_two_ranks_equal_one(host_api):
     # one share of an N-rank run by itself (profiling lines: profiles/r04_shares_all_ranks.txt): any rank's rows
     share = last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--emulate-world", "2", "--emulate-rank", "1"] + common, env=env, cwd=ROOT, timeout=600))
     assert "rank 1's rows of a 2-rank shard" in share["metric"]
+
+
+def test_bench_line_witnesses_parity(host_api):
+    """bench.py's cpu_baseline leg renders the step's frames with the oracle ONCE, times that as the baseline, and compares its
+    accumulator with the device's as a whole: the JSON line carries parity_check, and the run fails above 1e-4."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--width", "160", "--height", "90", "--spp", "3", "--cpu-seconds", "30"], cwd=ROOT, timeout=600)
+    d = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
+    pc, cb = d["parity_check"], d["cpu_baseline"]
+    assert pc["ok"] and pc["frames"] == 3 and pc["pixels"] == 160 * 90 and pc["max_rel_err"] <= 1e-4 and pc["nonfinite_class_equal"]
+    assert pc["same_frames_as_timed_step"] and pc["same_checksum_as_timed_step"]
+    assert cb["kind"] == "port" and 1 <= cb["cores"] <= cb["physical_cores"] and "frames 0..2" in cb["sample"]
 
 
 @pytest.mark.parametrize("name,kw", [("tlas_test2", {"mesh": "BigB"}), ("pretty_tlas", {"n_instances": 4}), ("mixed_small", {})])
