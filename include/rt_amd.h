@@ -30,7 +30,7 @@ typedef enum {
 	RT_E_HIP = -3,         /* HIP runtime error */
 	RT_E_UNSUPPORTED = -4, /* scene feature outside the device path (see rt_upload_scene) */
 	RT_E_STATE = -5,       /* call order (e.g. render before upload) */
-	RT_E_OVERFLOW = -6     /* traversal stack deeper than 130 = tlas.cpp:67 stack[64] + instance sentinel + bvh.cpp:608 stack[64], or too many pending Whitted branches */
+	RT_E_OVERFLOW = -6     /* traversal stack deeper than 130 = tlas.cpp:67 stack[64] + instance sentinel + bvh.cpp:608 stack[64], too many pending Whitted branches, or (Q-learning sampler) more than 2^19 rewards for one (cell, direction) between two rt_qlearn_apply calls */
 } rt_status;
 
 /* ---- scene records -------------------------------------------------------------------------

@@ -2124,6 +2124,7 @@ int rt_qlearn_enable(rt_ctx* c, const rt_qlearn_params* p)
 	HIPCHK(c, dalloc(c->qAllocs, &Q.v, cells * RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &Q.sum, cells * RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &Q.cnt, cells * RT_Q_PATCHES));
+	HIPCHK(c, dalloc(c->qAllocs, &Q.acc, cells * RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &centre, (size_t)RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &wgt, (size_t)RT_Q_PATCHES * RT_Q_PATCHES));
 	Q.centre = centre, Q.wgt = wgt, Q.grid = p->grid, Q.on = 1;
@@ -2135,10 +2136,27 @@ int rt_qlearn_enable(rt_ctx* c, const rt_qlearn_params* p)
 	c->Qt = Q;
 	return RT_OK;
 }
+// the batch's packed reward words -> the wide sums (rt_qlearn.h k_q_fold); waits for the stream and reports a count field near its end
+static int qlearn_fold(rt_ctx* c, const char* who)
+{
+	const int n = c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
+	int* flag = c->flags + 2;
+	hipLaunchKernelGGL(k_q_fold, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Qt, flag);
+	int f = 0;
+	HIPCHK(c, hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (f) {
+		(void)hipMemsetAsync(flag, 0, sizeof(int), c->stream);
+		return fail(c, RT_E_OVERFLOW, "%s: more than %u rewards for one (cell, direction) since the last fold: render fewer frames between rt_qlearn_apply calls", who, RT_Q_ACC_LIMIT);
+	}
+	return RT_OK;
+}
 int rt_qlearn_apply(rt_ctx* c)
 {
 	if (!c || !c->Qt.on) return fail(c, RT_E_STATE, "rt_qlearn_apply: the sampler is off");
 	HIPCHK(c, hipSetDevice(c->device));
+	const int rc = qlearn_fold(c, "rt_qlearn_apply");
+	if (rc != RT_OK) return rc;
 	const int cells = c->Qt.grid * c->Qt.grid * c->Qt.grid;
 	hipLaunchKernelGGL(k_q_apply, dim3((cells + 63) / 64), dim3(64), 0, c->stream, c->Qt); // a 64 x 64 product per cell: one wave per block spreads the cells over the CUs
 	HIPCHK(c, hipGetLastError());
@@ -2149,7 +2167,8 @@ int rt_qlearn_get_sums(rt_ctx* c, int64_t* sums, uint32_t* counts)
 	if (!c || !c->Qt.on || !sums || !counts) return fail(c, RT_E_STATE, "rt_qlearn_get_sums: the sampler is off, or a null argument");
 	HIPCHK(c, hipSetDevice(c->device));
 	const size_t n = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const int rc = qlearn_fold(c, "rt_qlearn_get_sums");
+	if (rc != RT_OK) return rc;
 	HIPCHK(c, hipMemcpy(sums, c->Qt.sum, n * 8, hipMemcpyDeviceToHost));
 	HIPCHK(c, hipMemcpy(counts, c->Qt.cnt, n * 4, hipMemcpyDeviceToHost));
 	return RT_OK;
@@ -2160,6 +2179,7 @@ int rt_qlearn_set_sums(rt_ctx* c, const int64_t* sums, const uint32_t* counts)
 	HIPCHK(c, hipSetDevice(c->device));
 	const size_t n = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemset(c->Qt.acc, 0, n * 8)); // the caller's sums replace everything gathered so far
 	HIPCHK(c, hipMemcpy(c->Qt.sum, sums, n * 8, hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpy(c->Qt.cnt, counts, n * 4, hipMemcpyHostToDevice));
 	return RT_OK;

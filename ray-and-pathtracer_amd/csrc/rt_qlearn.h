@@ -18,7 +18,8 @@
 //                        normal quantised to the patch it points into; luminance(col) * mean Q[cell(y)] (specular).  V is
 //                        recomputed whenever Q changes (k_q_init, k_q_apply: a 64 x 64 product per cell, microseconds), so a hit
 //                        reads ONE value where round 3 read the cell's 64 and took 64 dot products (config 5: shade 1.16 s of
-//                        2.20 s).  Rewards are summed as 48.16 fixed-point INTEGERS with a count per (cell, patch);
+//                        2.20 s).  Rewards are summed as 48.16 fixed-point INTEGERS with a count per (cell, patch) (one packed
+//                        64-bit atomic per reward, q_reward);
 //                        rt_qlearn_apply folds them into Q <- (1 - alpha) Q + alpha mean between batches.  Within a batch Q
 //                        and V are read-only.
 // Why integers: sums of integers do not depend on the order in which lanes, waves or GPUs add them, so a frame is
@@ -36,8 +37,9 @@ struct QTable {
 	float* q;            // [cells][RT_Q_ROW]
 	float* v;            // [cells][64] V[cell][m] = sum_p Q[cell][p] * wgt[m][p]: the expected reflected Q for a normal in patch m
 	const float* wgt;    // [64][64] max(0, d_m . d_p) of the patch centres
-	long long* sum;      // [cells][64] rewards of the current batch, 48.16 fixed point
-	uint* cnt;           // [cells][64]
+	long long* sum;      // [cells][64] rewards of the current batch, 48.16 fixed point   } the exchange format (rt_qlearn_get_sums / set_sums);
+	uint* cnt;           // [cells][64]                                                   } k_q_fold moves acc[] here
+	unsigned long long* acc; // [cells][64] what the shading kernel adds to: count << 44 | sum, ONE atomic per reward (see q_reward)
 	const float4* centre; // [64] patch centre directions
 	int grid, on;
 	float lo[3], inv[3]; // cell = (int)((x - lo) * inv), clamped
@@ -107,7 +109,7 @@ __global__ void k_q_init(QTable Q, float qInit)
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= cells) return;
 	float* row = Q.q + (size_t)t * RT_Q_ROW;
-	for (int p = 0; p < RT_Q_PATCHES; p++) row[8 + p] = qInit, Q.sum[(size_t)t * RT_Q_PATCHES + p] = 0, Q.cnt[(size_t)t * RT_Q_PATCHES + p] = 0;
+	for (int p = 0; p < RT_Q_PATCHES; p++) row[8 + p] = qInit, Q.sum[(size_t)t * RT_Q_PATCHES + p] = 0, Q.cnt[(size_t)t * RT_Q_PATCHES + p] = 0, Q.acc[(size_t)t * RT_Q_PATCHES + p] = 0;
 	q_derive(Q, t);
 }
 // fold the batch's rewards into the table: one thread per cell
@@ -129,12 +131,33 @@ __global__ void k_q_apply(QTable Q)
 	q_derive(Q, t);
 }
 
-// the reward a scattered ray brings back to (cell, patch) = key - 1
+// the reward a scattered ray brings back to (cell, patch) = key - 1.
+// Scattered global atomics execute at the memory side on this part, one 64-byte request per lane, ~16-20 G per second for the whole
+// chip (MI355X_MICROARCH.md "Global float atomics": 64 lanes in 64 rows 17x below the contiguous rate; measured here: config 5's
+// shade launches 0.79 s with 0.1 % of the samples paying rewards, 1.02 s with 25 %, 2.06 s with all -- profiles/r05_ab_qlearn_atomics.txt).
+// A reward was two of them (sum, count); it is ONE: the count rides in the top 20 bits of the 64-bit word, the sum (<= 2^22 per
+// reward) in the low 44.  k_q_fold moves the words into the wide sums between batches and reports a count field that got past
+// half its range (RT_Q_ACC_LIMIT rewards for one (cell, patch) within one batch: 7x what config 5 reaches with every sample
+// paying) as RT_E_OVERFLOW instead of letting it wrap.
+#define RT_Q_ACC_SHIFT 44
+#define RT_Q_ACC_LIMIT (1u << 19)
 __device__ __forceinline__ void q_reward(const QTable& Q, uint key, float R)
 {
 	R = (R >= 0) ? (R < 64.0f ? R : 64.0f) : 0.0f; // a directly seen light is +inf in the reference (Q7); NaN teaches nothing
-	atomicAdd((unsigned long long*)&Q.sum[key - 1], (unsigned long long)__float2ll_rn(R * 65536.0f));
-	atomicAdd(&Q.cnt[key - 1], 1u);
+	atomicAdd(&Q.acc[key - 1], (1ull << RT_Q_ACC_SHIFT) | (unsigned long long)__float2ll_rn(R * 65536.0f));
+}
+// acc[] -> sum[], cnt[] (one thread per (cell, patch)); *flag = 1 when a count field is past RT_Q_ACC_LIMIT
+__global__ void k_q_fold(QTable Q, int* flag)
+{
+	const size_t n = (size_t)Q.grid * Q.grid * Q.grid * RT_Q_PATCHES;
+	const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const unsigned long long a = Q.acc[k];
+	if (a == 0) return;
+	const uint c = (uint)(a >> RT_Q_ACC_SHIFT);
+	Q.sum[k] += (long long)(a & ((1ull << RT_Q_ACC_SHIFT) - 1)), Q.cnt[k] += c;
+	Q.acc[k] = 0;
+	if (c >= RT_Q_ACC_LIMIT) *flag = 1;
 }
 // expected reflected Q at a surface hit (the integral of eq. 8 over the 64 patches): one value of the cell's V row for a diffuse
 // surface, the mean of the cell's Q for a specular one

@@ -1350,6 +1350,25 @@ def test_qlearning_sampler_is_unbiased(scenes, oracle_api, host_api):
     r.close()
 
 
+def test_qlearning_reward_words_report_overflow(scenes, host_api):
+    """A reward is ONE packed 64-bit atomic (count << 44 | 48.16 sum, csrc/rt_qlearn.h q_reward); the words are folded into the wide
+    sums at rt_qlearn_apply / rt_qlearn_get_sums.  A count field past half its range must come back as RT_E_OVERFLOW, never wrap
+    silently: a 1-cell grid with every sample paying puts a whole 1080p batch on 64 words."""
+    w, h = 1920, 1080
+    r = host_api.HostRenderer(w, h)
+    scenes.REGISTRY["mixed_small"](r.scene)
+    r.commit()
+    r.qlearn_enable(1, (-50, -50, -50), (50, 50, 50), 0.3, 0.2, 1.0, 0)
+    r.clear(); r.render(host_api.RT_MODE_PATH, 0, 2)
+    sums, cnts = r.qlearn_sums()  # two frames: well inside the range, and exact
+    assert 0 < cnts.max() < (1 << 19) and cnts.sum() > w * h // 4
+    r.qlearn_apply()
+    r.render(host_api.RT_MODE_PATH, 2, 64)  # ~15 k rewards per word and frame
+    with pytest.raises(RuntimeError, match="rewards for one"):
+        r.qlearn_apply()
+    r.close()
+
+
 @pytest.mark.parametrize("name,kw,w,h,box", [("mixed_small", {}, 64, 40, ((-4, -1, -4), (4, 5, 6))), ("pretty_tlas", {"n_instances": 4}, 96, 54, ((-6, -1.5, -1), (8, 5, 10))),
                                              ("tlas_test2", {}, 64, 40, ((-6, -1, -2), (6, 7, 8))),
                                              ("bigb_instanced", {"n": 16, "mesh": "lowBigB"}, 96, 54, ((-12, -2, -8), (12, 10, 16))),  # BASELINE config 5's layout ("Q-learning sampler on") ...
