@@ -177,13 +177,14 @@ int rt_bind_accumulator(rt_ctx* ctx, void* device_ptr);
  * row_first + k*row_stride, k < row_count, that context src rendered into the same rows of context dst's
  * accumulator -- device to device over xGMI (peer access is enabled on first use; without it the rows are
  * copied one by one through hipMemcpyPeerAsync).  Asynchronous: the copy is a push queued on src's stream behind
- * the rendering already queued there (several sources push over their own links at the same time), and dst's
- * stream is made to wait for it, so whatever is queued on dst afterwards (rt_resolve, rt_download_accumulator,
- * the next frame) sees the rows; the host does not wait.  src's accumulator must not be re-bound or freed before
- * dst has synchronised.  May be called from src's host thread while another thread drives dst (only stream
- * operations touch dst; errors after the argument checks are reported on src).  Both contexts must have the same
- * width and height.  rt_device_of: the HIP device a
- * context lives on. */
+ * the rendering already queued there (several sources push over their own links at the same time) AND behind
+ * whatever was queued on dst's stream when the call was made (rt_clear's memset, dst's own resolve of the frame
+ * before: src's stream waits for an event recorded on dst's stream first), and dst's stream is made to wait for
+ * it, so whatever is queued on dst afterwards (rt_resolve, rt_download_accumulator, the next frame) sees the
+ * rows; the host does not wait.  src's accumulator must not be re-bound or freed before dst has synchronised.
+ * May be called from src's host thread while another thread drives dst (only stream operations touch dst; EVERY
+ * error of the call, the argument checks included, is reported on src: rt_last_error(src)).  Both contexts
+ * must have the same width and height.  rt_device_of: the HIP device a context lives on. */
 int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int row_count);
 int rt_device_of(const rt_ctx* ctx);
 

@@ -67,6 +67,7 @@ struct rt_ctx {
 	uint* streamSideSpill = nullptr;
 	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
 	hipEvent_t gatherDone = nullptr; // rt_gather_rows with this context as the source: its rows have arrived at the destination
+	hipEvent_t gatherReady = nullptr; // ... and, recorded on the destination's stream before the push: what the destination had queued is done
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
@@ -365,6 +366,7 @@ void rt_destroy(rt_ctx* c)
 	if (c->streamFork) (void)hipEventDestroy(c->streamFork);
 	if (c->streamJoin) (void)hipEventDestroy(c->streamJoin);
 	if (c->gatherDone) (void)hipEventDestroy(c->gatherDone);
+	if (c->gatherReady) (void)hipEventDestroy(c->gatherReady);
 	for (int k = 0; k < 2; k++) if (c->megaEv[k]) (void)hipEventDestroy(c->megaEv[k]);
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
@@ -1847,17 +1849,24 @@ int rt_device_of(const rt_ctx* c) { return c ? c->device : -1; }
 
 int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int row_count)
 {
-	if (!dst || !src) return fail(dst, RT_E_ARG, "rt_gather_rows: null context");
-	if (dst->width != src->width || dst->height != src->height) return fail(dst, RT_E_ARG, "rt_gather_rows: contexts differ in size (%dx%d vs %dx%d)", dst->width, dst->height, src->width, src->height);
+	// (every error of this call is reported on SRC -- rt_last_error(src) -- : the call may come from the source context's host
+	// thread while another thread drives dst, whose error string must not be written from here)
+	if (!dst || !src) return fail(src, RT_E_ARG, "rt_gather_rows: null context");
+	if (dst->width != src->width || dst->height != src->height) return fail(src, RT_E_ARG, "rt_gather_rows: contexts differ in size (%dx%d vs %dx%d)", dst->width, dst->height, src->width, src->height);
 	if (row_first < 0 || row_stride < 1 || row_count < 1 || row_first + (row_count - 1) * row_stride >= dst->height)
-		return fail(dst, RT_E_ARG, "rt_gather_rows: rows %d + k*%d (k < %d) outside 0..%d", row_first, row_stride, row_count, dst->height);
+		return fail(src, RT_E_ARG, "rt_gather_rows: rows %d + k*%d (k < %d) outside 0..%d", row_first, row_stride, row_count, dst->height);
 	if (dst == src) return RT_OK;
-	// (errors from here on are reported on SRC: the call may come from the source context's host thread while another thread
-	// drives dst)
 	// A PUSH on the source's stream: the copy follows the source's rendering in stream order (no host wait), every source
 	// context pushes over its own link to the destination at the same time (xGMI is point to point), and the destination's
 	// stream waits for the source's event -- what it does next (resolve, the next frame) sees the rows.
+	// The push must also come AFTER whatever is already queued on the destination's stream and touches these rows (rt_clear's
+	// whole-frame memset on a camera change, the destination's own resolve of the frame before): the source's stream waits for
+	// an event recorded on the destination's stream first.  Work queued on dst->stream after this call is ordered by the second event.
+	HIPCHK(src, hipSetDevice(dst->device));
+	if (!src->gatherReady) HIPCHK(src, hipEventCreateWithFlags(&src->gatherReady, hipEventDisableTiming));
+	HIPCHK(src, hipEventRecord(src->gatherReady, dst->stream));
 	HIPCHK(src, hipSetDevice(src->device));
+	HIPCHK(src, hipStreamWaitEvent(src->stream, src->gatherReady, 0));
 	const size_t rowBytes = (size_t)dst->width * sizeof(float4), pitch = rowBytes * (size_t)row_stride;
 	const float4* from = src->accum + (size_t)row_first * src->width;
 	float4* to = dst->accum + (size_t)row_first * dst->width;
