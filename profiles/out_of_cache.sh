@@ -1,27 +1,33 @@
 #!/bin/bash
-# profiles/out_of_cache.py under rocprofv3: one plain run with the oracle check, then separate --pmc passes (counters only) -> gpurun_out/r04_out_of_cache*.json
-#   bash profiles/out_of_cache.sh [n]      (GPU box, repository root; copy the two JSON files into profiles/ afterwards)
+# profiles/out_of_cache.py under rocprofv3: one plain run with the oracle check, then separate --pmc passes (counters only) -> gpurun_out/<tag>_out_of_cache*.json
+#   bash profiles/out_of_cache.sh [n] [spp] [tag]      (GPU box, repository root; copy the two JSON files into profiles/ afterwards)
+# spp 4 = 8.3 M samples per batch: one traversal launch per round (k_traverse_s); spp 16 = 33 M: k_extend_s and k_connect_s on two streams.
+# The result is stamped with bench.py's kernel_hash of the sources it ran on: bench.py quotes it only while that is the tree's.
 set -u
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 N=${1:-2048}
-OUT=gpurun_out/r04_ooc
+SPP=${2:-4}
+TAG=${3:-r05}
+OUT=gpurun_out/${TAG}_ooc_spp$SPP
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 900 python3 profiles/out_of_cache.py --n $N --check --json gpurun_out/r04_out_of_cache_run.json > $OUT/run.log 2>&1 || { echo "plain run failed"; tail -5 $OUT/run.log; exit 1; }
+timeout -k 10 900 python3 profiles/out_of_cache.py --n $N --spp $SPP --check --json $OUT/run.json > $OUT/run.log 2>&1 || { echo "plain run failed"; tail -5 $OUT/run.log; exit 1; }
 tail -2 $OUT/run.log | head -1
-run() { name=$1; shift; timeout -k 10 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 profiles/out_of_cache.py --n $N --steps 2 > $OUT/$name.log 2>&1 || echo "pass $name failed"; }
+run() { name=$1; shift; timeout -k 10 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 profiles/out_of_cache.py --n $N --spp $SPP --steps 2 > $OUT/$name.log 2>&1 || echo "pass $name failed"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE GRBM_TA_BUSY TA_BUSY_avr TA_BUSY_max
 run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run sq3 SQ_INSTS_VMEM SQ_INSTS_VALU
-python3 profiles/pmc_summary.py $OUT > gpurun_out/r04_out_of_cache_pmc_summary.json
-python3 - <<PY
-import json
-d = json.load(open("gpurun_out/r04_out_of_cache_pmc_summary.json"))
-run = json.load(open("gpurun_out/r04_out_of_cache_run.json"))
-out = {"run": run, "kernels": {}}
+python3 profiles/pmc_summary.py $OUT > gpurun_out/${TAG}_out_of_cache_spp${SPP}_pmc_summary.json
+python3 - $OUT gpurun_out/${TAG}_out_of_cache_spp${SPP} <<PY
+import json, sys
+sys.path.insert(0, '.')
+import bench
+d = json.load(open(sys.argv[2] + "_pmc_summary.json"))
+run = json.load(open(sys.argv[1] + "/run.json"))
+out = {"kernel_hash": bench.kernel_hash(run["build"]), "run": run, "kernels": {}}
 for k, v in sorted(d.items()):
     c = v["counters"]; ms = v["ms_by_pass"].get("fetch", 0); n = v["launches"]
     if ms <= 0: continue
@@ -38,6 +44,6 @@ for k, v in sorted(d.items()):
          "vmem_insts_M": round(c.get("SQ_INSTS_VMEM", 0) / 1e6, 1)}
     out["kernels"][k] = o
     print("%-40s %s" % (k, o))
-json.dump(out, open("gpurun_out/r04_out_of_cache.json", "w"), indent=1)
+json.dump(out, open(sys.argv[2] + ".json", "w"), indent=1)
 PY
 find $OUT -name "*.csv" -delete
