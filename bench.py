@@ -337,14 +337,21 @@ def roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, w
     # The regime north_star's "fraction of the HBM-read roofline on BVH traversal" is defined in -- a scene the caches cannot hold --
     # is ANOTHER workload (profiles/out_of_cache.py: the 8.4 M-triangle terrain).  Its committed counter figures ride along for
     # reference; they are not measured by this run and never enter 'frac'.
-    try:
-        ooc = json.load(open(os.path.join(ROOT, "profiles", "r04_out_of_cache.json")))
-        k = ooc["kernels"].get("k_traverse_s") or ooc["kernels"].get("k_extend_s<false>")
-        rb["hbm"]["out_of_cache_reference"] = {"file": "profiles/r04_out_of_cache.json", "scene": ooc["run"]["scene"], "scene_bytes": ooc["run"]["scene_bytes"],
-                                               "traversal_hbm_TBps": k["hbm_TBps"], "frac_of_hbm_peak": k["frac_of_8TBps"], "l2_hit_rate": k["l2_hit_rate"],
-                                               "ta_busy_avg": k["ta_busy_avg"], "note": "static, from the committed profile of another workload"}
-    except Exception:
-        pass
+    # (quoted only while the file was measured on THESE kernel sources and compile flags: its own stamp, kernel_hash of the
+    # library's rt_build_info -- the context's scene-dependent tuning string is another scene's there)
+    src_hash = kernel_hash(build_info.split(" | ")[0])
+    for name in ("r05_out_of_cache_spp16.json", "r05_out_of_cache_spp4.json"):
+        try:
+            ooc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            kname = "k_extend_s<false>" if "spp16" in name else "k_traverse_s"
+            k = ooc["kernels"][kname]
+            ref = {"file": "profiles/" + name, "kernel": kname, "scene": ooc["run"]["scene"], "scene_bytes": ooc["run"]["scene_bytes"], "frame": ooc["run"]["frame"],
+                   "traversal_hbm_TBps": k["hbm_TBps"], "frac_of_hbm_peak": k["frac_of_8TBps"], "l2_hit_rate": k["l2_hit_rate"], "ta_busy_avg": k["ta_busy_avg"],
+                   "measured_on_these_kernels": ooc.get("kernel_hash") == src_hash, "note": "static, from the committed profile of another workload"}
+            if ref["measured_on_these_kernels"]:
+                rb["hbm"].setdefault("out_of_cache_reference", []).append(ref)
+        except Exception:
+            pass
     return rb
 
 

@@ -27,7 +27,7 @@ sys.path.insert(0, '.')
 import bench
 d = json.load(open(sys.argv[2] + "_pmc_summary.json"))
 run = json.load(open(sys.argv[1] + "/run.json"))
-out = {"kernel_hash": bench.kernel_hash(run["build"]), "run": run, "kernels": {}}
+out = {"kernel_hash": bench.kernel_hash(run["build"].split(" | ")[0]), "run": run, "kernels": {}}
 for k, v in sorted(d.items()):
     c = v["counters"]; ms = v["ms_by_pass"].get("fetch", 0); n = v["launches"]
     if ms <= 0: continue
