@@ -26,4 +26,4 @@ for name, kw in (("mixed_small", {}), ("pretty_tlas", {"n_instances": 8})):
     pr = r.profile(); r.set_profiling(False)
     out.append("%s %.3f ms (parked %.0f / Tick; %s)" % (name, dt * 1e3, parked / max(1, batches), " ".join("%s %.2f" % (k, v["ms"] / 5) for k, v in pr.items() if v["launches"])))
     r.close()
-print("%-40s %s" % (" ".join("%s=%s" % (k, os.environ[k]) for k in ("RT_CARRY", "RT_CARRY_K", "RT_FUSE", "RT_MIXED_MAX") if k in os.environ) or "(defaults)", " | ".join(out)), flush=True)
+print("%-40s %s" % (" ".join("%s=%s" % (k, os.environ[k]) for k in ("RT_CARRY_K", "RT_FUSE", "RT_MIXED_MAX") if k in os.environ) or "(defaults)", " | ".join(out)), flush=True)
