@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE (round 5): this script sweeps RT_REFILL / RT_STEPMIN / RT_PAIRAGAIN / RT_DRAIN_LANES through the ENVIRONMENT, as the library read them when it was
+# written.  They are compile-time constants since round 4 (csrc/rt_scene_dev.h; the library prints a warning when it sees one set): re-running
+# it as it is gives identical rows.  A sweep is a rebuild per value now: profiles/bisect.sh over trees built with make EXTRA=-DRT_...=N.
 # Round 4, fourth batch on one box: the scheduling thresholds re-swept on the 64-register / eight-wave kernels, and the backend's
 # max-memory-clause scheduling strategy.  bash profiles/r04_batch4.sh -> gpurun_out/r04_batch4.txt
 cd "$(dirname "$0")/.."

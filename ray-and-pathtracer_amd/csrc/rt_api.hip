@@ -87,6 +87,7 @@ struct rt_ctx {
 	uint* megaCost = nullptr; uint* megaOrder = nullptr; uint* megaHist = nullptr;
 	size_t megaCostCap = 0;
 	unsigned megaCostSamples = 0, megaCostFirst = 0; // the batch megaCost describes (0 samples: nothing yet)
+	int exactGamma = 0;      // RT_EXACT_GAMMA: the gamma of a finished sample as the reference's double-precision pow (rt_kernels.h gamma_powf)
 	int deferGamma = 1;      // RT_DEFER_GAMMA: path-mode samples get their gamma in k_accumulate (rt_kernels.h store_sample)
 	int megaLpt = 1;         // RT_MEGA_LPT: 0 keeps the multiplicative permutation
 	int useMega = 1;         // RT_MEGA: 1 Whitted frames as one launch (default), 0 the wavefront rounds of rt_kernels.h
@@ -285,6 +286,14 @@ rt_ctx* rt_create(int device, int width, int height)
 	memset(&c->slot.P, 0, sizeof(PathState)), memset(&c->slot.Q, 0, sizeof(Queues));
 	if (getenv("RT_FUSE")) { const int f = atoi(getenv("RT_FUSE")); c->fuseTraversal = f < 0 ? -1 : (f > 2 ? 2 : f); } // 0 one kernel at a time, 1 one traversal launch per round, 2 connect + light on a second stream; negative: the default by batch size
 	if (getenv("RT_STREAM")) c->useStream = atoi(getenv("RT_STREAM")) != 0;
+	{
+		// the scheduling thresholds are compile-time constants since round 4 (rt_scene_dev.h): a sweep script that still sets them in
+		// the environment would read as a flat sweep -- say so once
+		static bool warned = false;
+		const char* retired[] = { "RT_REFILL", "RT_REFILL_ANY", "RT_STEPMIN", "RT_STEPMIN_ANY", "RT_STEPMIN_XFORM", "RT_PAIRAGAIN", "RT_PAIRAGAIN_ANY", "RT_DRAIN_LANES", "RT_DRAIN_LANES_ANY" };
+		for (const char* name : retired)
+			if (!warned && getenv(name)) { fprintf(stderr, "rt_amd: %s is a compile-time constant (rebuild with make EXTRA=-D%s=N); the environment variable is ignored\n", name, name); warned = true; }
+	}
 	if (getenv("RT_DECIDE")) c->decideRays = atoi(getenv("RT_DECIDE")) & 3; // 0 off, 1 on, 2 / 3 on, but generate leaves the finished camera samples to the first shade
 	if (getenv("RT_MEGA")) c->useMega = atoi(getenv("RT_MEGA")) != 0;
 	if (getenv("RT_MEGA_LPT")) c->megaLpt = atoi(getenv("RT_MEGA_LPT")) != 0;
@@ -335,6 +344,12 @@ rt_ctx* rt_create(int device, int width, int height)
 	ok = ok && hipMemset(c->counters, 0, 2 * sizeof(DCounters)) == hipSuccess;
 	ok = ok && hipHostMalloc((void**)&c->hostCounts, 16 * sizeof(int)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&c->gammaLut, 256 * sizeof(float)) == hipSuccess;
+	if (ok) {
+		const int exact = getenv("RT_EXACT_GAMMA") && atoi(getenv("RT_EXACT_GAMMA")) != 0 ? 1 : 0; // rt_kernels.h gamma_powf
+		ok = hipMemcpyToSymbol(HIP_SYMBOL(g_exactGamma), &exact, sizeof(int), 0, hipMemcpyHostToDevice) == hipSuccess;
+		c->exactGamma = exact;
+		if (exact) c->deferGamma = 1; // the exact form lives where samples are read (k_accumulate), not in the shading kernels
+	}
 	if (ok) hipLaunchKernelGGL(k_gamma_lut, dim3(1), dim3(256), 0, c->stream, c->gammaLut);
 	if (!ok) { fail(nullptr, RT_E_HIP, "rt_create: device allocation failed: %s", hipGetErrorString(hipGetLastError())); rt_destroy(c); return nullptr; }
 	// default camera = Camera::Camera (camera.h:10-22) for this aspect
@@ -2221,9 +2236,9 @@ const char* rt_tuning_info(rt_ctx* c)
 {
 	if (!c) return "";
 	char buf[640];
-	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
+	snprintf(buf, sizeof(buf), "stream=%d decide=%d fuse=%d refill=%d refill_any=%d stepmin=%d stepmin_any=%d stepmin_xform=%d pairagain=%d pairagain_any=%d drain=%d drain_any=%d shade_lds=%d gamma_lut=%d exact_gamma=%d defer_gamma=%d wide=%d wide8=%d mega=%d mega_levels=%d mega_lpt=%d qlearn=%d tlas_lds=%d stack_rows=%d slots=%d",
 	         c->useStream, c->decideRays, c->fuseTraversal, RT_REFILL, RT_REFILL_ANY, RT_STEPMIN, RT_STEPMIN_ANY, RT_STEPMIN_XFORM,
-	         RT_PAIRAGAIN, RT_PAIRAGAIN_ANY, RT_DRAIN_LANES, RT_DRAIN_LANES_ANY, c->shadeLds, c->S.gammaLut ? 1 : 0, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
+	         RT_PAIRAGAIN, RT_PAIRAGAIN_ANY, RT_DRAIN_LANES, RT_DRAIN_LANES_ANY, c->shadeLds, c->S.gammaLut ? 1 : 0, c->exactGamma, c->deferGamma, c->S.wide ? 1 : 0, c->S.wide8 ? 1 : 0, c->useMega, c->megaLevels, c->megaLpt, c->Qt.on,
 	         c->S.tlasLds, c->S.stackRows, slot_budget(c));
 	c->tuningInfo = buf;
 	return c->tuningInfo.c_str();

@@ -195,6 +195,12 @@ __device__ __forceinline__ f3 sky_color(const DScene& S, const f3& D)
 // <= 2 on the 256 sky values: tests/test_gpu_parity.py::test_gamma_of_finished_samples).  Values outside [1e-30, 1e30] -- zero,
 // negatives, NaN, inf (a directly viewed light, Q7), denormals -- take the library's powf.  ONE function everywhere a finished
 // sample is made (here, k_accumulate, k_gamma_lut), so the knobs that move the gamma between kernels still give identical bits.
+// RT_EXACT_GAMMA=1 (read at rt_create, one value per device): the reference's expression itself, pow in double rounded to float
+// (x_powf) -- what rounds 1-3 computed.  With it the accumulator's bits are the oracle's wherever the radiance's are; the parity
+// tier runs once that way (tests/test_gpu_parity.py::test_exact_gamma_switch), the product keeps the fast form.
+// (Only where samples are READ -- k_accumulate, k_gamma_lut -- : the switch forces the deferred gamma, so the shading kernels,
+// whose register budget a double-precision pow in their call graph would eat, never see it.)
+__device__ int g_exactGamma;
 __device__ __forceinline__ float gamma_powf(float x)
 {
 	if (!(x >= 1e-30f && x <= 1e30f)) return powf(x, RT_GAMMA);
@@ -210,7 +216,7 @@ __global__ void k_gamma_lut(float* lut)
 {
 	const int b = (int)threadIdx.x;
 	const f3 c = f3((float)b, (float)b, (float)b) / 255;
-	lut[b] = gamma_powf(c.x * 1);
+	lut[b] = g_exactGamma ? x_powf(c.x * 1, RT_GAMMA) : gamma_powf(c.x * 1);
 }
 
 // diffuse::scatter (template/scene.h:605-620): att out, energy in/out
@@ -973,7 +979,7 @@ __global__ void k_accumulate(DCamera C, RenderParams R, int batchFrames)
 	float4 a = R.accum[pixel];
 	for (int f = 0; f < batchFrames; f++) {
 		float4 s = R.samples[(size_t)f * R.tilePixels + lp];
-		if (s.w != 0) s = gamma_sample(xyz(s)); // stored raw (R.deferGamma)
+		if (s.w != 0) s = g_exactGamma ? make_float4(x_powf(s.x * 1, RT_GAMMA), x_powf(s.y * 1, RT_GAMMA), x_powf(s.z * 1, RT_GAMMA), 0.0f) : gamma_sample(xyz(s)); // stored raw (R.deferGamma)
 		a.x += s.x, a.y += s.y, a.z += s.z, a.w += 0;
 	}
 	R.accum[pixel] = a;
