@@ -235,6 +235,15 @@ def main():
                                        r.build_info(), sec_per_step, prof["connect"]),
         }
         out["frame_checksum"] = "%016x" % int(torch.sum(acc.view(torch.int32).to(torch.int64)).item() & 0xFFFFFFFFFFFFFFFF)
+        # several ranks: the gathered frame must be the one-GPU frame bit for bit (rows are independent, sums are in frame order); the
+        # committed one-GPU line of the same workload is the witness (its own frame was compared with the oracle's: parity_check there)
+        try:
+            ref = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench.json")))
+            if ref["metric"] == out["metric"] and not args.qlearn and args.emulate_world <= 1:
+                out["frame_checksum_of_committed_1gpu_line"] = ref["frame_checksum"]
+                out["frame_equals_committed_1gpu_frame"] = ref["frame_checksum"] == out["frame_checksum"]
+        except Exception:
+            pass
         parity_ok = True
         if world == 1 and not args.no_cpu_baseline:
             can_check = not args.qlearn and args.emulate_world <= 1
