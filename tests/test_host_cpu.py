@@ -225,3 +225,39 @@ def test_partition_closed_form_equals_the_loop():
         p = rnd.random()
         is_left = {x: rnd.random() < p for x in a}
         assert loop(a, is_left) == closed_form(a, is_left)
+
+
+def test_bench_plumbing_without_a_gpu(tmp_path, monkeypatch):
+    """bench.py's host-side plumbing that needs no device: the kernel hash covers the kernel sources and the build string (a profile
+    measured on other sources is never quoted: roofline_pmc.json, the out-of-cache files), the frame comparison of parity_check
+    (tests/conftest.py rel_err's rule), the CPU allowance parser, and -- `python bench.py --gpus N` with no WORLD_SIZE -- the
+    self-start: a child torch.distributed.run with N ranks on 127.0.0.1, before torch is imported, the exit code relayed."""
+    import importlib, subprocess, sys
+    from conftest import ROOT
+    bench = importlib.import_module("bench")
+    h0 = bench.kernel_hash("flags=[] A=1")
+    assert h0 == bench.kernel_hash("flags=[] A=1") and h0 != bench.kernel_hash("flags=[-DX] A=1") and len(h0) == 16
+    # the committed counter file and the out-of-cache files are stamped with hashes of this shape
+    import json
+    pj = json.load(open(os.path.join(ROOT, "profiles", "roofline_pmc.json")))
+    assert all(re.fullmatch(r"[0-9a-f]{16}", w["kernel_hash"]) for w in pj["by_world"].values())
+    a = np.array([[1.0, 2.0, np.inf], [0.0, 1e-9, np.nan]])
+    b = np.array([[1.0, 2.0002, np.inf], [0.0, 0.0, np.nan]])
+    err, cls_ok = bench.frame_error(a, b)
+    assert cls_ok and abs(err - 0.0002 / 2.0002) < 1e-9
+    assert not bench.frame_error(np.array([1.0, np.inf]), np.array([1.0, -np.inf]))[1]
+    allowed = bench.cpu_allowance()
+    assert allowed is None or allowed > 0
+    # the self-start, with a stand-in for torch.distributed.run on the path: it records its arguments and exits 7
+    fake = tmp_path / "torch" / "distributed"
+    fake.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (fake / "__init__.py").write_text("")
+    (fake / "run.py").write_text("import sys, json\njson.dump(sys.argv[1:], open(%r, 'w'))\nsys.exit(7)\n" % str(tmp_path / "argv.json"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PYTHONPATH"] = str(tmp_path) + os.pathsep + env.get("PYTHONPATH", "")
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2"], env=env, cwd=ROOT).returncode
+    assert rc == 7
+    argv = json.load(open(tmp_path / "argv.json"))
+    assert argv[:2] == ["--nnodes=1", "--nproc-per-node"] and argv[2] == "3" and "--master-addr" in argv and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[-4:] == ["--gpus", "3", "--steps", "2"] and argv[-5].endswith("bench.py")
