@@ -30,7 +30,7 @@ typedef enum {
 	RT_E_HIP = -3,         /* HIP runtime error */
 	RT_E_UNSUPPORTED = -4, /* scene feature outside the device path (see rt_upload_scene) */
 	RT_E_STATE = -5,       /* call order (e.g. render before upload) */
-	RT_E_OVERFLOW = -6     /* traversal stack deeper than 130 = tlas.cpp:67 stack[64] + instance sentinel + bvh.cpp:608 stack[64], too many pending Whitted branches, or (Q-learning sampler) more than 2^19 rewards for one (cell, direction) between two rt_qlearn_apply calls */
+	RT_E_OVERFLOW = -6     /* traversal stack deeper than 130 = tlas.cpp:67 stack[64] + instance sentinel + bvh.cpp:608 stack[64], too many pending Whitted branches, or (Q-learning sampler) more than 2^19 rewards for one (cell, direction) within one batch of frames of a render call (reported by that call) */
 } rt_status;
 
 /* ---- scene records -------------------------------------------------------------------------
@@ -184,7 +184,14 @@ int rt_bind_accumulator(rt_ctx* ctx, void* device_ptr);
  * rows; the host does not wait.  src's accumulator must not be re-bound or freed before dst has synchronised.
  * May be called from src's host thread while another thread drives dst (only stream operations touch dst; EVERY
  * error of the call, the argument checks included, is reported on src: rt_last_error(src)).  Both contexts
- * must have the same width and height.  rt_device_of: the HIP device a context lives on. */
+ * must have the same width and height.  rt_device_of: the HIP device a context lives on.
+ * rt_gather_begin(dst): called by dst's owner ONCE PER FRAME, after whatever must precede the frame's rows on dst (rt_clear, the
+ * resolve of the frame before) and BEFORE dst's own share of the frame is queued: it marks "dst's rows are free" on dst's stream,
+ * and every rt_gather_rows into dst until the next rt_gather_begin waits for that mark only -- not for dst's own rendering of
+ * the frame, and not for the pushes of the sources that called earlier: the pushes then run side by side, each over its own
+ * xGMI link.  Without it (never called on dst) every gather orders itself behind all that dst's stream held when it was
+ * called, which is correct and serialises the pushes behind dst's rendering. */
+int rt_gather_begin(rt_ctx* dst);
 int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int row_count);
 int rt_device_of(const rt_ctx* ctx);
 

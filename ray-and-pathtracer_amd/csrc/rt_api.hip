@@ -68,6 +68,7 @@ struct rt_ctx {
 	hipEvent_t streamFork = nullptr, streamJoin = nullptr;
 	hipEvent_t gatherDone = nullptr; // rt_gather_rows with this context as the source: its rows have arrived at the destination
 	hipEvent_t gatherReady = nullptr; // ... and, recorded on the destination's stream before the push: what the destination had queued is done
+	hipEvent_t rowsFree = nullptr;    // this context as a DESTINATION: recorded by rt_gather_begin on its stream, once per frame, before its own share is queued
 	int useStream = 1;       // RT_STREAM: 1 the dense pipeline for path batches with an entry per sample (default), 0 the slot pipeline of rt_kernels.h
 	// Renderer::Trace as one persistent launch per frame (rt_mega.h)
 	MegaState M;
@@ -382,6 +383,7 @@ void rt_destroy(rt_ctx* c)
 	if (c->streamJoin) (void)hipEventDestroy(c->streamJoin);
 	if (c->gatherDone) (void)hipEventDestroy(c->gatherDone);
 	if (c->gatherReady) (void)hipEventDestroy(c->gatherReady);
+	if (c->rowsFree) (void)hipEventDestroy(c->rowsFree);
 	for (int k = 0; k < 2; k++) if (c->megaEv[k]) (void)hipEventDestroy(c->megaEv[k]);
 	if (c->accum && c->accumOwned) (void)hipFree(c->accum);
 	if (c->spill) (void)hipFree(c->spill);
@@ -1624,9 +1626,20 @@ static int run_rounds_stream(rt_ctx* c, const RenderParams& R, int rounds)
 	if (pendingJoin) HIPCHK(c, hipStreamWaitEvent(st, c->streamJoin, 0));
 	if (cnt) hipLaunchKernelGGL(k_fold_decided, dim3(1), dim3(1), 0, st, c->S, T.counts, c->counters);
 	HIPCHK(c, hipMemcpyAsync(c->hostCounts, T.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+	c->hostCounts[4] = 0;
+	if (c->Qt.on) {
+		// the batch's packed reward words -> the wide sums, in stream order; the overflow word rides home with the round flags
+		const int nq = c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
+		hipLaunchKernelGGL(k_q_fold, dim3((nq + 255) / 256), dim3(256), 0, st, c->Qt);
+		HIPCHK(c, hipMemcpyAsync(c->hostCounts + 4, c->Qt.ovf, sizeof(int), hipMemcpyDeviceToHost, st));
+	}
 	HIPCHK(c, hipStreamSynchronize(st));
 	const int* hc = c->hostCounts;
 	int rc = RT_OK;
+	if (hc[4] != 0) {
+		(void)hipMemsetAsync(c->Qt.ovf, 0, sizeof(int), st);
+		return fail(c, RT_E_OVERFLOW, "Q-learning sampler: more than %u rewards for one (cell, direction) within one batch of frames: render fewer frames per call", RT_Q_ACC_LIMIT);
+	}
 	if (hc[3] == 1) rc = fail(c, RT_E_OVERFLOW, "traversal stack deeper than %d entries", RT_STACK_MAX);
 	else if (hc[3] == 199) rc = fail(c, RT_E_STATE, "a traversal launch met a link no step understands (corrupt tree?) and dropped rays");
 	else if (hc[3] >= 100) rc = fail(c, RT_E_STATE, "debug check %d failed in a wavefront kernel (RT_DEBUG_CHECKS build)", hc[3] - 100);
@@ -1862,6 +1875,15 @@ int rt_bind_accumulator(rt_ctx* c, void* p)
 
 int rt_device_of(const rt_ctx* c) { return c ? c->device : -1; }
 
+int rt_gather_begin(rt_ctx* dst)
+{
+	if (!dst) return RT_E_ARG;
+	HIPCHK(dst, hipSetDevice(dst->device));
+	if (!dst->rowsFree) HIPCHK(dst, hipEventCreateWithFlags(&dst->rowsFree, hipEventDisableTiming));
+	HIPCHK(dst, hipEventRecord(dst->rowsFree, dst->stream));
+	return RT_OK;
+}
+
 int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int row_count)
 {
 	// (every error of this call is reported on SRC -- rt_last_error(src) -- : the call may come from the source context's host
@@ -1877,11 +1899,19 @@ int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int 
 	// The push must also come AFTER whatever is already queued on the destination's stream and touches these rows (rt_clear's
 	// whole-frame memset on a camera change, the destination's own resolve of the frame before): the source's stream waits for
 	// an event recorded on the destination's stream first.  Work queued on dst->stream after this call is ordered by the second event.
-	HIPCHK(src, hipSetDevice(dst->device));
-	if (!src->gatherReady) HIPCHK(src, hipEventCreateWithFlags(&src->gatherReady, hipEventDisableTiming));
-	HIPCHK(src, hipEventRecord(src->gatherReady, dst->stream));
-	HIPCHK(src, hipSetDevice(src->device));
-	HIPCHK(src, hipStreamWaitEvent(src->stream, src->gatherReady, 0));
+	// Which event: the destination's own "rows free" mark of this frame when its owner set one (rt_gather_begin: before dst's share
+	// of the frame was queued, so the push waits neither for dst's rendering nor for the sources that pushed earlier -- the pushes
+	// overlap, one xGMI link each); otherwise one recorded now, behind everything dst's stream holds at this moment.
+	if (dst->rowsFree) {
+		HIPCHK(src, hipSetDevice(src->device));
+		HIPCHK(src, hipStreamWaitEvent(src->stream, dst->rowsFree, 0));
+	} else {
+		HIPCHK(src, hipSetDevice(dst->device));
+		if (!src->gatherReady) HIPCHK(src, hipEventCreateWithFlags(&src->gatherReady, hipEventDisableTiming));
+		HIPCHK(src, hipEventRecord(src->gatherReady, dst->stream));
+		HIPCHK(src, hipSetDevice(src->device));
+		HIPCHK(src, hipStreamWaitEvent(src->stream, src->gatherReady, 0));
+	}
 	const size_t rowBytes = (size_t)dst->width * sizeof(float4), pitch = rowBytes * (size_t)row_stride;
 	const float4* from = src->accum + (size_t)row_first * src->width;
 	float4* to = dst->accum + (size_t)row_first * dst->width;
@@ -2151,6 +2181,8 @@ int rt_qlearn_enable(rt_ctx* c, const rt_qlearn_params* p)
 	HIPCHK(c, dalloc(c->qAllocs, &Q.acc, cells * RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &centre, (size_t)RT_Q_PATCHES));
 	HIPCHK(c, dalloc(c->qAllocs, &wgt, (size_t)RT_Q_PATCHES * RT_Q_PATCHES));
+	HIPCHK(c, dalloc(c->qAllocs, &Q.ovf, (size_t)4)); // the sampler's own overflow word (flags[2] belongs to the wide occlusion walk's leftover count)
+	HIPCHK(c, hipMemsetAsync(Q.ovf, 0, 4 * sizeof(int), c->stream));
 	Q.centre = centre, Q.wgt = wgt, Q.grid = p->grid, Q.on = 1;
 	for (int a = 0; a < 3; a++) Q.lo[a] = p->lo[a], Q.inv[a] = (float)p->grid / (p->hi[a] - p->lo[a]);
 	Q.eps = p->epsilon, Q.alpha = p->alpha, Q.qMin = 1e-4f, Q.learnMask = p->learn_mask;
@@ -2160,27 +2192,12 @@ int rt_qlearn_enable(rt_ctx* c, const rt_qlearn_params* p)
 	c->Qt = Q;
 	return RT_OK;
 }
-// the batch's packed reward words -> the wide sums (rt_qlearn.h k_q_fold); waits for the stream and reports a count field near its end
-static int qlearn_fold(rt_ctx* c, const char* who)
-{
-	const int n = c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
-	int* flag = c->flags + 2;
-	hipLaunchKernelGGL(k_q_fold, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Qt, flag);
-	int f = 0;
-	HIPCHK(c, hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
-	if (f) {
-		(void)hipMemsetAsync(flag, 0, sizeof(int), c->stream);
-		return fail(c, RT_E_OVERFLOW, "%s: more than %u rewards for one (cell, direction) since the last fold: render fewer frames between rt_qlearn_apply calls", who, RT_Q_ACC_LIMIT);
-	}
-	return RT_OK;
-}
 int rt_qlearn_apply(rt_ctx* c)
 {
 	if (!c || !c->Qt.on) return fail(c, RT_E_STATE, "rt_qlearn_apply: the sampler is off");
 	HIPCHK(c, hipSetDevice(c->device));
-	const int rc = qlearn_fold(c, "rt_qlearn_apply");
-	if (rc != RT_OK) return rc;
+	// stream-ordered, no host wait: the rewards of every batch were folded into the wide sums at the batch's end (run_rounds_stream),
+	// where a count field past its limit was reported by the render call itself
 	const int cells = c->Qt.grid * c->Qt.grid * c->Qt.grid;
 	hipLaunchKernelGGL(k_q_apply, dim3((cells + 63) / 64), dim3(64), 0, c->stream, c->Qt); // a 64 x 64 product per cell: one wave per block spreads the cells over the CUs
 	HIPCHK(c, hipGetLastError());
@@ -2191,8 +2208,7 @@ int rt_qlearn_get_sums(rt_ctx* c, int64_t* sums, uint32_t* counts)
 	if (!c || !c->Qt.on || !sums || !counts) return fail(c, RT_E_STATE, "rt_qlearn_get_sums: the sampler is off, or a null argument");
 	HIPCHK(c, hipSetDevice(c->device));
 	const size_t n = (size_t)c->Qt.grid * c->Qt.grid * c->Qt.grid * RT_Q_PATCHES;
-	const int rc = qlearn_fold(c, "rt_qlearn_get_sums");
-	if (rc != RT_OK) return rc;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
 	HIPCHK(c, hipMemcpy(sums, c->Qt.sum, n * 8, hipMemcpyDeviceToHost));
 	HIPCHK(c, hipMemcpy(counts, c->Qt.cnt, n * 4, hipMemcpyDeviceToHost));
 	return RT_OK;

@@ -45,6 +45,7 @@ struct QTable {
 	float lo[3], inv[3]; // cell = (int)((x - lo) * inv), clamped
 	float eps, alpha, qMin;
 	uint learnMask;      // a sample pays rewards iff (its stream's state after the pixel jitter) & learnMask == 0
+	int* ovf;            // sticky: a count field of acc[] got past RT_Q_ACC_LIMIT (q_reward sees it in the word it adds to, k_q_fold in the word it folds)
 };
 #define RT_Q_LEARNER 0x80000000u // bit of an entry's key word (W.w): this sample pays rewards
 
@@ -136,18 +137,22 @@ __global__ void k_q_apply(QTable Q)
 // chip (MI355X_MICROARCH.md "Global float atomics": 64 lanes in 64 rows 17x below the contiguous rate; measured here: config 5's
 // shade launches 0.79 s with 0.1 % of the samples paying rewards, 1.02 s with 25 %, 2.06 s with all -- profiles/r05_ab_qlearn_atomics.txt).
 // A reward was two of them (sum, count); it is ONE: the count rides in the top 20 bits of the 64-bit word, the sum (<= 2^22 per
-// reward) in the low 44.  k_q_fold moves the words into the wide sums between batches and reports a count field that got past
-// half its range (RT_Q_ACC_LIMIT rewards for one (cell, patch) within one batch: 7x what config 5 reaches with every sample
-// paying) as RT_E_OVERFLOW instead of letting it wrap.
+// reward) in the low 44.  k_q_fold moves the words into the wide sums at the end of every batch of frames (stream-ordered, no host
+// wait) and reports a count field that got past half its range (RT_Q_ACC_LIMIT rewards for one (cell, patch) within one batch: 7x
+// what config 5 reaches with every sample paying) as RT_E_OVERFLOW.  The field cannot wrap unseen either: the atomic returns the
+// word it added to, and a reward that lands on a count in [2^19, 2^20) -- bit 63 of the old word -- is reported by the lane that
+// paid it (the 2^19 rewards a word must take before its count wraps all see that bit).
 #define RT_Q_ACC_SHIFT 44
 #define RT_Q_ACC_LIMIT (1u << 19)
-__device__ __forceinline__ void q_reward(const QTable& Q, uint key, float R)
+// returns the top half of the word the reward was added to (bit 31: the count was already past RT_Q_ACC_LIMIT)
+__device__ __forceinline__ uint q_reward(const QTable& Q, uint key, float R)
 {
 	R = (R >= 0) ? (R < 64.0f ? R : 64.0f) : 0.0f; // a directly seen light is +inf in the reference (Q7); NaN teaches nothing
-	atomicAdd(&Q.acc[key - 1], (1ull << RT_Q_ACC_SHIFT) | (unsigned long long)__float2ll_rn(R * 65536.0f));
+	const unsigned long long old = atomicAdd(&Q.acc[key - 1], (1ull << RT_Q_ACC_SHIFT) | (unsigned long long)__float2ll_rn(R * 65536.0f));
+	return (uint)(old >> 32);
 }
-// acc[] -> sum[], cnt[] (one thread per (cell, patch)); *flag = 1 when a count field is past RT_Q_ACC_LIMIT
-__global__ void k_q_fold(QTable Q, int* flag)
+// acc[] -> sum[], cnt[] (one thread per (cell, patch)); *Q.ovf = 1 when a count field is past RT_Q_ACC_LIMIT
+__global__ void k_q_fold(QTable Q)
 {
 	const size_t n = (size_t)Q.grid * Q.grid * Q.grid * RT_Q_PATCHES;
 	const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,7 +162,7 @@ __global__ void k_q_fold(QTable Q, int* flag)
 	const uint c = (uint)(a >> RT_Q_ACC_SHIFT);
 	Q.sum[k] += (long long)(a & ((1ull << RT_Q_ACC_SHIFT) - 1)), Q.cnt[k] += c;
 	Q.acc[k] = 0;
-	if (c >= RT_Q_ACC_LIMIT) *flag = 1;
+	if (c >= RT_Q_ACC_LIMIT) *Q.ovf = 1;
 }
 // expected reflected Q at a surface hit (the integral of eq. 8 over the 64 patches): one value of the cell's V row for a diffuse
 // surface, the mean of the cell's Q for a specular one

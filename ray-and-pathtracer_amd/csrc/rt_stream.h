@@ -372,6 +372,7 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 {
 	__shared__ ShadeTables tables;
 	uint nDecided = 0;
+	uint qOld = 0; // QL: the words this lane's rewards were added to, or-ed (q_reward: bit 31 = a count field past its limit)
 	const int parity = round & 1;
 	prepare_round(T, round + 1, -1);
 	DScene S = S0;
@@ -426,18 +427,18 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 			if (id.x == -1) {
 				const f3 sky = sky_color(S, D);
 				Lsum = Lsum + W * sky; // renderer.cpp:134
-				if (QL && prevKey) q_reward(Qt, prevKey, q_lum(sky));
+				if (QL && prevKey) qOld |= q_reward(Qt, prevKey, q_lum(sky));
 			} else if (id.x >= 11 && id.x < 11 + S.nLights) {
 				const f3 li = light_intensity(S.lights[id.x - 11], I, normal, I);
 				Lsum = Lsum + W * li; // :135-137
-				if (QL && prevKey) q_reward(Qt, prevKey, q_lum(li));
+				if (QL && prevKey) qOld |= q_reward(Qt, prevKey, q_lum(li));
 			} else {
 				const DMaterial m = S.mats[id.y];
 				const f3 col(m.col[0], m.col[1], m.col[2]);
 				if (QL && prevKey) {
 					const bool dif = m.type != 3 && m.type != 2;
 					const f3 albedoQ(m.albedo[0], m.albedo[1], m.albedo[2]);
-					q_reward(Qt, prevKey, q_expected(Qt, q_cell(Qt, I), normal, dif ? q_lum(col * albedoQ) : q_lum(col), dif));
+					qOld |= q_reward(Qt, prevKey, q_expected(Qt, q_cell(Qt, I), normal, dif ? q_lum(col * albedoQ) : q_lum(col), dif));
 				}
 				if (m.type == 3) { // GLASS, renderer.cpp:198-233
 					const float kr = glass_fresnel(normalize(D), normalize(normal), m.ir);
@@ -492,7 +493,7 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 							nextKey = learner ? 1u + (uint)cell * RT_Q_PATCHES + (uint)patch : 0u;
 						} else {
 							deadSample = true; // below the surface: the patch learns a reward of 0, the path carries no weight on
-							if (learner) q_reward(Qt, 1u + (uint)cell * RT_Q_PATCHES + (uint)patch, 0.0f);
+							if (learner) qOld |= q_reward(Qt, 1u + (uint)cell * RT_Q_PATCHES + (uint)patch, 0.0f);
 						}
 					} else {
 						const f3 rayToHemi = RandomInHemisphere(seed, normal);
@@ -530,6 +531,7 @@ __global__ void __launch_bounds__(RT_BLOCK, QL ? RT_SHADE_Q_WAVES : RT_SHADE_S_W
 			} else store_sample(R, __float_as_uint(l4.w), Lsum);
 		}
 	}
+	if (QL && (qOld >> 31)) *Qt.ovf = 1;
 	if (counting) flush_decided(T.counts, nDecided);
 }
 

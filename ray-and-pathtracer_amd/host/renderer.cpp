@@ -152,6 +152,7 @@ void Renderer::Tick(float /*deltaTime*/)
 		// the scanline loop of renderer.cpp:259, one interleaved share of the rows per GPU, each on its context's own (parked)
 		// host thread; a share's rows are pushed to context 0 from that thread as soon as they are queued -- every gather is
 		// issued before anything waits (rt_gather_rows is asynchronous: context 0's stream waits for the rows, not the host)
+		check(ctx, rt_gather_begin(ctx)); // context 0's rows are free from here on (after the clear above and the resolve of the frame before): the pushes wait for this mark alone
 		workers->run([&](int k) {
 			const int count = (height - k + n - 1) / n;
 			if (count <= 0) return;

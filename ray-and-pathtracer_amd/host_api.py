@@ -24,7 +24,7 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_render", "rt_render_rows", "rt_clear", "rt_download_accumulator", "rt_resolve", "rt_accumulator_device_ptr",
               "rt_bind_accumulator", "rt_intersect_batch", "rt_occluded_batch", "rt_primary_hits", "rt_trace_batch",
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
-              "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_device_of",
+              "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_gather_begin", "rt_device_of",
               "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy", "rt_build_info", "rt_tuning_info",
               "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table"]
 
@@ -57,7 +57,7 @@ RT_HIT_DTYPE = np.dtype([("t", np.float32), ("obj_idx", np.int32), ("material", 
 def build(force=False):
     """Compile both product libraries in-tree (hipcc cross-compiles gfx950 without a GPU)."""
     def stale(so, d):
-        srcs = [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".cpp", ".hip"))]
+        srcs = [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".cpp", ".hip", ".inc")) or f == "Makefile"]
         srcs.append(os.path.join(_HERE, "..", "include", "rt_amd.h"))
         return force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale(RT_SO, os.path.join(_HERE, "csrc")):

@@ -1408,8 +1408,10 @@ def test_qlearning_sampler_variance_falls_with_learning(scenes, oracle_api, host
 
 def test_qlearning_reward_words_report_overflow(scenes, host_api):
     """A reward is ONE packed 64-bit atomic (count << 44 | 48.16 sum, csrc/rt_qlearn.h q_reward); the words are folded into the wide
-    sums at rt_qlearn_apply / rt_qlearn_get_sums.  A count field past half its range must come back as RT_E_OVERFLOW, never wrap
-    silently: a 1-cell grid with every sample paying puts a whole 1080p batch on 64 words."""
+    sums at the end of every batch of frames of a render call.  A count field past half its range must come back as RT_E_OVERFLOW
+    from that call, never wrap silently: a 1-cell grid with every sample paying puts a whole 1080p batch on 64 words.  Two sizes:
+    64 frames leave the busiest count inside [2^19, 2^20) (the fold sees it); 128 frames (~1.9 M rewards per word) carry it past
+    2^20, where the field has wrapped by the time it is folded -- the lanes that paid into a word with bit 63 set saw it."""
     w, h = 1920, 1080
     r = host_api.HostRenderer(w, h)
     scenes.REGISTRY["mixed_small"](r.scene)
@@ -1418,10 +1420,31 @@ def test_qlearning_reward_words_report_overflow(scenes, host_api):
     r.clear(); r.render(host_api.RT_MODE_PATH, 0, 2)
     sums, cnts = r.qlearn_sums()  # two frames: well inside the range, and exact
     assert 0 < cnts.max() < (1 << 19) and cnts.sum() > w * h // 4
+    per_frame = int(cnts.max()) // 2
     r.qlearn_apply()
-    r.render(host_api.RT_MODE_PATH, 2, 64)  # ~15 k rewards per word and frame
-    with pytest.raises(RuntimeError, match="rewards for one"):
-        r.qlearn_apply()
+    assert (1 << 19) <= per_frame * 64 < (1 << 20) < per_frame * 128, per_frame
+    for frames in (64, 128):  # ~15 k rewards per word and frame
+        with pytest.raises(RuntimeError, match="rewards for one"):
+            r.render(host_api.RT_MODE_PATH, 2, frames)
+        r.qlearn_enable(1, (-50, -50, -50), (50, 50, 50), 0.3, 0.2, 1.0, 0)  # a fresh table
+    r.close()
+
+
+def test_qlearning_flag_is_not_the_wide_walks(scenes, host_api):
+    """the sampler's overflow word used to be flags[2], which is also the 4-wide occlusion walk's count of rays it handed
+    back to the binary walk.  An axis-aligned shadow ray (not 'clean') on a scene with wide nodes left it > 0, and the next
+    rt_qlearn_apply / rt_qlearn_get_sums failed with a spurious RT_E_OVERFLOW.  The sampler has its own word now."""
+    r = host_api.HostRenderer(64, 40)
+    scenes.REGISTRY["mixed_small"](r.scene)  # one scene BVH: the wide walk is on by default
+    r.commit()
+    r.qlearn_enable(4, (-4, -1, -4), (4, 5, 6), 0.3, 0.2, 1.0, 0)
+    O = np.array([[0.0, 3.0, 0.0], [0.5, 3.0, 0.5]], np.float32)
+    D = np.array([[0.0, -1.0, 0.0], [0.0, -1.0, 0.0]], np.float32)  # axis-aligned: handed back by the wide walk
+    r.is_occluded(O, D)
+    r.render(host_api.RT_MODE_PATH, 0, 2)
+    r.qlearn_sums()
+    r.qlearn_apply()
+    r.synchronize()
     r.close()
 
 
