@@ -12,13 +12,19 @@ accumulator rows are gathered to rank 0 inside the step (strong scaling: total w
 
 Rank 0 prints ONE JSON line.  value = W*H*spp / seconds / 1e6, the reference's own definition of
 "Mrays/s" (renderer.cpp:300-304: primary pixel samples per second); all traced rays per second are
-reported beside it.  roofline: dominant kernel = k_extend (Scene::FindNearest), see roofline_block():
-the VALU lane throughput it reaches (it is bound by the CUs' vector pipelines, not by HBM), with the
-SURVEY.md 8(d) algorithmic-bytes rate (work counters from an untimed counting pass of the identical,
-deterministic workload / device time measured with HIP events on the kernel's stream during the timed
-steps) and the counter-measured HBM rate beside it.  cpu_baseline: the oracle (oracle/, the CPU
-restatement; kind "port") on the host cores this job may use and on one thread, on bounded samples; parity_check: the
-oracle's accumulator of those frames against the device's, the whole frame (rc != 0 above 1e-4).
+reported beside it.  roofline: dominant kernel = k_extend_s (Scene::FindNearest), see roofline_block():
+what binds it on this workload (the vector-memory path: texture addressers + L1; the scene lives in
+L2), with the SURVEY.md 8(d) algorithmic-bytes rate (work counters from an untimed counting pass of
+the identical, deterministic workload / device time measured with HIP events on the kernel's stream
+during the timed steps), the counter-measured HBM rate and the VALU figure beside it -- and, measured
+LIVE by this run outside the timed region (out_of_cache_leg), the same kernel on a scene the caches
+cannot hold (8.4 M-triangle terrain, built on the device): there SURVEY 8(d)'s bytes over the HBM
+peak is a roofline fraction (<= 1).  tick_ms / share_ms: Renderer::Tick latency (Whitted, path) and
+the eight 1/8 row shares of the headline step, live as well.  cpu_baseline: the oracle (oracle/,
+the CPU restatement; kind "port") on the host cores this job may use and on one thread, on bounded
+samples; parity_check: the oracle's accumulator of those frames against the device's, the whole
+frame (rc != 0 above 1e-4); the out-of-cache scene's crop of hits against the oracle's (rc != 0 when
+a bit differs).
 """
 import argparse
 import importlib
@@ -55,18 +61,19 @@ def main():
                     "(no process group, no gather): the counters of that share are what rank 0 of the N-GPU run is priced with")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world N: the rows of rank R instead of rank 0's (the N-GPU step is as "
                     "long as its SLOWEST share: profiles/r04_shares_all_ranks.txt)")
+    ap.add_argument("--no-legs", action="store_true", help="profiling runs: skip the live legs outside the timed region (out-of-cache terrain, Tick latency, 1/8 shares)")
+    ap.add_argument("--ooc-n", type=int, default=2048, help="out-of-cache leg: the terrain is 2 n^2 triangles (2048: 8.4 M, pairs + primitive records 0.94 GB)")
+    ap.add_argument("--ooc-spp", type=int, default=16)
+    ap.add_argument("--ooc-steps", type=int, default=3)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by itself: start the N ranks as a CHILD process (torch.distributed.run, one rank per GPU) before
         # torch is imported or HIP touched in this one, relay rank 0's JSON line (the ranks inherit stdout) and the exit code
-        import socket
+        # (the launcher picks the rendezvous port itself -- endpoint port 0 -- : no bind-then-close race with other jobs on the box)
         import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--rdzv-backend=c10d",
+               "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd).returncode)
 
     import numpy as np
@@ -84,21 +91,25 @@ def main():
     # devices (local_rank % device_count) and the gather goes through host memory.  The driver's
     # multi-GPU runs use the default: one GPU per rank, "nccl" (= RCCL over xGMI).
     backend = os.environ.get("RAPT_DIST_BACKEND", "nccl")
+    ha, scenes, dpar = pkg("host_api"), pkg("scenes"), pkg("distributed")
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:  # before anything is initialised: a rank per GPU or no run
+        raise SystemExit("bench.py: --gpus %d over RCCL needs %d GPUs, %d visible" % (world, world, torch.cuda.device_count()))
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-
-    ha, scenes, dpar = pkg("host_api"), pkg("scenes"), pkg("distributed")
+        dpar.init_group(backend, rank, world, device_index)  # timeouts on the rendezvous and on every collective: a hang becomes a non-zero exit
     # one rank (re)builds stale libraries; the others wait, they would race in the same directory
     if rank == 0:
         ha.build()
     if world > 1:
         dist.barrier()
+    # which GPU every rank really sits on (PCI address through the C ABI), on every rank; two ranks on one GPU end an RCCL run here
+    red_dev0 = "cuda" if backend == "nccl" else "cpu"
+    ranks_devices = dpar.exchange_device_ids(ha.device_pci_bus_id(device_index), world, red_dev0)
+    try:
+        devices_distinct = dpar.check_rank_devices(ranks_devices, backend if world > 1 else "single")
+    except RuntimeError as e:
+        raise SystemExit("bench.py: %s" % e)
 
     # ---- workload ----
     probe = ha.HostScene()
@@ -132,6 +143,12 @@ def main():
 
     qbox = cfg.get("qbox", ((-12.0, -2.0, -8.0), (12.0, 10.0, 16.0)))
     timing, timed = {}, [False]  # render / gather split of the timed steps (several ranks)
+    # several ranks with the sampler on: the pending reward sums live in torch tensors on the device (rt_qlearn_bind_sums) and are
+    # all-reduced in place -- RCCL on device memory, no host copy in the exchange (the gloo rehearsal stages through the host)
+    qsum = qcnt = None
+    if args.qlearn and world > 1:
+        qsum = torch.zeros(16 ** 3 * 64, dtype=torch.int64, device="cuda")
+        qcnt = torch.zeros(16 ** 3 * 64, dtype=torch.int32, device="cuda")
 
     def step():
         acc.zero_()
@@ -141,14 +158,20 @@ def main():
             return
         # every step learns from scratch, so that the K timed steps do the same work
         r.qlearn_enable(16, qbox[0], qbox[1], 0.3, 0.2, 1.0, args.qlearn_mask)
+        if qsum is not None:
+            r.qlearn_bind_sums(qsum.data_ptr(), qcnt.data_ptr())
         first, stride, count = shard.rows()
         for f0 in range(0, spp, args.qlearn):
-            r.render_rows(mode, f0, min(args.qlearn, spp - f0), first, stride, count)
+            r.render_rows(mode, f0, min(args.qlearn, spp - f0), first, stride, count)  # (returns with the batch complete and its rewards folded into the sums)
             if world > 1:  # the one exchange step this sampler adds: integer sums, so the order of the reduction does not matter
-                sums, cnts = r.qlearn_sums()
-                ts, tc = torch.from_numpy(sums).to(red_dev_early), torch.from_numpy(cnts.astype(np.int64)).to(red_dev_early)
-                dist.all_reduce(ts), dist.all_reduce(tc)
-                r.qlearn_set_sums(ts.cpu().numpy(), tc.cpu().numpy().astype(np.uint32))
+                if red_dev_early == "cuda":
+                    dpar.all_reduce_reward_sums(qsum, qcnt)
+                    torch.cuda.current_stream().synchronize()  # the apply below runs on the renderer's own stream
+                else:
+                    hs, hc = qsum.cpu(), qcnt.cpu()
+                    dpar.all_reduce_reward_sums(hs, hc)
+                    qsum.copy_(hs), qcnt.copy_(hc)
+                    torch.cuda.synchronize()
             r.qlearn_apply()
         r.synchronize()
         if host_staging is None:
@@ -234,29 +257,201 @@ def main():
                                        {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]},
                                        r.build_info(), sec_per_step, prof["connect"]),
         }
-        out["frame_checksum"] = "%016x" % int(torch.sum(acc.view(torch.int32).to(torch.int64)).item() & 0xFFFFFFFFFFFFFFFF)
+        out["frame_checksum"] = frame_checksum(acc)
+        out["ranks_devices"] = ranks_devices  # PCI address of every rank's GPU, in rank order (one all-gather; distinct under RCCL or the run has ended above)
+        out["ranks_devices_distinct"] = bool(devices_distinct)
         # several ranks: the gathered frame must be the one-GPU frame bit for bit (rows are independent, sums are in frame order); the
         # committed one-GPU line of the same workload is the witness (its own frame was compared with the oracle's: parity_check there)
         try:
-            ref = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench.json")))
+            ref = json.load(open(os.path.join(ROOT, "profiles", "final_bench.json")))
             if ref["metric"] == out["metric"] and not args.qlearn and args.emulate_world <= 1:
                 out["frame_checksum_of_committed_1gpu_line"] = ref["frame_checksum"]
                 out["frame_equals_committed_1gpu_frame"] = ref["frame_checksum"] == out["frame_checksum"]
         except Exception:
             pass
-        parity_ok = True
+        failures = []
+        if int(seen.item()) != world:
+            failures.append("the process group held %d ranks, not %d" % (int(seen.item()), world))
+        if world > 1 and out.get("frame_equals_committed_1gpu_frame") is False:
+            failures.append("the gathered %d-rank frame is not the committed one-GPU frame (%s vs %s)" % (world, out["frame_checksum"], out["frame_checksum_of_committed_1gpu_line"]))
+        # ---- live legs outside the timed region (one GPU, the default workload): what the driver cannot see otherwise ----
+        plain = world == 1 and not args.qlearn and args.emulate_world <= 1 and args.workload == "config3" and not (args.width or args.height or args.spp)
+        terrain = None
+        if plain and not args.no_legs:
+            t_legs = time.perf_counter()
+            out["share_ms"] = share_leg(dpar, r, acc, mode, spp, H, W, sec_per_step * 1e3)
+            out["tick_ms"] = tick_leg(ha, scenes, device_index)
+            ooc, terrain = out_of_cache_leg(args, ha, scenes, device_index)
+            out["roofline"]["hbm"]["out_of_cache_live"] = ooc
+            out["gpu_leg_s"] = round(time.perf_counter() - t_legs, 2)
         if world == 1 and not args.no_cpu_baseline:
+            t_cpu = time.perf_counter()
             can_check = not args.qlearn and args.emulate_world <= 1
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(args, cfg, W, H, spp, (r, acc, mode, out["frame_checksum"]) if can_check else None)
-            parity_ok = out["parity_check"] is None or out["parity_check"]["ok"]
+            if out["parity_check"] is not None and not out["parity_check"]["ok"]:
+                failures.append("the frame differs from the oracle's beyond the tolerance: %s" % json.dumps(out["parity_check"]))
+            if terrain is not None:
+                crop = out_of_cache_crop_check(args, scenes, terrain)
+                out["roofline"]["hbm"]["out_of_cache_live"]["crop_parity"] = crop
+                if not crop["bit_exact"]:
+                    failures.append("out-of-cache scene: the crop's hits differ from the oracle's: %s" % json.dumps(crop))
+            out["cpu_leg_s"] = round(time.perf_counter() - t_cpu, 2)
+        if terrain is not None:
+            terrain[0].close()
+        out["timed_region_s"] = round(dt, 3)
         print(json.dumps(out), flush=True)
-        if not parity_ok:
+        if failures:
             r.close()
-            raise SystemExit("bench.py: the frame differs from the oracle's beyond the tolerance: %s" % json.dumps(out["parity_check"]))
+            raise SystemExit("bench.py: " + "; ".join(failures))
     r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def frame_checksum(acc, rows=None):
+    """64-bit sum of the accumulator's float bits (of the rows first::stride when given): equal frames, equal sums"""
+    import torch
+    a = acc if rows is None else acc[rows[0]::rows[1]]
+    return "%016x" % int(torch.sum(a.contiguous().view(torch.int32).to(torch.int64)).item() & 0xFFFFFFFFFFFFFFFF)
+
+
+def share_leg(dpar, r, acc, mode, spp, H, W, full_ms, world=8, steps=3):
+    """The eight interleaved 1/8 row shares of the headline step, each rendered alone on this GPU (what rank k of an 8-GPU run
+    renders; no process group, no gather): an N-GPU step is as long as its slowest share, so full / max is the speed-up the row
+    shard can reach before the exchange -- a projection from one GPU, not a multi-GPU measurement."""
+    import torch
+    ms, sums = [], []
+    for k in range(world):
+        shard = dpar.RowShard(H, W, 0, 1, acc.device)
+        shard.first, shard.stride, shard.count = dpar.shard_rows(H, k, world)
+        best = None
+        for it in range(steps + 1):  # the first one warms the share's state sizes up
+            acc.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dpar.render_step(r, acc, mode, 0, spp, shard)
+            dt = (time.perf_counter() - t0) * 1e3
+            if it > 0:
+                best = dt if best is None else min(best, dt)
+        ms.append(round(best, 3))
+        sums.append(frame_checksum(acc, (k, world)))
+    return {"world": world, "per_rank": ms, "slowest": max(ms), "mean": round(sum(ms) / len(ms), 3), "steps": steps, "statistic": "best of %d" % steps,
+            "full_step_ms": round(full_ms, 3), "projected_speedup": round(full_ms / max(ms), 3), "row_set_checksums": sums,
+            "note": "projection from ONE GPU (each share alone on it; no exchange): not a multi-GPU measurement"}
+
+
+def tick_leg(ha, scenes, device_index, ticks=20):
+    """rapt::Renderer::Tick (renderer.cpp:240-305: one frame per call, pixels resolved to the host every call) at 1920x1080 on the
+    headline scene, Whitted and path mode: host-clock milliseconds per Tick, the accumulator's host mirror off (the PCIe-inclusive
+    figure with it on is in profiles/)."""
+    out = {"scene": "config3's (pretty_tlas, 8 instances), 1920x1080", "ticks": ticks, "includes": "rt_render + rt_resolve + the 8-MB pixel download of every Tick"}
+    for name, path in (("whitted", False), ("path", True)):
+        r = ha.HostRenderer(1920, 1080, device_index)
+        d = scenes.REGISTRY["config3"](r.scene)
+        r.commit()
+        c = d["camera"]
+        r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+        r.scene.set_raytracer(not path)
+        r.L.rth_renderer_set_download(r.h, 0)
+        for _ in range(6):
+            r.tick()
+        t0 = time.perf_counter()
+        for _ in range(ticks):
+            r.tick()
+        out[name] = round((time.perf_counter() - t0) / ticks * 1e3, 3)
+        px = r.tick_pixels()
+        out[name + "_pixels_checksum"] = "%016x" % (int(px.astype("uint64").sum()) & 0xFFFFFFFFFFFFFFFF)
+        r.close()
+    return out
+
+
+def out_of_cache_leg(args, ha, scenes, device_index):
+    """The regime north_star's "fraction of the HBM-read roofline on BVH traversal" is defined in: a scene the caches cannot hold.
+    scenes.terrain_scene: 2 n^2 triangles (n = 2048: 8.4 M, pair + primitive records 0.94 GB = several L2s + Infinity Caches), ONE
+    scene BVH built with rt_build_bvh_split ON THE DEVICE (binned SAH, the reference's tree bit for bit), rendered 1920x1080 x spp
+    in path mode: a counting pass gives SURVEY 8(d)'s bytes for exactly these rays (64 B per inner visit, 52 per primitive test,
+    48 per ray), HIP events on the kernel's stream give k_extend_s's time over the timed steps.  -> (record, (renderer, scene
+    description)); the renderer stays open for the crop check of the CPU leg."""
+    W, H, spp, steps = 1920, 1080, args.ooc_spp, args.ooc_steps
+    t0 = time.perf_counter()
+    r = ha.HostRenderer(W, H, device_index)
+    r.scene.device_build(r.ctx)  # Scene::BuildBVH -> rt_build_bvh_split
+    d = scenes.terrain_scene(r.scene, n=args.ooc_n)
+    t_build = time.perf_counter() - t0
+    r.commit()
+    t_commit = time.perf_counter() - t0 - t_build
+    c = d["camera"]
+    r.set_camera(c["cam_pos"], c["top_left"], c["top_right"], c["bottom_left"])
+    info = r.scene.bvh_dump_info()
+    pair_bytes, prim_bytes = info["nodes_used"] // 2 * 64, info["N"] * 64
+    r.set_counting(ha.RT_COUNT_EXECUTED)
+    r.counters()
+    r.clear(), r.render(ha.RT_MODE_PATH, 0, spp)
+    near, occl = r.counters_split()
+    r.set_counting(False)
+    r.clear(), r.render(ha.RT_MODE_PATH, 0, spp), r.synchronize()
+    r.set_profiling(True)
+    r.profile()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        r.clear(), r.render(ha.RT_MODE_PATH, 0, spp)
+    r.synchronize()
+    dt = (time.perf_counter() - t1) / steps
+    pr = r.profile()
+    r.set_profiling(False)
+    ext, con = pr["extend"], pr["connect"]
+    ext_ms, con_ms = ext["ms"] / max(1, ext["launches"]), con["ms"] / max(1, con["launches"])
+    b_ext, b_con = ha.algorithmic_bytes(near), ha.algorithmic_bytes(occl)
+    per_launch = b_ext / max(1.0, ext["launches"] / steps)
+    rec = {"scene": "terrain n=%d: %d triangles, %d BVH nodes, pair + primitive records %.3f GB; built by rt_build_bvh_split on the device (binned SAH)" % (args.ooc_n, d["triangles"], info["nodes_used"], (pair_bytes + prim_bytes) / 1e9),
+           "scene_bytes": pair_bytes + prim_bytes, "frame": "%dx%d x %d spp, path integrator" % (W, H, spp), "steps": steps,
+           "build_s": round(t_build, 2), "upload_s": round(t_commit, 2), "ms_per_step": round(dt * 1e3, 3),
+           "kernel": "k_extend_s<false>", "kernel_ms": round(ext_ms, 4), "launches_per_step": ext["launches"] / steps,
+           "algorithmic_bytes_per_launch": int(per_launch), "algorithmic_GBps": round(per_launch / (ext_ms * 1e-3) / 1e9, 1),
+           "frac_of_hbm_peak": round(per_launch / (ext_ms * 1e-3) / 8e12, 4), "peak_GBps": 8000.0,
+           "connect_kernel_ms": round(con_ms, 4), "connect_algorithmic_GBps": round(b_con / max(1.0, con["launches"] / steps) / (con_ms * 1e-3) / 1e9, 1) if con_ms > 0 else None,
+           "work_per_step": {k: int(near[k]) for k in ("inner_visits", "prim_tests", "rays_nearest")},
+           "kernel_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in pr.items() if v["launches"]},
+           "note": "SURVEY 8(d) bytes of the rays actually traced / HIP-event kernel time; the counter-measured HBM rate of the same kernel on the same scene is in counters (when profiles/out_of_cache_pmc.json was measured on these kernel sources)"}
+    src_hash = kernel_hash(r.build_info().split(" | ")[0])
+    try:  # the counter side (rocprofv3 --pmc of profiles/out_of_cache.py: HBM bytes, L2 hit rate, TA busy), quoted only while it is these kernels'
+        pj = json.load(open(os.path.join(ROOT, "profiles", "out_of_cache_pmc.json")))
+        if pj.get("kernel_hash") == src_hash:
+            k = pj["kernels"]["k_extend_s<false>"]
+            rec["counters"] = {"file": "profiles/out_of_cache_pmc.json", "hbm_TBps": k["hbm_TBps"], "frac_of_hbm_peak": k["frac_of_8TBps"], "l2_hit_rate": k["l2_hit_rate"], "ta_busy_avg": k["ta_busy_avg"]}
+        else:
+            rec["counters"] = {"file": "profiles/out_of_cache_pmc.json", "used": False, "why": "measured on other kernel sources (%s, these are %s)" % (pj.get("kernel_hash"), src_hash)}
+    except Exception:
+        rec["counters"] = None
+    return rec, (r, d)
+
+
+def out_of_cache_crop_check(args, scenes, terrain):
+    """CPU leg: the oracle builds the same terrain and the same tree on the host and answers the primary rays of a 64 x 64 crop of
+    the frame (below the horizon); the device's hit ids, distances, normals and occlusion flags for the same rays must equal them
+    bit for bit (the witness that the out-of-cache figures were measured on the reference's traversal)."""
+    import numpy as np
+    from oracle import oracle_api as oa
+    r, d = terrain
+    W, H, c = 1920, 1080, d["camera"]
+    t0 = time.perf_counter()
+    o = oa.OracleScene()
+    scenes.terrain_scene(o, n=args.ooc_n)
+    tl, tr, bl = (np.array(c[k], np.float64) for k in ("top_left", "top_right", "bottom_left"))
+    x0, y0, n = 928, 560, 64
+    P = lambda x, y: tl + (x / W) * (tr - tl) + (y / H) * (bl - tl)
+    orr = oa.OracleRenderer(o, n, n)
+    orr.set_camera(c["cam_pos"], tuple(P(x0, y0)), tuple(P(x0 + n, y0)), tuple(P(x0, y0 + n)))
+    O, D = orr.primary_rays()
+    ref, got = o.find_nearest(O, D, t_min=1e-6), r.find_nearest(O, D, t_min=1e-6)
+    hit = ref["obj"] != -1
+    ok = (np.array_equal(got["obj"], ref["obj"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+          and np.array_equal(got["normal"][hit].view(np.uint32), ref["normal"][hit].view(np.uint32)))
+    ok = ok and np.array_equal(o.is_occluded(O, D)["occluded"], r.is_occluded(O, D))
+    orr.close()
+    o.close()
+    return {"crop": [x0, y0, n, n], "rays": int(len(O)), "hits": int(hit.sum()), "bit_exact": bool(ok), "oracle_s": round(time.perf_counter() - t0, 1)}
 
 
 def kernel_hash(build_info=""):
@@ -277,29 +472,35 @@ def kernel_hash(build_info=""):
 
 
 def roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, world, kernel_ms, build_info, sec_per_step, prof_connect):
-    """Dominant kernel k_extend (Scene::FindNearest).  What binds it, measured (DESIGN.md section 5): neither HBM
-    (the scene is a few MB and lives in L1/L2; counter HBM traffic is ~1.6 TB/s) nor MFMA (none on this path) but
-    the CUs' vector pipelines -- the VALU with ~43 % of its lanes enabled and the vector-memory (TA/L1) gather
-    path.  'frac' is therefore the enabled-lane VALU throughput against the chip's VALU peak (<= 1 by
-    construction), with the SURVEY 8(d) algorithmic-bytes rate and the counter-measured HBM rate beside it.
-      achieved = enabled-lane VALU instruction slots per launch (SQ_THREAD_CYCLES_VALU, from the committed PMC
-                 summary of these very kernel sources; the workload is deterministic, so the count is the same in
-                 every run) / the launch duration measured live with HIP events
-      peak     = 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (157.3 TFLOP/s fp32 at 2 flops per FMA)
-    Counter-derived fields are null when profiles/roofline_pmc.json was measured on other kernel sources, on
-    another workload size, or with more than one rank."""
+    """Dominant kernel k_extend_s (Scene::FindNearest).  What binds it ON THIS WORKLOAD, measured (DESIGN.md section 5): neither HBM
+    (the scene is a few MB and lives in L2: counter HBM traffic ~0.1 of the peak) nor MFMA (none on this path) nor the VALU
+    (enabled-lane issue slots ~0.25 of the peak) but the vector-memory path of the CUs: every lane's 64-byte record is a separate
+    access through the texture addresser (TA) and L1.  So:
+      bound    = "vector-memory (TA/L1)"
+      achieved = TA busy fraction of the launch: TA busy cycles per launch (avg over the TAs; from the committed PMC summary of THESE
+                 kernel sources -- the workload is deterministic, the same accesses are made in every run) / the launch duration
+                 measured LIVE with HIP events on the kernel's stream inside the timed steps
+      peak     = 1.0 (a TA busy every cycle), frac = achieved / peak
+      traffic  = HBM bytes per launch from the PMC counters (FETCH_SIZE + WRITE_SIZE, the guide's gfx950 units)
+    'sides' puts every other candidate ceiling beside it, each recomputable from profiles/roofline_pmc.json + the live time: L1
+    accesses per CU-cycle, the enabled-lane VALU fraction, the counter HBM fraction, and SURVEY 8(d)'s algorithmic-bytes demand over
+    the HBM peak -- which exceeds 1 here because the bytes are served by L1/L2, i.e. it is a demand figure, not a roofline; the
+    regime where it IS a roofline (a scene the caches cannot hold) is measured live by this run: hbm.out_of_cache_live.
+    Counter-derived fields are null when profiles/roofline_pmc.json was measured on other kernel sources, on another workload size,
+    or with another number of ranks."""
     bytes_extend = ha.algorithmic_bytes(near, executed=True)  # this rank, one step: 64 I + 52 P + 48 R + 64 T + 128 X
     reach_bytes = 48 * near["tlas_inner"]  # the builder's own reach[] records, reported apart from SURVEY 8(d)'s terms
     sec = avg_ms * 1e-3
     alg_per_launch = bytes_extend / max(1.0, launches_per_step)
-    rb = {"bound": "valu", "kernel": "k_extend (Scene::FindNearest)", "achieved": None, "peak": 78.6432, "unit": "Tlane-op/s",
+    rb = {"bound": "vector-memory (TA/L1)", "kernel": "k_extend_s<false> (Scene::FindNearest)", "achieved": None, "peak": 1.0, "unit": "TA busy fraction",
           "frac": None, "traffic": None,
           "avg_launch_ms": round(avg_ms, 5), "launches_per_step": launches_per_step, "kernel_ms_per_step": kernel_ms,
+          "sides": None,
           "hbm": {"peak_GBps": 8000.0,
                   "algorithmic_bytes_per_launch": int(alg_per_launch), "reach_bytes_per_launch": int(reach_bytes / max(1.0, launches_per_step)),
                   "algorithmic_GBps": round(alg_per_launch / sec / 1e9, 2) if sec > 0 else None,
-                  "algorithmic_frac_of_hbm_peak": round(alg_per_launch / sec / 8e12, 4) if sec > 0 else None,
-                  "note": "algorithmic bytes (SURVEY 8d: every node pair and primitive a ray touches, as if fetched from memory) exceed what HBM delivers because the scene is served from L1/L2: a demand figure, not a roofline"},
+                  "algorithmic_demand_over_hbm_peak": round(alg_per_launch / sec / 8e12, 4) if sec > 0 else None,
+                  "note": "served by caches: SURVEY 8(d)'s algorithmic bytes (every node pair and primitive a ray touches, as if fetched from memory) exceed what HBM could deliver because this scene is served from L1/L2 -- a demand figure, not a roofline; see out_of_cache_live for the regime where it is one"},
           "algorithmic_work_per_step": {k: int(near[k]) for k in ("inner_visits", "prim_tests", "tlas_inner", "instance_visits", "rays_nearest")}}
     # the same SURVEY 8(d) figure for the any-hit kernel and for the whole step (both traversal kernels' bytes over the step time;
     # rank 0's rows when the frame is sharded)
@@ -310,7 +511,7 @@ def roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, w
     rb["hbm"]["connect_algorithmic_GBps"] = round(bytes_connect / con_launches / con_sec / 1e9, 2) if con_sec > 0 else None
     rb["hbm"]["step_algorithmic_bytes"] = int(bytes_extend + bytes_connect)
     rb["hbm"]["step_algorithmic_GBps"] = round((bytes_extend + bytes_connect) / sec_per_step / 1e9, 2) if sec_per_step > 0 else None
-    rb["hbm"]["step_algorithmic_frac_of_hbm_peak"] = round((bytes_extend + bytes_connect) / sec_per_step / 8e12, 4) if sec_per_step > 0 else None
+    rb["hbm"]["step_algorithmic_demand_over_hbm_peak"] = round((bytes_extend + bytes_connect) / sec_per_step / 8e12, 4) if sec_per_step > 0 else None
     rb["build"] = build_info
     ppath = os.path.join(ROOT, "profiles", "roofline_pmc.json")
     try:
@@ -330,37 +531,27 @@ def roofline_block(args, ha, near, occl, avg_ms, launches_per_step, W, H, spp, w
               pj.get("workload") == [args.workload, W, H, spp] and pj.get("world", 1) == world)
     rb["pmc"] = {"file": "profiles/roofline_pmc.json", "used": bool(usable), "kernel_hash": khash,
                  "file_kernel_hash": pj.get("kernel_hash") if pj else None}
-    if usable and sec > 0:
+    if usable and sec > 0 and "ta_busy_avg" in pj["kernels"]["k_extend"]:
         k = pj["kernels"]["k_extend"]
+        prof_sec = k["ms"] / k["launches"] * 1e-3  # the launch under the profiler (counters cost a few per cent)
+        clock = k["clock_ghz"] * 1e9
+        ta_cycles = k["ta_busy_avg"] * prof_sec * clock  # TA busy cycles per launch, avg over the TAs: work, not time
+        ta_live = ta_cycles / (sec * clock)
         lane_ops = k["lane_ops_per_launch"]
-        rb["achieved"] = round(lane_ops / sec / 1e12, 3)
-        rb["frac"] = round(lane_ops / sec / 78.6432e12, 4)
+        rb["achieved"] = round(ta_live, 4)
+        rb["frac"] = round(ta_live, 4)
         rb["traffic"] = k["hbm_bytes_per_launch"]
-        rb["hbm"]["counter_GBps"] = round(k["hbm_bytes_per_launch"] / sec / 1e9, 1)
-        rb["hbm"]["counter_frac_of_hbm_peak"] = round(k["hbm_bytes_per_launch"] / sec / 8e12, 4)
-        rb["valu"] = {"lanes_enabled": k["lanes_enabled"], "valu_pipe_busy": k["valu_pipe_busy"], "wave_wait_frac": k["wave_wait_frac"],
-                      "l1_accesses_per_cu_cycle": k["l1_accesses_per_cu_cycle"], "profile_launch_ms": round(k["ms"] / k["launches"], 4)}
-        if "ta_busy_avg" in k:  # the busiest unit: the texture addressers (every vector-memory instruction costs ~16-19 of their cycles)
-            rb["ta"] = {"busy_avg": k["ta_busy_avg"], "busy_max": k["ta_busy_max"], "cycles_per_vmem_inst": k.get("ta_cycles_per_vmem_inst"),
-                        "vmem_insts_per_launch": int(k["vmem_insts"] / k["launches"]) if k.get("vmem_insts") else None}
-    # The regime north_star's "fraction of the HBM-read roofline on BVH traversal" is defined in -- a scene the caches cannot hold --
-    # is ANOTHER workload (profiles/out_of_cache.py: the 8.4 M-triangle terrain).  Its committed counter figures ride along for
-    # reference; they are not measured by this run and never enter 'frac'.
-    # (quoted only while the file was measured on THESE kernel sources and compile flags: its own stamp, kernel_hash of the
-    # library's rt_build_info -- the context's scene-dependent tuning string is another scene's there)
-    src_hash = kernel_hash(build_info.split(" | ")[0])
-    for name in ("r05_out_of_cache_spp16.json", "r05_out_of_cache_spp4.json"):
-        try:
-            ooc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            kname = "k_extend_s<false>" if "spp16" in name else "k_traverse_s"
-            k = ooc["kernels"][kname]
-            ref = {"file": "profiles/" + name, "kernel": kname, "scene": ooc["run"]["scene"], "scene_bytes": ooc["run"]["scene_bytes"], "frame": ooc["run"]["frame"],
-                   "traversal_hbm_TBps": k["hbm_TBps"], "frac_of_hbm_peak": k["frac_of_8TBps"], "l2_hit_rate": k["l2_hit_rate"], "ta_busy_avg": k["ta_busy_avg"],
-                   "measured_on_these_kernels": ooc.get("kernel_hash") == src_hash, "note": "static, from the committed profile of another workload"}
-            if ref["measured_on_these_kernels"]:
-                rb["hbm"].setdefault("out_of_cache_reference", []).append(ref)
-        except Exception:
-            pass
+        rb["sides"] = {
+            "ta_busy": {"profiled": k["ta_busy_avg"], "profiled_max_over_tas": k["ta_busy_max"], "live": round(ta_live, 4), "cycles_per_vmem_inst": k.get("ta_cycles_per_vmem_inst"),
+                        "vmem_insts_per_launch": int(k["vmem_insts"] / k["launches"]) if k.get("vmem_insts") else None},
+            "l1_accesses_per_cu_cycle": k["l1_accesses_per_cu_cycle"],
+            "valu_enabled_lane_frac_of_peak": round(lane_ops / sec / 78.6432e12, 4),  # 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
+            "valu": {"lanes_enabled": k["lanes_enabled"], "valu_pipe_busy": k["valu_pipe_busy"], "wave_wait_frac": k["wave_wait_frac"]},
+            "hbm_counter_frac_of_peak": round(k["hbm_bytes_per_launch"] / sec / 8e12, 4),
+            "hbm_counter_GBps": round(k["hbm_bytes_per_launch"] / sec / 1e9, 1),
+            "hbm_algorithmic_demand_over_peak": rb["hbm"]["algorithmic_demand_over_hbm_peak"],
+            "hbm_algorithmic_demand_note": "served by caches (L2 hit rate %.2f): > 1 is possible and says nothing about HBM" % k["l2_hit_rate"],
+            "l2_hit_rate": k["l2_hit_rate"], "profile_launch_ms": round(k["ms"] / k["launches"], 4), "profile_clock_ghz": k["clock_ghz"]}
     return rb
 
 
@@ -415,7 +606,7 @@ def cpu_baseline(args, cfg, W, H, spp, gpu=None):
     """The oracle (CPU restatement, kind 'port') on the host cores: frames 0 .. F-1 of the same workload, OpenMP over
     scanlines like renderer.cpp:259, per-pixel RNG streams; F = the step's spp when that fits --cpu-seconds.  Threads =
     the physical cores this job may really use (the cgroup quota caps them: cpu_allowance).  value_1thread: one thread on
-    every 2nd scanline of one frame (a bounded sample of the same image).
+    every 8th scanline of one frame (a bounded sample of the same image: the GPU legs stay visible beside the CPU leg).
     gpu = (renderer, accumulator tensor, mode, checksum of the timed steps' frame): the SAME F frames are rendered once more
     on the device, outside the timed region, and compared with the oracle's accumulator as a whole -> (baseline, parity_check):
     the witness that the numbers above were measured on the reference's image (renderer.cpp:263-285), at full size."""
@@ -442,7 +633,7 @@ def cpu_baseline(args, cfg, W, H, spp, gpu=None):
         orr.render(1, frames - 1, nthreads=threads)
     dt = time.perf_counter() - t0
     ref = orr.accumulator()
-    rows = list(range(1, H, 2))
+    rows = list(range(4, H, 8))
     t0 = time.perf_counter()
     for y in rows:
         orr.render(0, 1, y0=y, y1=y + 1, nthreads=1)
@@ -454,7 +645,7 @@ def cpu_baseline(args, cfg, W, H, spp, gpu=None):
             "physical_cores": phys, "logical_cpus": logical, "cpu_allowance": allowed,
             "threads_note": "threads = min(physical cores, cgroup CPU quota): the box shows %d logical CPUs but this job may use %s of them" % (logical, "all" if allowed is None else "%.0f CPUs' worth of time" % allowed),
             "value_1thread": round(W * len(rows) / dt1 / 1e6, 4),
-            "sample_1thread": "%d scanlines (every 2nd) of one %dx%d frame on 1 thread (%.1f s)" % (len(rows), W, H, dt1)}
+            "sample_1thread": "%d scanlines (every 8th) of one %dx%d frame on 1 thread (%.1f s)" % (len(rows), W, H, dt1)}
     if gpu is None:
         return base, None
     import torch

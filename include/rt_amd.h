@@ -194,6 +194,9 @@ int rt_bind_accumulator(rt_ctx* ctx, void* device_ptr);
 int rt_gather_begin(rt_ctx* dst);
 int rt_gather_rows(rt_ctx* dst, rt_ctx* src, int row_first, int row_stride, int row_count);
 int rt_device_of(const rt_ctx* ctx);
+/* PCI address ("0000:c1:00.0") of HIP device 'device' into out[cap >= 16]: the ranks of a multi-process run exchange these to
+ * prove that no two of them render on the same GPU (bench.py ranks_devices). */
+int rt_device_pci_bus_id(int device, char* out, int cap);
 
 /* ---- batch queries ---------------------------------------------------------------------------- */
 /* Scene::FindNearest(ray, t_min) (template/scene.h:1248-1267) for n rays. O, D: n*3 floats;
@@ -248,6 +251,10 @@ int rt_qlearn_apply(rt_ctx* ctx);
 int rt_qlearn_get_sums(rt_ctx* ctx, int64_t* sums_out, uint32_t* counts_out);
 int rt_qlearn_set_sums(rt_ctx* ctx, const int64_t* sums, const uint32_t* counts);
 int rt_qlearn_get_table(rt_ctx* ctx, float* q_out);
+/* The pending sums live in the caller's DEVICE arrays from here on (grid^3 * 64 int64 / uint32; what was pending is copied over;
+ * the caller keeps them alive until the sampler is switched off): one process per GPU all-reduces them in place between the
+ * ranks (RCCL on device memory) before every rank's rt_qlearn_apply -- no host copy in the exchange. */
+int rt_qlearn_bind_sums(rt_ctx* ctx, int64_t* dev_sums, uint32_t* dev_counts);
 
 /* ---- acceleration structure build ("next" row N1) ------------------------------------------------ */
 /* bvh::Build() with splitMethod BINNEDSAH (bvh.cpp:18-56; FindBestSplitPlane :116-193, Subdivide :223-333,

@@ -8,10 +8,62 @@ is read-only, so every rank holds a full copy of the scene and renders rows rank
 the final framebuffer gather: W*H*16 B * (world-1)/world into rank 0, e.g. 29 MB at 1080p / 8 ranks.
 xGMI is point to point, so a gather to one rank uses all of that rank's links at once; no ring.
 """
+import datetime
+import os
 import time
 
 import torch
 import torch.distributed as dist
+
+COLLECTIVE_TIMEOUT_S = 300  # every collective of a bench / Tick run ends within this, or the run ends with a non-zero exit code
+
+
+def init_group(backend, rank, world, device_index=None, timeout_s=COLLECTIVE_TIMEOUT_S):
+    """The process group of an N-rank run, made so that a rank that never arrives, or a collective that never completes, ENDS the
+    run (non-zero exit) instead of hanging it: a timeout on the rendezvous and on every collective (gloo raises; for "nccl" =
+    RCCL the watchdog aborts the process: TORCH_NCCL_ASYNC_ERROR_HANDLING=1), and -- "nccl" only -- one visible GPU per rank
+    checked BEFORE anything is initialised.  No re-exec, no in-process restart."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    timeout = datetime.timedelta(seconds=timeout_s)
+    if backend == "nccl":
+        have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+        if have < world:
+            raise SystemExit("%d ranks over RCCL need %d GPUs on this node, %d visible (RAPT_DIST_BACKEND=gloo rehearses on fewer: the ranks then share devices)" % (world, world, have))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=timeout, device_id=torch.device("cuda", device_index))
+    else:
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+
+
+def exchange_device_ids(my_id, world, device="cpu"):
+    """Every rank's device identity (a PCI address, host_api.device_pci_bus_id; any short string), in rank order, on every rank:
+    one all-gather of a fixed-size byte tensor."""
+    raw = my_id.encode()[:63]
+    mine = torch.zeros(64, dtype=torch.uint8)
+    mine[: len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    mine = mine.to(device)
+    if world == 1:
+        return [my_id]
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return [bytes(p.cpu().tolist()).split(b"\0")[0].decode() for p in parts]
+
+
+def check_rank_devices(ids, backend):
+    """One GPU per rank is what an RCCL run means: two ranks on one device would time one GPU's work as two GPUs'.  Raises under
+    "nccl"; under "gloo" (the rehearsal mode: ranks share devices on purpose) sharing is reported by the caller, not refused."""
+    dup = sorted({i for i in ids if ids.count(i) > 1})
+    if dup and backend == "nccl":
+        raise RuntimeError("ranks share a GPU: %s (rank -> device: %s)" % (", ".join(dup), ids))
+    return not dup
+
+
+def all_reduce_reward_sums(sums, counts):
+    """The one exchange step the Q-learning sampler adds: the ranks' pending reward sums (int64) and counts (uint32 held as int32:
+    two's-complement addition is the same bits), added IN PLACE on whatever device they live on -- integers, so the order of the
+    reduction does not matter and every rank ends with the same totals."""
+    dist.all_reduce(sums)
+    dist.all_reduce(counts)
 
 
 def shard_rows(height, rank, world):

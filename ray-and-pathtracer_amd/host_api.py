@@ -26,7 +26,8 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_set_counting", "rt_get_counters", "rt_get_counters_split", "rt_set_profiling", "rt_get_profile", "rt_synchronize",
               "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_gather_begin", "rt_device_of",
               "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy", "rt_build_info", "rt_tuning_info",
-              "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table"]
+              "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table", "rt_qlearn_bind_sums",
+              "rt_device_pci_bus_id"]
 
 
 class RtQlearnParams(C.Structure):
@@ -85,6 +86,9 @@ def rt_lib():
         L.rt_qlearn_get_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_qlearn_set_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_qlearn_get_table.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_qlearn_bind_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        L.rt_gather_begin.argtypes = [C.c_void_p]
         L.rt_build_info.restype = C.c_char_p
         L.rt_build_info.argtypes = []
         L.rt_tuning_info.restype = C.c_char_p
@@ -252,6 +256,12 @@ class HostScene:
         ids = np.zeros(n, dtype=np.int32)
         self.L.rth_mesh_get(self.h, mesh, _p(out), _p(ids))
         return out, ids
+
+    def bvh_dump_info(self, blas=-1):
+        """sizes of a tree without copying it: nodes_used, N (primitives), NTri, NSph, NPla, max_depth"""
+        info = (C.c_int * 7)()
+        self.L.rth_bvh_info(self.h, blas, info)
+        return dict(nodes_used=info[0], N=info[1], NTri=info[2], NSph=info[3], NPla=info[4], max_depth=info[5])
 
     def bvh_dump(self, blas=-1):
         info = (C.c_int * 7)()
@@ -538,6 +548,11 @@ class HostRenderer:
         sums, cnts = np.ascontiguousarray(sums, np.int64), np.ascontiguousarray(cnts, np.uint32)
         self._rt(self.rt.rt_qlearn_set_sums(self.ctx, _p(sums), _p(cnts)))
 
+    def qlearn_bind_sums(self, sums_ptr, counts_ptr):
+        """rt_qlearn_bind_sums: the pending reward sums live in the caller's device arrays (data_ptr() of an int64 / int32 torch tensor
+        of grid^3 * 64 elements) from here on"""
+        self._rt(self.rt.rt_qlearn_bind_sums(self.ctx, C.c_void_p(sums_ptr), C.c_void_p(counts_ptr)))
+
     def qlearn_table(self):
         tab = np.zeros((self._qgrid ** 3, 64), np.float32)
         self._rt(self.rt.rt_qlearn_get_table(self.ctx, _p(tab)))
@@ -554,6 +569,15 @@ class HostRenderer:
         p = RtProfile()
         self._rt(self.rt.rt_get_profile(self.ctx, C.byref(p), int(reset)))
         return {k: dict(launches=int(getattr(p, k).launches), ms=float(getattr(p, k).ms)) for k in ("generate", "extend", "shade", "connect", "query")}
+
+
+def device_pci_bus_id(device):
+    """rt_device_pci_bus_id: the PCI address of HIP device 'device' (what two ranks on one GPU have in common)"""
+    buf = C.create_string_buffer(64)
+    rc = rt_lib().rt_device_pci_bus_id(int(device), buf, 64)
+    if rc != 0:
+        raise RuntimeError("rt_amd error %d: %s" % (rc, rt_lib().rt_last_error(None).decode()))
+    return buf.value.decode()
 
 
 def algorithmic_bytes(counters, executed=False):

@@ -231,7 +231,8 @@ def test_bench_plumbing_without_a_gpu(tmp_path, monkeypatch):
     """bench.py's host-side plumbing that needs no device: the kernel hash covers the kernel sources and the build string (a profile
     measured on other sources is never quoted: roofline_pmc.json, the out-of-cache files), the frame comparison of parity_check
     (tests/conftest.py rel_err's rule), the CPU allowance parser, and -- `python bench.py --gpus N` with no WORLD_SIZE -- the
-    self-start: a child torch.distributed.run with N ranks on 127.0.0.1, before torch is imported, the exit code relayed."""
+    self-start: a child torch.distributed.run with N ranks on 127.0.0.1, before torch is imported, the exit code relayed.  And the
+    staleness rule of host_api.build(): the .inc step fragments are the hottest code of the library and count as sources."""
     import importlib, subprocess, sys
     from conftest import ROOT
     bench = importlib.import_module("bench")
@@ -248,6 +249,21 @@ def test_bench_plumbing_without_a_gpu(tmp_path, monkeypatch):
     assert not bench.frame_error(np.array([1.0, np.inf]), np.array([1.0, -np.inf]))[1]
     allowed = bench.cpu_allowance()
     assert allowed is None or allowed > 0
+    # an edited step fragment makes the library stale: build() must call make for it
+    ha = importlib.import_module("ray-and-pathtracer_amd.host_api")
+    calls = []
+    monkeypatch.setattr(ha.subprocess, "check_call", lambda cmd, **kw: calls.append(cmd))
+    inc = os.path.join(ROOT, "ray-and-pathtracer_amd", "csrc", "rt_step_pair.inc")
+    st = os.stat(inc)
+    try:
+        ha.build()
+        assert not any("csrc" in " ".join(c) for c in calls), calls  # fresh: nothing to do
+        os.utime(inc, (st.st_atime, os.path.getmtime(ha.RT_SO) + 10))
+        ha.build()
+        assert any("csrc" in " ".join(c) for c in calls), calls
+    finally:
+        os.utime(inc, (st.st_atime, st.st_mtime))
+    monkeypatch.undo()
     # the self-start, with a stand-in for torch.distributed.run on the path: it records its arguments and exits 7
     fake = tmp_path / "torch" / "distributed"
     fake.mkdir(parents=True)
@@ -259,5 +275,6 @@ def test_bench_plumbing_without_a_gpu(tmp_path, monkeypatch):
     rc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2"], env=env, cwd=ROOT).returncode
     assert rc == 7
     argv = json.load(open(tmp_path / "argv.json"))
-    assert argv[:2] == ["--nnodes=1", "--nproc-per-node"] and argv[2] == "3" and "--master-addr" in argv and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    # one node, N ranks, the rendezvous on 127.0.0.1 with a port the launcher picks itself (no bind-then-close race: ADVICE r5)
+    assert argv[:2] == ["--nnodes=1", "--nproc-per-node"] and argv[2] == "3" and "--rdzv-endpoint=127.0.0.1:0" in argv and argv[argv.index("--local-addr") + 1] == "127.0.0.1"
     assert argv[-4:] == ["--gpus", "3", "--steps", "2"] and argv[-5].endswith("bench.py")
