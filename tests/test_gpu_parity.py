@@ -315,6 +315,15 @@ def test_trace_batch_and_renderer_surface(scenes, oracle_api, host_api):
     assert np.array_equal(r.trace_batch(host_api.RT_MODE_WHITTED, O[:5], D[:5], depth=0), np.zeros((5, 3), np.float32))
     one = r.trace_one(O[100], D[100], 4, path=False)
     assert np.array_equal(one, got[100])
+    # the flag decides which function Tick calls; the other combination (renderer.cpp:33-43, 107-121, 143-153: unreachable from
+    # Tick, restated in the oracle only) is refused on the preserved surface, never answered by the other branch
+    with pytest.raises(RuntimeError, match="RT_E_UNSUPPORTED"):
+        r.trace_one(O[100], D[100], 4, path=True)
+    r.scene.set_raytracer(False)
+    with pytest.raises(RuntimeError, match="RT_E_UNSUPPORTED"):
+        r.trace_one(O[100], D[100], 4, path=False)
+    assert np.isfinite(r.trace_one(O[100], D[100], 4, path=True)).all()
+    r.scene.set_raytracer(True)
     # Tick in Whitted mode fills accumulator and pixels
     r.tick()
     acc = r.tick_accumulator()
@@ -558,8 +567,7 @@ def test_members_below_scene_level(name, kw, scenes, oracle_api, host_api):
         got = r.trace_batch(mode, pO, pD, depth=4, seed_base=99, energy=e)
         err, cls_ok = rel_err(got, ref)
         assert cls_ok and err.max() <= RADIANCE_TOL
-        one = r.trace_one(pO[200], pD[200], 4, path=False, energy=e) if mode == host_api.RT_MODE_WHITTED else None
-        if one is not None:
+        if mode == host_api.RT_MODE_WHITTED:
             r.scene.set_raytracer(True)
             e1, c1 = rel_err(r.trace_one(pO[200], pD[200], 4, path=False, energy=e), orr.trace_rays(0, pO[200:201], pD[200:201], 4, e, seed_base=0x12345678)[0])
             assert c1 and e1.max() <= RADIANCE_TOL
