@@ -61,7 +61,7 @@ def main():
                     "(no process group, no gather): the counters of that share are what rank 0 of the N-GPU run is priced with")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world N: the rows of rank R instead of rank 0's (the N-GPU step is as "
                     "long as its SLOWEST share: profiles/r04_shares_all_ranks.txt)")
-    ap.add_argument("--no-legs", action="store_true", help="profiling runs: skip the live legs outside the timed region (out-of-cache terrain, Tick latency, 1/8 shares)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the live legs outside the timed region (out-of-cache terrain, Tick latency, 1/8 shares); --no-cpu-baseline skips them too")
     ap.add_argument("--ooc-n", type=int, default=2048, help="out-of-cache leg: the terrain is 2 n^2 triangles (2048: 8.4 M, pairs + primitive records 0.94 GB)")
     ap.add_argument("--ooc-spp", type=int, default=16)
     ap.add_argument("--ooc-steps", type=int, default=3)
@@ -277,7 +277,7 @@ def main():
         # ---- live legs outside the timed region (one GPU, the default workload): what the driver cannot see otherwise ----
         plain = world == 1 and not args.qlearn and args.emulate_world <= 1 and args.workload == "config3" and not (args.width or args.height or args.spp)
         terrain = None
-        if plain and not args.no_legs:
+        if plain and not args.no_legs and not args.no_cpu_baseline:  # (profiling runs pass --no-cpu-baseline: their kernel statistics are the timed steps' alone)
             t_legs = time.perf_counter()
             out["share_ms"] = share_leg(dpar, r, acc, mode, spp, H, W, sec_per_step * 1e3)
             out["tick_ms"] = tick_leg(ha, scenes, device_index)

@@ -16,6 +16,9 @@
 
 using namespace rtd;
 
+#ifndef RT_GRID_CAP
+#define RT_GRID_CAP 8
+#endif
 static std::string g_err;
 
 struct Timer {
@@ -325,7 +328,7 @@ rt_ctx* rt_create(int device, int width, int height)
 	{
 		// the persistent traversal kernels are launched with exactly the blocks a CU can hold (occupancy calculator, per
 		// kernel): a block that had to wait for a slot would find its share of the queue already taken
-		const int capBlocks = 8;
+		const int capBlocks = RT_GRID_CAP; // (measurement builds: -DRT_GRID_CAP=4 halves the resident blocks of every persistent kernel)
 		auto resident = [&](const void* fn) { int b = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, RT_BLOCK, 0) != hipSuccess || b < 1) b = 1; if (b > 8) b = 8; if (capBlocks >= 1 && b > capBlocks) b = capBlocks; return b * prop.multiProcessorCount; };
 		const int e0 = std::min(resident((const void*)k_extend<false, false>), resident((const void*)k_extend<false, true>)), e1 = std::min(resident((const void*)k_extend<true, false>), resident((const void*)k_extend<true, true>));
 		const int c0 = resident((const void*)k_connect<false>), c1 = resident((const void*)k_connect<true>);

@@ -1438,6 +1438,41 @@ def test_qlearning_reward_words_report_overflow(scenes, host_api):
     r.close()
 
 
+def test_qlearning_sums_in_caller_memory(scenes, host_api):
+    """rt_qlearn_bind_sums: the pending reward sums live in the caller's device arrays -- what one process per
+    GPU all-reduces in place over RCCL (bench.py --qlearn with several ranks) instead of four host copies per exchange.  Held here on
+    one GPU: the bound tensors ARE the sums (equal to an unbound renderer's rt_qlearn_get_sums after the same frames), doubling them
+    in place is what two identical ranks' all-reduce leaves, and the table learnt from them equals rt_qlearn_set_sums' of the same."""
+    import torch
+    w, h, box = 64, 40, ((-4, -1, -4), (4, 5, 6))
+    rs = []
+    for _ in range(2):
+        r = host_api.HostRenderer(w, h)
+        scenes.REGISTRY["mixed_small"](r.scene)
+        r.commit()
+        r.qlearn_enable(8, box[0], box[1], 0.3, 0.2, 1.0, 0)
+        rs.append(r)
+    a, b = rs
+    n = 8 ** 3 * 64
+    qs = torch.zeros(n, dtype=torch.int64, device="cuda")
+    qc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    a.qlearn_bind_sums(qs.data_ptr(), qc.data_ptr())
+    for f in range(2):
+        a.render(host_api.RT_MODE_PATH, 2 * f, 2)
+        b.render(host_api.RT_MODE_PATH, 2 * f, 2)
+        sums, cnts = b.qlearn_sums()
+        torch.cuda.synchronize()
+        assert np.array_equal(qs.cpu().numpy().reshape(sums.shape), sums) and np.array_equal(qc.cpu().numpy().astype(np.uint32).reshape(cnts.shape), cnts)
+        assert cnts.sum() > 0
+        qs.mul_(2), qc.mul_(2)  # two ranks that rendered the same rows: what the in-place all-reduce leaves
+        torch.cuda.synchronize()
+        b.qlearn_set_sums(2 * sums, 2 * cnts)
+        a.qlearn_apply(), b.qlearn_apply()
+        assert np.array_equal(a.qlearn_table().view(np.uint32), b.qlearn_table().view(np.uint32))
+        assert int(qs.abs().sum().item()) == 0 and int(qc.abs().sum().item()) == 0  # the apply consumed them, in the caller's arrays
+    a.close(), b.close()
+
+
 def test_qlearning_flag_is_not_the_wide_walks(scenes, host_api):
     """the sampler's overflow word used to be flags[2], which is also the 4-wide occlusion walk's count of rays it handed
     back to the binary walk.  An axis-aligned shadow ray (not 'clean') on a scene with wide nodes left it > 0, and the next
