@@ -205,8 +205,8 @@ static float3 eval(rt_ctx* ctx, int mode, const Ray& ray, int depth, const float
 }
 // The device evaluates Trace as Tick calls it (scene.raytracer set: renderer.cpp:268-271) and Sample as Tick calls it (clear: :272-283).
 // The reference's other two combinations -- Trace with the flag clear (Russian roulette + an indirect term, renderer.cpp:33-43,
-// :107-121) and Sample with it set (:143-153) -- are unreachable from Tick and not built on the device (the oracle restates them:
-// oracle/orc_render.h); asking for one is an error (RT_E_UNSUPPORTED), never the other branch's answer.
+// :107-121) and Sample with it set (:143-153) -- are unreachable from Tick and not built on the device (the test tier's CPU
+// checker restates them); asking for one is an error (RT_E_UNSUPPORTED), never the other branch's answer.
 float3 Renderer::Trace(Ray& ray, int depth, float3 energy)
 {
 	if (!scene.raytracer) throw std::runtime_error("rt_amd: RT_E_UNSUPPORTED: Renderer::Trace with scene.raytracer == false (renderer.cpp:33-43, 107-121) is not built on the device; Tick never calls it");

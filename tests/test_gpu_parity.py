@@ -1168,17 +1168,19 @@ def test_fewer_slots_than_samples(slots, name, kw, scenes, oracle_api, host_api,
     r.clear()
     r.render(host_api.RT_MODE_PATH, 0, 12)
     full = r.accumulator()
-    monkeypatch.setenv("RT_SLOTS", slots)
-    err, _ = check_frames(orr, r, "path", 12, host_api)
-    assert np.array_equal(r.accumulator().view(np.uint32), full.view(np.uint32))
-    # Whitted: pending branches + pool
-    r.clear()
-    r.render(host_api.RT_MODE_WHITTED, 0, 1)
-    few = r.accumulator()
+    monkeypatch.setenv("RT_SLOTS", slots)  # (read when a context is created: csrc/rt_ctx.h Knobs)
+    o2, orr2, r2, d2 = make_pair(scenes.REGISTRY[name], oracle_api, host_api, 96, 54, **kw)
     monkeypatch.delenv("RT_SLOTS")
+    err, _ = check_frames(orr2, r2, "path", 12, host_api)
+    assert np.array_equal(r2.accumulator().view(np.uint32), full.view(np.uint32))
+    # Whitted: pending branches + pool
+    r2.clear()
+    r2.render(host_api.RT_MODE_WHITTED, 0, 1)
+    few = r2.accumulator()
     r.clear()
     r.render(host_api.RT_MODE_WHITTED, 0, 1)
     assert np.array_equal(r.accumulator().view(np.uint32), few.view(np.uint32))
+    r.close(), r2.close()
 
 
 @pytest.mark.parametrize("name,kw,w,h,frames", [("pretty_tlas", {"n_instances": 4}, 160, 90, 7), ("mixed_small", {}, 96, 64, 5), ("bigb_instanced", {"n": 9, "mesh": "lowBigB"}, 128, 72, 3),

@@ -38,7 +38,7 @@ def test_product_does_not_load_the_oracle():
     pkg_dir = os.path.join(ROOT, "ray-and-pathtracer_amd")
     for dirpath, _, files in os.walk(pkg_dir):
         for f in files:
-            if f.endswith((".py", ".h", ".cpp", ".hip")) or f == "Makefile":
+            if f.endswith((".py", ".h", ".cpp", ".hip", ".inc")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt and "orc_" not in txt, os.path.join(dirpath, f)
 
