@@ -222,6 +222,12 @@ int rt_primary_hits(rt_ctx* ctx, float t_min, int32_t* obj_idx_out, float* t_out
 /* Renderer::Trace / Renderer::Sample on caller-supplied rays: rgb_out[n*3].  Stream i starts at
  * InitSeed(seed_base + i). */
 int rt_trace_batch(rt_ctx* ctx, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, float* rgb_out);
+/* scene.raytracer as the caller's Scene holds it, for rt_trace_batch*: -1 (default) the flag follows the function called -- Trace with the
+ * flag set, Sample with it clear, as Renderer::Tick calls them (renderer.cpp:268-283); 0 / 1: the flag's value.  Trace with the flag clear
+ * (Russian roulette, sampled light positions, an indirect child: renderer.cpp:33-43, 107-121) and Sample with it set (:143-153) are what the
+ * reference's Renderer::Trace / Sample compute when called that way; the device evaluates them one lane per call tree (slow path,
+ * correctness only; not with the Q-learning sampler on: RT_E_UNSUPPORTED).  rt_render ignores the flag (it is Tick's loop). */
+int rt_set_scene_raytracer(rt_ctx* ctx, int flag);
 /* The same with Trace / Sample's third argument: energy[3] instead of float3(1) */
 int rt_trace_batch_energy(rt_ctx* ctx, int mode, int n, const float* O, const float* D, int depth, uint32_t seed_base, const float* energy, float* rgb_out);
 

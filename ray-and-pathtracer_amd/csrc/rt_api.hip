@@ -139,6 +139,13 @@ void rt_destroy(rt_ctx* c)
 	delete c;
 }
 
+int rt_set_scene_raytracer(rt_ctx* c, int flag)
+{
+	if (!c || flag < -1 || flag > 1) return fail(c, RT_E_ARG, "rt_set_scene_raytracer: flag %d (-1, 0, 1)", flag);
+	c->sceneRaytracer = flag;
+	return RT_OK;
+}
+
 int rt_set_camera(rt_ctx* c, const rt_camera* cam)
 {
 	if (!c || !cam) return fail(c, RT_E_ARG, "rt_set_camera: null argument");

@@ -81,6 +81,7 @@ struct rt_ctx {
 	DScene S;
 	bool sceneLoaded = false;
 	std::vector<void*> sceneAllocs;
+	int sceneRaytracer = -1; // rt_set_scene_raytracer: scene.raytracer as the caller's Scene holds it (-1: it follows the function called)
 	bool pathUnsupported = false; // shiny or rt==0 diffuse present: path mode runs k_sample_general instead of the wavefront
 	std::string pathUnsupportedWhy;
 	// animation (rt_set_time): original leaf records of the scene BVH and its pair records by level

@@ -71,6 +71,9 @@ struct RenderParams {
 	int finishInline;  // path mode with a slot per sample: nothing to resume and no sample to pull when a segment ends,
 	                   // so shade / light store the finished sample themselves and the round has no finish pass
 	int deferGamma;    // path mode: a finished sample is stored raw with w = 1 and k_accumulate applies the gamma (see store_sample)
+	int sceneRt;       // rt_trace_batch with rt_set_scene_raytracer: scene.raytracer as the caller's Scene holds it, when it is NOT what the
+	                   // function called implies (Trace with the flag clear, Sample with it set: renderer.cpp:33-43, 107-121, 143-153) -- the
+	                   // general kernels below; -1: the flag follows the function, as Tick calls it
 };
 
 #define ST_ACTIVE 1      // has a ray for extend + shade
@@ -895,10 +898,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_sample_general(DScene S, DCamera C
 					else {
 						const DMaterial m = S.mats[matId];
 						const f3 col(m.col[0], m.col[1], m.col[2]);
+						bool survives = true;
+						if (R.sceneRt == 1) { // Sample with scene.raytracer set (renderer.cpp:143-153): Russian roulette on the largest colour component
+							const double p = col.x > col.y && col.x > col.z ? col.x : col.y > col.z ? col.y : col.z;
+							if (depth < 5 || !p) survives = (double)RandomFloat(seed) < p; // (the survivor's f = f * (1 / p) is never read)
+						}
+						if (!survives) {
+							// return totCol (= 0): nothing is added
+						} else
 						if (m.type == 2) {
 							O = I + normal * 0.001f, D = reflect(D, normal), W = W * col, depth--;
 							continue;
-						}
+						} else
 						if (m.type == 3) {
 							const float kr = glass_fresnel(normalize(D), normalize(normal), m.ir);
 							const bool outside = dot(D, normal) < 0;
@@ -918,10 +929,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_sample_general(DScene S, DCamera C
 							}
 							depth--;
 							continue;
+						} else {
+							cur.P = I, cur.N = normal, cur.rayD = D, cur.W = W, cur.E = E, cur.mat = matId, cur.nextLight = 0, cur.depth = depth;
+							resume = true;
+							continue;
 						}
-						cur.P = I, cur.N = normal, cur.rayD = D, cur.W = W, cur.E = E, cur.mat = matId, cur.nextLight = 0, cur.depth = depth;
-						resume = true;
-						continue;
 					}
 				}
 				// this Sample returned: resume the innermost suspended light loop, or finish
@@ -936,7 +948,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_sample_general(DScene S, DCamera C
 			const f3 col(m.col[0], m.col[1], m.col[2]), albedo(m.albedo[0], m.albedo[1], m.albedo[2]);
 			bool branched = false;
 			for (int i = cur.nextLight; i < S.nLights; i++) {
-				const f3 pickedPos = light_position(S.lights[i], false, seed);
+				const f3 pickedPos = light_position(S.lights[i], R.sceneRt == 1, seed); // (a light follows scene.raytracer: its position itself when the flag is set, template/scene.h:133)
 				f3 L = pickedPos - cur.P;
 				const float len2 = dot(L, L);
 				L = normalize(L);
@@ -964,6 +976,114 @@ __global__ void __launch_bounds__(RT_BLOCK) k_sample_general(DScene S, DCamera C
 		}
 		if (R.customOut) R.customOut[sid] = mk4(Lsum, 0.0f);
 		else store_sample(R, sid, Lsum);
+	}
+}
+
+// ---- general Whitted kernel: Renderer::Trace with scene.raytracer == false (renderer.cpp:21-126 with :33-43 and :107-121 taken) ----
+// Unreachable from Tick (which calls Trace only while the flag is set), reachable through the preserved Renderer::Trace.  With the
+// flag clear Trace draws random numbers -- Russian roulette at every surface hit, the lights' sampled positions, diffuse::scatter's
+// hemisphere sample, whose LAST value becomes the direction of an extra indirect child -- interleaved with occlusion queries and
+// child calls in depth-first order, so one lane runs one whole call tree: recursion becomes a stack of frames (a child still to be
+// called, or a light loop to resume), radiance is carried forward as weights like everywhere else.
+struct TraceFrame {
+	f3 P, N, rayD, W, E, sdir; // kind 0: a child Trace(P, rayD) still to be called with weight W and energy E; kind 1: a suspended light loop
+	int mat, nextLight, depth, kind;
+};
+#define RT_TRACE_FRAMES 12
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_general(DScene S, DCamera C, RenderParams R, uint* spill, int* overflow)
+{
+	__shared__ uint ldsStack[RT_STACK_LDS * RT_BLOCK];
+	Stack st = make_stack(ldsStack, spill, overflow, RT_STACK_LDS);
+	for (uint sid = blockIdx.x * blockDim.x + threadIdx.x; sid < R.nSamples; sid += gridDim.x * blockDim.x) {
+		f3 O(R.customO[3 * sid], R.customO[3 * sid + 1], R.customO[3 * sid + 2]), D(R.customD[3 * sid], R.customD[3 * sid + 1], R.customD[3 * sid + 2]);
+		uint seed = StreamSeed(R.seedBase + sid);
+		int depth = R.customDepth;
+		f3 W(1.0f), E(R.customE[0], R.customE[1], R.customE[2]), Lsum(0.0f);
+		TraceFrame stack[RT_TRACE_FRAMES];
+		int sp = 0;
+		bool resume = false;
+		TraceFrame cur;
+		while (true) {
+			if (!resume) {
+				// ---- Trace(ray, depth, energy) from its first line ----
+				bool returned = true;
+				if (depth > 0) {
+					HitRef hit;
+					find_nearest_one(S, O, D, 1e34f, (float)1e-6, hit, st);
+					int objIdx, matId;
+					f3 normal;
+					resolve_hit(S, hit, O, D, objIdx, matId, normal);
+					const f3 I = O + hit.t * D;
+					if (objIdx == -1) Lsum = Lsum + W * sky_color(S, D);
+					else if (objIdx >= 11 && objIdx < 11 + S.nLights) Lsum = Lsum + W * light_intensity(S.lights[objIdx - 11], I, normal, I);
+					else {
+						const DMaterial m = S.mats[matId];
+						const f3 col(m.col[0], m.col[1], m.col[2]);
+						const double p = col.x > col.y && col.x > col.z ? col.x : col.y > col.z ? col.y : col.z; // :34
+						bool survives = true;
+						if (depth < 5 || !p) survives = (double)RandomFloat(seed) < p; // :35-40
+						if (survives && m.type == 3) { // GLASS :45-80: the refraction child first, the reflection child after it
+							const float kr = glass_fresnel(normalize(D), normalize(normal), m.ir);
+							const bool outside = dot(D, normal) < 0;
+							const f3 bias = 0.0001f * normal, norm = outside ? normal : -normal;
+							const float r = !outside ? m.ir : (1 / m.ir);
+							if (outside) {
+								E.x *= x_expf(m.absorption[0] * -hit.t);
+								E.y *= x_expf(m.absorption[1] * -hit.t);
+								E.z *= x_expf(m.absorption[2] * -hit.t);
+							}
+							const f3 reflD = normalize(reflect(D, norm)), reflO = outside ? I + bias : I - bias, reflW = W * (col * kr);
+							if (kr < 1) {
+								if (sp < RT_TRACE_FRAMES) { TraceFrame& f = stack[sp++]; f.kind = 0, f.P = reflO, f.rayD = reflD, f.W = reflW, f.E = E, f.depth = depth - 1; } else *overflow = 2;
+								const f3 refrD = normalize(glass_refract(D, norm, r));
+								O = outside ? I - bias : I + bias, D = refrD, W = W * ((col * E) * (1 - kr));
+							} else O = reflO, D = reflD, W = reflW;
+							depth--, returned = false;
+						} else if (survives && m.type == 2) { // METAL :81-86
+							O = I + normal * 0.001f, D = reflect(D, normal), W = W * (col * E), depth--, returned = false;
+						} else if (survives) { // DIFFUSE :87-122
+							cur.kind = 1, cur.P = I, cur.N = normal, cur.rayD = D, cur.W = W, cur.E = E, cur.sdir = f3(0.0f), cur.mat = matId, cur.nextLight = 0, cur.depth = depth;
+							resume = true, returned = false;
+						}
+					}
+				}
+				if (!returned) continue;
+				// this Trace returned: the innermost frame goes on, or the tree is finished
+				if (sp == 0) break;
+				cur = stack[--sp];
+				if (cur.kind == 0) { O = cur.P, D = cur.rayD, W = cur.W, E = cur.E, depth = cur.depth; continue; }
+				resume = true;
+				continue;
+			}
+			// ---- the light loop of a DIFFUSE hit (:89-106), possibly resumed, then the indirect child (:107-121) ----
+			resume = false;
+			const DMaterial m = S.mats[cur.mat];
+			const f3 col(m.col[0], m.col[1], m.col[2]);
+			bool branched = false;
+			for (int i = cur.nextLight; i < S.nLights; i++) {
+				const f3 pickedPos = light_position(S.lights[i], false, seed); // the flag is clear: a sampled position
+				f3 L = pickedPos - cur.P;
+				const float len2 = dot(L, L);
+				L = normalize(L);
+				const f3 att = diffuse_scatter(m, cur.rayD, L, light_intensity(S.lights[i], cur.P, cur.N, pickedPos), cur.N, cur.E); // before the occlusion test (:97-98)
+				if (!m.raytracer) cur.sdir = RandomInHemisphere(seed, cur.N); // diffuse::scatter's own draw: scatteredDir (template/scene.h:612-614)
+				if (is_occluded_one(S, cur.P + L * 1e-4f, L, sqrtf(len2), st)) continue;
+				Lsum = Lsum + cur.W * ((((1 - m.shinieness) * col * att) * cur.E) * RT_INVPI); // (totCol = totCol * INVPI at :119 scales the whole loop's sum)
+				if (m.shinieness != 0) {
+					cur.nextLight = i + 1;
+					if (sp < RT_TRACE_FRAMES) stack[sp++] = cur; else *overflow = 2;
+					O = cur.P, D = reflect(cur.rayD, cur.N), E = cur.E, depth = cur.depth - 1;
+					W = cur.W * ((((m.shinieness * col)) * cur.E) * RT_INVPI);
+					branched = true;
+					break;
+				}
+			}
+			if (branched) continue;
+			const f3 cos_i(dot(cur.sdir, f3(1.0f))); // float3(dot(scatteredDir, float3((float)N))), N = 1 (:111)
+			O = cur.P, D = cur.sdir, E = cur.E, depth = cur.depth - 1;
+			W = cur.W * ((cos_i * 2) * RT_PI);
+		}
+		R.customOut[sid] = mk4(Lsum, 0.0f);
 	}
 }
 

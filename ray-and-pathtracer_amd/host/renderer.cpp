@@ -203,18 +203,16 @@ static float3 eval(rt_ctx* ctx, int mode, const Ray& ray, int depth, const float
 	check(ctx, rt_trace_batch_energy(ctx, mode, 1, &ray.O.x, &ray.D.x, depth, seed, &energy.x, rgb));
 	return float3(rgb[0], rgb[1], rgb[2]);
 }
-// The device evaluates Trace as Tick calls it (scene.raytracer set: renderer.cpp:268-271) and Sample as Tick calls it (clear: :272-283).
-// The reference's other two combinations -- Trace with the flag clear (Russian roulette + an indirect term, renderer.cpp:33-43,
-// :107-121) and Sample with it set (:143-153) -- are unreachable from Tick and not built on the device (the test tier's CPU
-// checker restates them); asking for one is an error (RT_E_UNSUPPORTED), never the other branch's answer.
+// Trace / Sample on a caller's ray, with scene.raytracer as the Scene holds it: the combinations Tick makes (Trace with the flag set, Sample
+// with it clear) run the wavefront kernels, the other two (renderer.cpp:33-43, 107-121, 143-153) the general kernels (rt_set_scene_raytracer).
 float3 Renderer::Trace(Ray& ray, int depth, float3 energy)
 {
-	if (!scene.raytracer) throw std::runtime_error("rt_amd: RT_E_UNSUPPORTED: Renderer::Trace with scene.raytracer == false (renderer.cpp:33-43, 107-121) is not built on the device; Tick never calls it");
+	check(ctx, rt_set_scene_raytracer(ctx, scene.raytracer ? 1 : 0));
 	return eval(ctx, RT_MODE_WHITTED, ray, depth, energy, seedBase);
 }
 float3 Renderer::Sample(Ray& ray, int depth, float3 energy)
 {
-	if (scene.raytracer) throw std::runtime_error("rt_amd: RT_E_UNSUPPORTED: Renderer::Sample with scene.raytracer == true (renderer.cpp:143-153) is not built on the device; Tick never calls it");
+	check(ctx, rt_set_scene_raytracer(ctx, scene.raytracer ? 1 : 0));
 	return eval(ctx, RT_MODE_PATH, ray, depth, energy, seedBase);
 }
 

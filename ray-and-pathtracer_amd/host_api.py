@@ -27,7 +27,7 @@ RT_SYMBOLS = ["rt_device_count", "rt_create", "rt_destroy", "rt_last_error", "rt
               "rt_build_bvh", "rt_build_bvh_split", "rt_build_tlas", "rt_gather_rows", "rt_gather_begin", "rt_device_of",
               "rt_intersect_scope", "rt_occluded_scope", "rt_sky_color_batch", "rt_trace_batch_energy", "rt_build_info", "rt_tuning_info",
               "rt_qlearn_enable", "rt_qlearn_apply", "rt_qlearn_get_sums", "rt_qlearn_set_sums", "rt_qlearn_get_table", "rt_qlearn_bind_sums",
-              "rt_device_pci_bus_id"]
+              "rt_device_pci_bus_id", "rt_set_scene_raytracer"]
 
 
 class RtQlearnParams(C.Structure):
@@ -89,6 +89,7 @@ def rt_lib():
         L.rt_qlearn_bind_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
         L.rt_gather_begin.argtypes = [C.c_void_p]
+        L.rt_set_scene_raytracer.argtypes = [C.c_void_p, C.c_int]
         L.rt_build_info.restype = C.c_char_p
         L.rt_build_info.argtypes = []
         L.rt_tuning_info.restype = C.c_char_p
@@ -480,6 +481,10 @@ class HostRenderer:
         t = np.zeros((self.hgt, self.w), dtype=np.float32)
         self._rt(self.rt.rt_primary_hits(self.ctx, t_min, _p(obj), _p(t)))
         return obj, t
+
+    def set_scene_raytracer(self, flag):
+        """rt_set_scene_raytracer: -1 the flag follows the function (Trace: set, Sample: clear), 0 / 1 scene.raytracer as the caller holds it"""
+        self._rt(self.rt.rt_set_scene_raytracer(self.ctx, int(flag)))
 
     def trace_batch(self, mode, O, D, depth=4, seed_base=0x12345678, energy=(1, 1, 1)):
         O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)

@@ -315,15 +315,9 @@ def test_trace_batch_and_renderer_surface(scenes, oracle_api, host_api):
     assert np.array_equal(r.trace_batch(host_api.RT_MODE_WHITTED, O[:5], D[:5], depth=0), np.zeros((5, 3), np.float32))
     one = r.trace_one(O[100], D[100], 4, path=False)
     assert np.array_equal(one, got[100])
-    # the flag decides which function Tick calls; the other combination (renderer.cpp:33-43, 107-121, 143-153: unreachable from
-    # Tick, restated in the oracle only) is refused on the preserved surface, never answered by the other branch
-    with pytest.raises(RuntimeError, match="RT_E_UNSUPPORTED"):
-        r.trace_one(O[100], D[100], 4, path=True)
-    r.scene.set_raytracer(False)
-    with pytest.raises(RuntimeError, match="RT_E_UNSUPPORTED"):
-        r.trace_one(O[100], D[100], 4, path=False)
+    # the other combination of function and flag (renderer.cpp:33-43, 107-121, 143-153: unreachable from Tick, reachable through the
+    # preserved surface) is answered by the general kernels, never by the other branch: test_trace_and_sample_with_the_other_flag
     assert np.isfinite(r.trace_one(O[100], D[100], 4, path=True)).all()
-    r.scene.set_raytracer(True)
     # Tick in Whitted mode fills accumulator and pixels
     r.tick()
     acc = r.tick_accumulator()
@@ -571,6 +565,48 @@ def test_members_below_scene_level(name, kw, scenes, oracle_api, host_api):
             r.scene.set_raytracer(True)
             e1, c1 = rel_err(r.trace_one(pO[200], pD[200], 4, path=False, energy=e), orr.trace_rays(0, pO[200:201], pD[200:201], 4, e, seed_base=0x12345678)[0])
             assert c1 and e1.max() <= RADIANCE_TOL
+    r.close()
+
+
+@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("scene3", {"force_diffuse": False}), ("tlas_test2", {})])
+def test_trace_and_sample_with_the_other_flag(name, kw, scenes, oracle_api, host_api):
+    """VERDICT r5 item 6: Renderer::Trace with scene.raytracer == false (Russian roulette at every surface hit, sampled light positions,
+    diffuse::scatter's hemisphere draw and the indirect child it feeds: renderer.cpp:33-43, 107-121) and Renderer::Sample with the flag
+    set (roulette, unsampled lights: :143-153).  Tick never makes these calls; the preserved Trace / Sample surface can.  One lane per
+    call tree on the device (k_trace_general, k_sample_general), held against the oracle's restatement of the same lines on the camera
+    rays of a frame: radiance within the tolerance, non-finite values equal by class.  Materials are built with raytracer == false, as a
+    scene constructed while the flag is clear has them (template/scene.h:605-620 draws only then)."""
+    w, h = 48, 32
+    o = oracle_api.OracleScene()
+    d = scenes.REGISTRY[name](o, rt=False, **kw)
+    r = host_api.HostRenderer(w, h)
+    scenes.REGISTRY[name](r.scene, rt=False, **kw)
+    r.commit()
+    orr = oracle_api.OracleRenderer(o, w, h)
+    O, D = orr.primary_rays()
+    e = (0.9, 0.8, 0.7)
+    for mode, flag in ((host_api.RT_MODE_WHITTED, False), (host_api.RT_MODE_PATH, True)):
+        o.set_raytracer(flag)
+        r.scene.set_raytracer(flag)
+        for depth in (1, 2, 4):
+            ref = orr.trace_rays(mode, O, D, depth, e, seed_base=4242)
+            r.set_scene_raytracer(1 if flag else 0)
+            got = r.trace_batch(mode, O, D, depth=depth, seed_base=4242, energy=e)
+            err, cls_ok = rel_err(got, ref)
+            assert cls_ok and err.max() <= RADIANCE_TOL, (name, mode, depth, err.max())
+            assert np.abs(ref[np.isfinite(ref)]).sum() > 0
+        # the C++ surface sets the flag from its Scene: one ray through rapt::Renderer::Trace / Sample
+        one = r.trace_one(O[700], D[700], 4, path=(mode == host_api.RT_MODE_PATH), energy=e)
+        ref1 = orr.trace_rays(mode, O[700:701], D[700:701], 4, e, seed_base=0x12345678)[0]
+        e1, c1 = rel_err(one, ref1)
+        assert c1 and e1.max() <= RADIANCE_TOL
+    # and the flag can be handed back to the function: Sample as Tick calls it
+    r.set_scene_raytracer(-1)
+    o.set_raytracer(False)
+    ref = orr.trace_rays(host_api.RT_MODE_PATH, O, D, 4, e, seed_base=9)
+    got = r.trace_batch(host_api.RT_MODE_PATH, O, D, depth=4, seed_base=9, energy=e)
+    err, cls_ok = rel_err(got, ref)
+    assert cls_ok and err.max() <= RADIANCE_TOL
     r.close()
 
 
