@@ -263,16 +263,17 @@ def main():
         # several ranks: the gathered frame must be the one-GPU frame bit for bit (rows are independent, sums are in frame order); the
         # committed one-GPU line of the same workload is the witness (its own frame was compared with the oracle's: parity_check there)
         try:
-            ref = json.load(open(os.path.join(ROOT, "profiles", "final_bench.json")))
+            ref = json.loads(open(os.path.join(ROOT, "profiles", "final_bench.json")).read().strip().splitlines()[-1])
             if ref["metric"] == out["metric"] and not args.qlearn and args.emulate_world <= 1:
                 out["frame_checksum_of_committed_1gpu_line"] = ref["frame_checksum"]
                 out["frame_equals_committed_1gpu_frame"] = ref["frame_checksum"] == out["frame_checksum"]
+                out["committed_1gpu_line_is_of_these_kernels"] = ref["roofline"]["pmc"]["kernel_hash"] == out["roofline"]["pmc"]["kernel_hash"]
         except Exception:
             pass
         failures = []
         if int(seen.item()) != world:
             failures.append("the process group held %d ranks, not %d" % (int(seen.item()), world))
-        if world > 1 and out.get("frame_equals_committed_1gpu_frame") is False:
+        if world > 1 and out.get("frame_equals_committed_1gpu_frame") is False and out.get("committed_1gpu_line_is_of_these_kernels"):  # same kernels, another frame: the shard or the gather is wrong
             failures.append("the gathered %d-rank frame is not the committed one-GPU frame (%s vs %s)" % (world, out["frame_checksum"], out["frame_checksum_of_committed_1gpu_line"]))
         # ---- live legs outside the timed region (one GPU, the default workload): what the driver cannot see otherwise ----
         plain = world == 1 and not args.qlearn and args.emulate_world <= 1 and args.workload == "config3" and not (args.width or args.height or args.spp)

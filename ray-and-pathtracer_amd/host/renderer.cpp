@@ -205,14 +205,20 @@ static float3 eval(rt_ctx* ctx, int mode, const Ray& ray, int depth, const float
 }
 // Trace / Sample on a caller's ray, with scene.raytracer as the Scene holds it: the combinations Tick makes (Trace with the flag set, Sample
 // with it clear) run the wavefront kernels, the other two (renderer.cpp:33-43, 107-121, 143-153) the general kernels (rt_set_scene_raytracer).
+// (the flag is the context's only for the duration of the call: direct users of the C ABI keep their own setting's default)
+struct ScopedSceneFlag {
+	rt_ctx* ctx;
+	ScopedSceneFlag(rt_ctx* c, bool raytracer) : ctx(c) { check(c, rt_set_scene_raytracer(c, raytracer ? 1 : 0)); }
+	~ScopedSceneFlag() { (void)rt_set_scene_raytracer(ctx, -1); }
+};
 float3 Renderer::Trace(Ray& ray, int depth, float3 energy)
 {
-	check(ctx, rt_set_scene_raytracer(ctx, scene.raytracer ? 1 : 0));
+	ScopedSceneFlag flag(ctx, scene.raytracer);
 	return eval(ctx, RT_MODE_WHITTED, ray, depth, energy, seedBase);
 }
 float3 Renderer::Sample(Ray& ray, int depth, float3 energy)
 {
-	check(ctx, rt_set_scene_raytracer(ctx, scene.raytracer ? 1 : 0));
+	ScopedSceneFlag flag(ctx, scene.raytracer);
 	return eval(ctx, RT_MODE_PATH, ray, depth, energy, seedBase);
 }
 
