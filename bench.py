@@ -427,6 +427,7 @@ def out_of_cache_leg(args, ha, scenes, device_index):
             rec["traffic"] = int(traffic)
             rec["hbm_GBps"] = round(traffic / (ext_ms * 1e-3) / 1e9, 1)
             rec["frac_of_hbm_peak"] = round(traffic / (ext_ms * 1e-3) / 8e12, 4)
+            rec["frac_of_measured_stream_peak"] = round(traffic / (ext_ms * 1e-3) / 6.29e12, 4)  # 6.29 TB/s: the streaming-read rate MI355X_MICROARCH.md measures on this part: the practical ceiling beside the data sheet's 8 TB/s (SURVEY 8d asks for both)
             rec["counters"] = {"file": "profiles/out_of_cache_pmc.json", "used": True, "profiled_launch_ms": round(k["ms_total"] / k["launches"], 4), "profiled_hbm_TBps": k["hbm_TBps"],
                                "profiled_frac_of_hbm_peak": k["frac_of_8TBps"], "l2_hit_rate": k["l2_hit_rate"], "ta_busy_avg": k["ta_busy_avg"], "ta_busy_max": k["ta_busy_max"]}
         else:

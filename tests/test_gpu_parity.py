@@ -1776,3 +1776,23 @@ def test_host_mirror_builds_on_the_device(name, kw, blas, scenes, oracle_api, ho
     r2.render(host_api.RT_MODE_WHITTED, 0, 1)
     assert np.array_equal(r2.accumulator().view(np.uint32), want.view(np.uint32))
     r2.close()
+
+
+def test_small_entry_points_check_their_arguments(scenes, host_api):
+    """The entry points added in round 6 report bad arguments as errors: rt_set_scene_raytracer (-1, 0, 1 only), rt_device_pci_bus_id (a buffer
+    of 16 bytes at least, a device that exists), rt_gather_begin (a context), rt_qlearn_bind_sums (the sampler on)."""
+    import ctypes as C
+    L = host_api.rt_lib()
+    r = host_api.HostRenderer(16, 8)
+    scenes.REGISTRY["mixed_small"](r.scene)
+    r.commit()
+    for bad in (-2, 2, 7):
+        assert L.rt_set_scene_raytracer(r.ctx, bad) < 0
+    for ok in (0, 1, -1):
+        assert L.rt_set_scene_raytracer(r.ctx, ok) == 0
+    buf = C.create_string_buffer(64)
+    assert L.rt_device_pci_bus_id(0, buf, 8) < 0 and L.rt_device_pci_bus_id(9999, buf, 64) < 0
+    assert L.rt_device_pci_bus_id(0, buf, 64) == 0 and host_api.device_pci_bus_id(0) == buf.value.decode() and ":" in buf.value.decode()
+    assert L.rt_gather_begin(None) < 0 and L.rt_gather_begin(r.ctx) == 0
+    assert L.rt_qlearn_bind_sums(r.ctx, None, None) < 0  # the sampler is off
+    r.close()
