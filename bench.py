@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world N: the rows of rank R instead of rank 0's (the N-GPU step is as "
                     "long as its SLOWEST share: profiles/r04_shares_all_ranks.txt)")
     ap.add_argument("--no-legs", action="store_true", help="skip the live legs outside the timed region (out-of-cache terrain, Tick latency, 1/8 shares); --no-cpu-baseline skips them too")
+    ap.add_argument("--force-legs", action="store_true", help="tests: run the live legs whatever the workload's size")
     ap.add_argument("--ooc-n", type=int, default=2048, help="out-of-cache leg: the terrain is 2 n^2 triangles (2048: 8.4 M, pairs + primitive records 0.94 GB)")
     ap.add_argument("--ooc-spp", type=int, default=16)
     ap.add_argument("--ooc-steps", type=int, default=3)
@@ -276,7 +277,7 @@ def main():
         if world > 1 and out.get("frame_equals_committed_1gpu_frame") is False and out.get("committed_1gpu_line_is_of_these_kernels"):  # same kernels, another frame: the shard or the gather is wrong
             failures.append("the gathered %d-rank frame is not the committed one-GPU frame (%s vs %s)" % (world, out["frame_checksum"], out["frame_checksum_of_committed_1gpu_line"]))
         # ---- live legs outside the timed region (one GPU, the default workload): what the driver cannot see otherwise ----
-        plain = world == 1 and not args.qlearn and args.emulate_world <= 1 and args.workload == "config3" and not (args.width or args.height or args.spp)
+        plain = world == 1 and not args.qlearn and args.emulate_world <= 1 and ((args.workload == "config3" and not (args.width or args.height or args.spp)) or args.force_legs)
         terrain = None
         if plain and not args.no_legs and not args.no_cpu_baseline:  # (profiling runs pass --no-cpu-baseline: their kernel statistics are the timed steps' alone)
             t_legs = time.perf_counter()

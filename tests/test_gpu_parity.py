@@ -517,6 +517,29 @@ def test_bench_line_witnesses_parity(host_api):
     assert cb["kind"] == "port" and 1 <= cb["cores"] <= cb["physical_cores"] and "frames 0..2" in cb["sample"]
 
 
+def test_bench_line_carries_its_live_legs(host_api):
+    """The legs bench.py runs outside the timed region of its default line, here on a small frame and a small terrain:
+    the out-of-cache record (a scene built by rt_build_bvh_split on the device, SURVEY 8(d) bytes over the HIP-event kernel time, the crop's hits
+    against the oracle's bit for bit), the eight 1/8 row shares with their row-set checksums and the projection, Renderer::Tick in both modes,
+    the split of the run into legs, every rank's device."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "160", "--height", "96", "--spp", "3", "--cpu-seconds", "30",
+                                   "--force-legs", "--ooc-n", "96", "--ooc-spp", "2", "--ooc-steps", "2"], cwd=ROOT, timeout=600)
+    d = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][-1])
+    r = d["roofline"]
+    assert r["bound"].startswith("vector-memory") and r["unit"] == "TA busy fraction" and r["pmc"]["used"] is False and r["frac"] is None  # another size: the counter file is not quoted
+    o = r["hbm"]["out_of_cache_live"]
+    assert "rt_build_bvh_split on the device" in o["scene"] and o["steps"] == 2 and o["kernel_ms"] > 0 and o["algorithmic_bytes_per_launch"] > 0 and o["algorithmic_GBps"] > 0
+    assert o["crop_parity"]["bit_exact"] and o["crop_parity"]["rays"] == 4096 and o["crop_parity"]["hits"] > 0
+    sh = d["share_ms"]
+    assert sh["world"] == 8 and len(sh["per_rank"]) == 8 and len(set(sh["row_set_checksums"])) == 8 and sh["slowest"] == max(sh["per_rank"]) and sh["projected_speedup"] > 0
+    tk = d["tick_ms"]
+    assert tk["whitted"] > 0 and tk["path"] > 0 and tk["whitted_pixels_checksum"] != tk["path_pixels_checksum"]
+    assert d["gpu_leg_s"] > 0 and d["cpu_leg_s"] > 0 and d["timed_region_s"] > 0 and len(d["ranks_devices"]) == 1 and ":" in d["ranks_devices"][0]
+    assert d["parity_check"]["ok"] and d["cpu_baseline"]["kind"] == "port"
+
+
 @pytest.mark.parametrize("name,kw", [("tlas_test2", {"mesh": "BigB"}), ("pretty_tlas", {"n_instances": 4}), ("mixed_small", {})])
 def test_members_below_scene_level(name, kw, scenes, oracle_api, host_api):
     """The surface SURVEY.md 8b lists under Scene: bvh::Intersect / IsOccluded (bvh.h:57, :65), tlas::Intersect /
