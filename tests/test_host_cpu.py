@@ -278,3 +278,35 @@ def test_bench_plumbing_without_a_gpu(tmp_path, monkeypatch):
     # one node, N ranks, the rendezvous on 127.0.0.1 with a port the launcher picks itself (no bind-then-close race: ADVICE r5)
     assert argv[:2] == ["--nnodes=1", "--nproc-per-node"] and argv[2] == "3" and "--rdzv-endpoint=127.0.0.1:0" in argv and argv[argv.index("--local-addr") + 1] == "127.0.0.1"
     assert argv[-4:] == ["--gpus", "3", "--steps", "2"] and argv[-5].endswith("bench.py")
+
+
+def test_committed_counter_files_are_of_these_kernel_sources():
+    """bench.py quotes profiles/roofline_pmc.json and profiles/out_of_cache_pmc.json only while they were measured on the tree's kernel sources
+    (kernel_hash over csrc/*.{h,hip,inc}, the Makefile and the library's build / tuning string).  The build string of the committed bench
+    line (profiles/final_bench.json) is the one a default context reports, so the check can be made without a GPU: a kernel edit that was not
+    followed by the counter passes fails HERE, not silently as a null roofline.frac in the driver's run.  And the roofline block recomputes from
+    the files: TA busy fraction = TA busy cycles per launch / the launch time it is given."""
+    import importlib, json, argparse
+    from conftest import ROOT
+    bench = importlib.import_module("bench")
+    line = json.loads(open(os.path.join(ROOT, "profiles", "final_bench.json")).read().strip().splitlines()[-1])
+    build = line["roofline"]["build"]
+    pj = json.load(open(os.path.join(ROOT, "profiles", "roofline_pmc.json")))["by_world"]
+    assert {w["kernel_hash"] for w in pj.values()} == {bench.kernel_hash(build)}, "kernel sources changed since profiles/roofline_pmc.json was measured: run profiles/roofline_passes.sh"
+    ooc = json.load(open(os.path.join(ROOT, "profiles", "out_of_cache_pmc.json")))
+    assert ooc["kernel_hash"] == bench.kernel_hash(build.split(" | ")[0]), "kernel sources changed since profiles/out_of_cache_pmc.json was measured: run profiles/out_of_cache.sh 2048 16 r06"
+    assert line["roofline"]["pmc"]["used"] and line["roofline"]["pmc"]["kernel_hash"] == bench.kernel_hash(build)
+    # the block, recomputed from the committed files and the line's own inputs
+    ha = importlib.import_module("ray-and-pathtracer_amd.host_api")
+    work = line["roofline"]["algorithmic_work_per_step"]
+    near = dict(work, rays_occluded=0, brute_tests=0, light_tests=0)
+    occl = dict(inner_visits=0, prim_tests=0, tlas_inner=0, instance_visits=0, rays_nearest=0, rays_occluded=line["rays_per_step"]["occluded"], brute_tests=0, light_tests=0)
+    args = argparse.Namespace(qlearn=0, workload="config3", steps=line["steps"])
+    rb = bench.roofline_block(args, ha, near, occl, line["roofline"]["avg_launch_ms"], line["roofline"]["launches_per_step"], 1920, 1080, 64, 1,
+                              line["roofline"]["kernel_ms_per_step"], build, line["ms_per_step"] * 1e-3, dict(launches=100, ms=150.0))
+    assert rb["bound"] == line["roofline"]["bound"] and rb["pmc"]["used"]
+    assert abs(rb["frac"] - line["roofline"]["frac"]) < 1e-3 and 0.5 < rb["frac"] <= 1.0
+    k = pj["1"]["kernels"]["k_extend"]
+    assert abs(rb["sides"]["ta_busy"]["live"] - k["ta_busy_avg"] * (k["ms"] / k["launches"]) / line["roofline"]["avg_launch_ms"]) < 1e-3
+    assert rb["sides"]["hbm_algorithmic_demand_over_peak"] > 1 and rb["sides"]["hbm_counter_frac_of_peak"] < 0.2  # demand served by the caches; what HBM really moves
+    assert rb["hbm"]["algorithmic_bytes_per_launch"] == line["roofline"]["hbm"]["algorithmic_bytes_per_launch"]
