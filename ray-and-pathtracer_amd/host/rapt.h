@@ -359,8 +359,8 @@ public:
 	void UseAllDevices();                                  // every device rt_device_count() reports
 	void Init();                                           // renderer.cpp:5-11
 	void Commit();                                         // scene.Commit() on every context
-	float3 Trace(Ray& ray, int depth, float3 energy);      // renderer.cpp:21
-	float3 Sample(Ray& ray, int depth, float3 energy);     // renderer.cpp:128
+	float3 Trace(Ray& ray, int depth, float3 energy);      // renderer.cpp:21   } with scene.raytracer as the Scene holds it: every combination of function
+	float3 Sample(Ray& ray, int depth, float3 energy);     // renderer.cpp:128  } and flag the reference's bodies contain (:33-43, :107-121, :143-153 included)
 	void Tick(float deltaTime);                            // renderer.cpp:240
 	void Shutdown();
 	// Q-learning guided sampling of the indirect bounce in path mode (README.md:36-42 of the reference names Dahm & Keller 2017;
