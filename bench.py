@@ -228,6 +228,7 @@ def main():
     if world > 1:
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
 
+    failures = []
     if rank == 0:
         sec_per_step = dt / args.steps
         value = W * H * spp / sec_per_step / 1e6
@@ -271,7 +272,6 @@ def main():
                 out["committed_1gpu_line_is_of_these_kernels"] = ref["roofline"]["pmc"]["kernel_hash"] == out["roofline"]["pmc"]["kernel_hash"]
         except Exception:
             pass
-        failures = []
         if int(seen.item()) != world:
             failures.append("the process group held %d ranks, not %d" % (int(seen.item()), world))
         if world > 1 and out.get("frame_equals_committed_1gpu_frame") is False and out.get("committed_1gpu_line_is_of_these_kernels"):  # same kernels, another frame: the shard or the gather is wrong
@@ -302,13 +302,12 @@ def main():
             terrain[0].close()
         out["timed_region_s"] = round(dt, 3)
         print(json.dumps(out), flush=True)
-        if failures:
-            r.close()
-            raise SystemExit("bench.py: " + "; ".join(failures))
     r.close()
-    if world > 1:
+    if world > 1:  # (rank 0 leaves through the same barrier as the others before it reports a failure: nobody is left waiting for it)
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and failures:
+        raise SystemExit("bench.py: " + "; ".join(failures))
 
 
 def frame_checksum(acc, rows=None):
