@@ -591,7 +591,7 @@ def test_members_below_scene_level(name, kw, scenes, oracle_api, host_api):
     r.close()
 
 
-@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("scene3", {"force_diffuse": False}), ("tlas_test2", {})])
+@pytest.mark.parametrize("name,kw", [("mixed_small", {}), ("scene3", {"force_diffuse": False}), ("tlas_test2", {}), ("shiny", {"shininess": 0.25})])
 def test_trace_and_sample_with_the_other_flag(name, kw, scenes, oracle_api, host_api):
     """VERDICT r5 item 6: Renderer::Trace with scene.raytracer == false (Russian roulette at every surface hit, sampled light positions,
     diffuse::scatter's hemisphere draw and the indirect child it feeds: renderer.cpp:33-43, 107-121) and Renderer::Sample with the flag
@@ -600,10 +600,12 @@ def test_trace_and_sample_with_the_other_flag(name, kw, scenes, oracle_api, host
     rays of a frame: radiance within the tolerance, non-finite values equal by class.  Materials are built with raytracer == false, as a
     scene constructed while the flag is clear has them (template/scene.h:605-620 draws only then)."""
     w, h = 48, 32
+    # ("shiny": a floor with shinieness != 0 -- the mirror child inside the light loop, renderer.cpp:100-103 / :172-173, on top of everything else)
+    build = (lambda b: _shiny_scene(b, kw["shininess"], False)) if name == "shiny" else (lambda b: scenes.REGISTRY[name](b, rt=False, **kw))
     o = oracle_api.OracleScene()
-    d = scenes.REGISTRY[name](o, rt=False, **kw)
+    d = build(o)
     r = host_api.HostRenderer(w, h)
-    scenes.REGISTRY[name](r.scene, rt=False, **kw)
+    build(r.scene)
     r.commit()
     orr = oracle_api.OracleRenderer(o, w, h)
     O, D = orr.primary_rays()
